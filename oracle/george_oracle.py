@@ -1,0 +1,390 @@
+# -*- coding: utf-8 -*-
+"""
+oracle/george_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU (NumPy/SciPy, IEEE fp64) restatement of the subset of the third-party
+``george`` library that approxposterior's GP-surrogate inner loop touches.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module, and only as the checker / reported CPU baseline.
+The product package (``approxposterior_amd``) never imports it.
+
+Why a restatement: the arithmetic of the hot path lives in ``george`` (PyPI /
+conda-forge, C++/pybind11/Eigen), which is NOT vendored in /root/reference
+(``setup.py:66`` just says ``'george'``, unpinned; approxposterior v0.4 was
+developed against george 0.3.x) and is not installable here (no network).  This
+file restates george 0.3.x's published algorithm for the members the reference
+calls (call sites: ``gpUtils.py:74,78,110,160-178,227,243-254``;
+``utility.py:130-131,177-178,223-224``; ``approx.py:178,431,706-717``).
+
+Parity pin: this oracle is checked in
+``tests/test_oracle_pins.py`` against every known-answer constant the
+reference's own tests hold for the path:
+  * ``tests/test_InitGP.py:43,76``     parameter vector after defaultGP
+  * ``tests/test_GPUtil.py:50,56,62,101,107,113``  AGP/BAPE/Jones utilities
+  * ``tests/test_OptimizeGP.py:50,91`` optimised hyper-parameters
+  * ``tests/test_findNewPoint.py:107`` selected design point (fitAmp=False)
+and, through ``oracle/make_golden.py``, by driving the reference's own
+``gpUtils`` / ``utility`` / ``approx`` modules (imported from /root/reference,
+never copied) on top of it.  "Parity unpinned" items (no reference test
+constrains them): grad_log_likelihood (checked here against finite differences
+only), D > 2, N > 52.
+
+george semantics restated:
+  A.1 parameter vector / names       A.2 ExpSquaredKernel, axis-aligned metric
+  A.3 ``c * kernel`` amplitude convention (log_constant = log(c/ndim), value c)
+  A.4 compute: K + diag(yerr^2 + exp(white_noise)); scipy cholesky(lower=False)
+  A.5 log_likelihood               A.6 grad_log_likelihood
+  A.7 predict (white noise NOT added to k(t,t))
+"""
+
+import numpy as np
+from scipy.linalg import cholesky, cho_solve, LinAlgError
+
+__all__ = ["GP", "ExpSquaredKernel", "ConstantKernel", "Product",
+           "ConstantModel", "kernels"]
+
+
+# ---------------------------------------------------------------------------
+# Parameterised models (george.modeling subset)
+# ---------------------------------------------------------------------------
+
+class ConstantModel(object):
+    """george.modeling.ConstantModel: one parameter ``value``."""
+
+    def __init__(self, value):
+        self.value = float(value)
+
+    def get_value(self, x):
+        return self.value + np.zeros(len(x))
+
+    def __len__(self):
+        return 1
+
+
+def _as_model(obj, default):
+    if obj is None:
+        return ConstantModel(default)
+    if isinstance(obj, ConstantModel):
+        return obj
+    return ConstantModel(float(obj))
+
+
+# ---------------------------------------------------------------------------
+# Kernels
+# ---------------------------------------------------------------------------
+
+class Kernel(object):
+    is_kernel = True
+    ndim = 1
+
+    def __rmul__(self, b):
+        # george: float * kernel -> Product(ConstantKernel(log(c/ndim)), kernel)
+        # (gpUtils.py:165).  The constant kernel is non-stationary in george
+        # and is evaluated as a SUM OVER AXES, so its value is
+        # ndim*exp(log_constant) = c.  Pinned by test_InitGP.py:43 (parameter
+        # 9.78479362 = log(var(y)/2)) together with test_GPUtil.py:50-62.
+        if hasattr(b, "is_kernel"):
+            return Product(b, self)
+        return Product(ConstantKernel(log_constant=np.log(float(b) / self.ndim),
+                                      ndim=self.ndim), self)
+
+    __mul__ = __rmul__
+
+    def __len__(self):
+        return len(self.get_parameter_vector())
+
+
+class ConstantKernel(Kernel):
+    def __init__(self, log_constant, ndim=1):
+        self.log_constant = float(log_constant)
+        self.ndim = int(ndim)
+        self.dirty = True
+
+    def get_parameter_names(self):
+        return ("log_constant",)
+
+    def get_parameter_vector(self):
+        return np.array([self.log_constant])
+
+    def set_parameter_vector(self, v):
+        self.log_constant = float(v[0])
+        self.dirty = True
+
+    def amplitude(self):
+        return self.ndim * np.exp(self.log_constant)
+
+    def get_value(self, x1, x2=None, diag=False):
+        n1 = len(x1)
+        if diag:
+            return np.full(n1, self.amplitude())
+        n2 = n1 if x2 is None else len(x2)
+        return np.full((n1, n2), self.amplitude())
+
+    def get_gradient(self, x1):
+        # d/d log_constant = value
+        n = len(x1)
+        return np.full((n, n, 1), self.amplitude())
+
+
+class ExpSquaredKernel(Kernel):
+    """k(x,x') = exp(-0.5 * sum_d (x_d-x'_d)^2 / M_d), parameters log M_d."""
+
+    def __init__(self, metric, ndim=1):
+        self.ndim = int(ndim)
+        metric = np.atleast_1d(np.asarray(metric, dtype=np.float64))
+        if metric.size == 1 and self.ndim > 1:
+            metric = np.full(self.ndim, float(metric[0]))
+        if metric.size != self.ndim:
+            raise ValueError("Dimension mismatch")
+        self.log_M = np.log(metric)
+        self.dirty = True
+
+    def get_parameter_names(self):
+        return tuple("metric:log_M_%d_%d" % (d, d) for d in range(self.ndim))
+
+    def get_parameter_vector(self):
+        return np.array(self.log_M)
+
+    def set_parameter_vector(self, v):
+        self.log_M = np.array(v, dtype=np.float64)
+        self.dirty = True
+
+    def _r2(self, x1, x2):
+        w = np.exp(-self.log_M)
+        r2 = np.zeros((len(x1), len(x2)))
+        for d in range(self.ndim):
+            diff = x1[:, d][:, None] - x2[:, d][None, :]
+            r2 += diff * diff * w[d]
+        return r2
+
+    def get_value(self, x1, x2=None, diag=False):
+        if diag:
+            return np.ones(len(x1))
+        if x2 is None:
+            x2 = x1
+        return np.exp(-0.5 * self._r2(x1, x2))
+
+    def get_gradient(self, x1):
+        # d k / d log M_d = k * 0.5 * (dx_d)^2 / M_d
+        k = self.get_value(x1)
+        w = np.exp(-self.log_M)
+        g = np.empty((len(x1), len(x1), self.ndim))
+        for d in range(self.ndim):
+            diff = x1[:, d][:, None] - x1[:, d][None, :]
+            g[:, :, d] = k * 0.5 * diff * diff * w[d]
+        return g
+
+
+class Product(Kernel):
+    def __init__(self, k1, k2):
+        self.k1 = k1
+        self.k2 = k2
+        self.ndim = k2.ndim
+
+    @property
+    def dirty(self):
+        return self.k1.dirty or self.k2.dirty
+
+    @dirty.setter
+    def dirty(self, v):
+        self.k1.dirty = v
+        self.k2.dirty = v
+
+    def get_parameter_names(self):
+        return tuple(["k1:" + n for n in self.k1.get_parameter_names()] +
+                     ["k2:" + n for n in self.k2.get_parameter_names()])
+
+    def get_parameter_vector(self):
+        return np.concatenate([self.k1.get_parameter_vector(),
+                               self.k2.get_parameter_vector()])
+
+    def set_parameter_vector(self, v):
+        n1 = len(self.k1)
+        self.k1.set_parameter_vector(v[:n1])
+        self.k2.set_parameter_vector(v[n1:])
+
+    def get_value(self, x1, x2=None, diag=False):
+        return (self.k1.get_value(x1, x2, diag=diag) *
+                self.k2.get_value(x1, x2, diag=diag))
+
+    def get_gradient(self, x1):
+        v1 = self.k1.get_value(x1)
+        v2 = self.k2.get_value(x1)
+        g1 = self.k1.get_gradient(x1) * v2[:, :, None]
+        g2 = self.k2.get_gradient(x1) * v1[:, :, None]
+        return np.concatenate([g1, g2], axis=2)
+
+
+class _KernelsNamespace(object):
+    """Stands in for the ``george.kernels`` module (gpUtils.py:160)."""
+    ExpSquaredKernel = ExpSquaredKernel
+    ConstantKernel = ConstantKernel
+    Product = Product
+
+
+kernels = _KernelsNamespace()
+
+
+# ---------------------------------------------------------------------------
+# GP
+# ---------------------------------------------------------------------------
+
+class GP(object):
+    """Restatement of george.GP with BasicSolver (scipy cholesky/cho_solve)."""
+
+    def __init__(self, kernel=None, fit_kernel=True, mean=None, fit_mean=None,
+                 white_noise=None, fit_white_noise=None, solver=None, **kwargs):
+        self.kernel = kernel
+        self.mean = _as_model(mean, 0.0)
+        self.white_noise = _as_model(white_noise, np.log(1.25e-12))
+        self.fit_mean = bool(fit_mean)
+        self.fit_white_noise = bool(fit_white_noise)
+        self._computed = False
+        self._alpha = None
+        self._y = None
+
+    # -- parameter-vector protocol (Appendix A.1) ---------------------------
+    def get_parameter_names(self):
+        names = []
+        if self.fit_mean:
+            names.append("mean:value")
+        if self.fit_white_noise:
+            names.append("white_noise:value")
+        names += ["kernel:" + n for n in self.kernel.get_parameter_names()]
+        return tuple(names)
+
+    def get_parameter_vector(self):
+        v = []
+        if self.fit_mean:
+            v.append(self.mean.value)
+        if self.fit_white_noise:
+            v.append(self.white_noise.value)
+        return np.concatenate([np.array(v, dtype=np.float64),
+                               self.kernel.get_parameter_vector()])
+
+    def set_parameter_vector(self, p):
+        p = np.asarray(p, dtype=np.float64).ravel()
+        if len(p) != len(self):
+            raise ValueError("dimension mismatch")
+        n = 0
+        if self.fit_mean:
+            self.mean.value = float(p[n]); n += 1
+        if self.fit_white_noise:
+            self.white_noise.value = float(p[n]); n += 1
+        self.kernel.set_parameter_vector(p[n:])
+        self.kernel.dirty = True
+
+    def __len__(self):
+        return int(self.fit_mean) + int(self.fit_white_noise) + len(self.kernel)
+
+    @property
+    def computed(self):
+        return self._computed and not self.kernel.dirty
+
+    # -- helpers ------------------------------------------------------------
+    def parse_samples(self, t):
+        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        if t.ndim == 1:
+            t = t[:, None]
+        if t.ndim != 2 or t.shape[1] != self.kernel.ndim:
+            raise ValueError("Dimension mismatch")
+        return np.ascontiguousarray(t)
+
+    def _check_dimensions(self, y):
+        n = len(self._x)
+        y = np.atleast_1d(np.asarray(y, dtype=np.float64))
+        if y.shape[0] != n:
+            raise ValueError("Dimension mismatch")
+        return y
+
+    # -- compute / recompute (Appendix A.4) ----------------------------------
+    def compute(self, x, yerr=0.0, **kwargs):
+        self._x = self.parse_samples(x)
+        self._yerr2 = float(yerr) ** 2 * np.ones(len(self._x))
+        yerr_eff = np.sqrt(self._yerr2 + np.exp(self.white_noise.get_value(self._x)))
+        K = self.kernel.get_value(self._x)
+        K[np.diag_indices_from(K)] += yerr_eff ** 2
+        self._factor = (cholesky(K, overwrite_a=True, lower=False), False)
+        self.log_determinant = 2.0 * np.sum(np.log(np.diag(self._factor[0])))
+        self._const = -0.5 * (len(self._x) * np.log(2.0 * np.pi) + self.log_determinant)
+        self._computed = True
+        self.kernel.dirty = False
+        self._alpha = None
+
+    def recompute(self, quiet=False, **kwargs):
+        if self.kernel.dirty or not self._computed:
+            if not hasattr(self, "_x"):
+                raise RuntimeError("You need to compute the model first")
+            try:
+                self.compute(self._x, np.sqrt(self._yerr2[0]) if len(self._yerr2) else 0.0)
+            except (ValueError, LinAlgError):
+                if quiet:
+                    return False
+                raise
+        return True
+
+    def apply_inverse(self, b):
+        return cho_solve(self._factor, b)
+
+    def _compute_alpha(self, y, cache=True):
+        if cache and self._alpha is not None and self._y is not None \
+                and np.array_equal(self._y, y):
+            return self._alpha
+        r = self._check_dimensions(y) - self.mean.get_value(self._x)
+        alpha = self.apply_inverse(np.ascontiguousarray(r))
+        if cache:
+            self._alpha = alpha
+            self._y = np.array(y, dtype=np.float64, copy=True)
+        return alpha
+
+    # -- likelihood (Appendix A.5, A.6) --------------------------------------
+    def log_likelihood(self, y, quiet=False):
+        if not self.recompute(quiet=quiet):
+            return -np.inf
+        try:
+            r = self._check_dimensions(y) - self.mean.get_value(self._x)
+        except ValueError:
+            if quiet:
+                return -np.inf
+            raise
+        ll = self._const - 0.5 * np.dot(r, self.apply_inverse(r))
+        return ll if np.isfinite(ll) else -np.inf
+
+    def grad_log_likelihood(self, y, quiet=False):
+        if not self.recompute(quiet=quiet):
+            return np.zeros(len(self))
+        try:
+            alpha = self._compute_alpha(y, False)
+        except ValueError:
+            if quiet:
+                return np.zeros(len(self))
+            raise
+        n = len(self._x)
+        K_inv = self.apply_inverse(np.eye(n))
+        A = np.outer(alpha, alpha) - K_inv
+        grad = []
+        if self.fit_mean:
+            grad.append(np.sum(alpha))
+        if self.fit_white_noise:
+            grad.append(0.5 * np.exp(self.white_noise.value) * np.trace(A))
+        Kg = self.kernel.get_gradient(self._x)
+        grad += list(0.5 * np.einsum("ijk,ij", Kg, A))
+        return np.array(grad)
+
+    # -- predict (Appendix A.7) ----------------------------------------------
+    def predict(self, y, t, return_cov=True, return_var=False, cache=True):
+        self.recompute()
+        alpha = self._compute_alpha(y, cache)
+        xs = self.parse_samples(t)
+        Kxs = self.kernel.get_value(xs, self._x)
+        mu = np.dot(Kxs, alpha) + self.mean.get_value(xs)
+        if not (return_var or return_cov):
+            return mu
+        KinvKxs = self.apply_inverse(Kxs.T)
+        if return_var:
+            var = self.kernel.get_value(xs, diag=True)
+            var = var - np.sum(Kxs.T * KinvKxs, axis=0)
+            return mu, var
+        cov = self.kernel.get_value(xs)
+        cov -= np.dot(Kxs, KinvKxs)
+        return mu, cov

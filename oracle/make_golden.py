@@ -1,0 +1,248 @@
+# -*- coding: utf-8 -*-
+"""
+oracle/make_golden.py -- TEST INFRASTRUCTURE (build container only).
+
+Generates the golden fixtures under ``tests/golden/`` by driving the REFERENCE's
+own ``gpUtils`` / ``utility`` / ``approx`` / ``likelihood`` modules (imported
+from /root/reference through ``oracle/ref_harness.py``; never copied) on top of
+the george restatement in ``oracle/george_oracle.py``.
+
+A fixture is data only: seeded inputs (theta, y, hyper-parameter vectors,
+candidate sets) and the outputs the reference produced for them (parameter
+vectors/names, per-candidate mu / var / AGP / BAPE / Jones utilities obtained by
+calling the reference's scalar utilities one candidate at a time exactly as
+``minimizeObjective`` does, log-likelihood, its gradient, ``_gpll`` tuples,
+``optimizeGP`` and ``findNextPoint`` results).  Run:
+
+    python -B oracle/make_golden.py
+
+The GPU box never runs this (no /root/reference there); it only reads the
+committed ``tests/golden/*.npz`` / ``*.json``.
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+from ref_harness import load_reference  # noqa: E402
+
+load_reference()
+from approxposterior import utility as ut, gpUtils, likelihood as lh, approx  # noqa: E402
+import george  # noqa: E402  (stub bound to the oracle)
+from scipy.optimize import rosen  # noqa: E402
+
+
+def rosen_set(m0, corners=False, dim=2):
+    """Inputs of the reference's known-answer tests (test_GPUtil.py:30-40)."""
+    theta = np.array(lh.rosenbrockSample(m0, dim) if dim != 2 else lh.rosenbrockSample(m0))
+    if corners:
+        theta = np.array(list(theta) + [[-5, 5], [5, 5]])
+    y = np.zeros(len(theta))
+    for ii in range(len(theta)):
+        y[ii] = lh.rosenbrockLnlike(theta[ii]) + lh.rosenbrockLnprior(theta[ii])
+    return theta, y
+
+
+def f(x):
+    """Reference utilities return float, 0.0, inf or a (1,)-array (Q2)."""
+    return float(np.asarray(x, dtype=float).ravel()[0])
+
+
+def box_prior(lo, hi):
+    def prior(theta):
+        t = np.asarray(theta)
+        if np.any(t < lo) or np.any(t > hi):
+            return -np.inf
+        return 0.0
+    return prior
+
+
+def sweep_case(name, theta, y, gp, cands, lo, hi, meta):
+    """Per-candidate outputs through the reference's scalar utilities."""
+    prior = box_prior(lo, hi)
+    M = len(cands)
+    mu = np.zeros(M); var = np.zeros(M)
+    u_agp = np.zeros(M); u_bape = np.zeros(M); u_jones = np.zeros(M)
+    for i in range(M):
+        t = cands[i]
+        m_, v_ = gp.predict(y, t.reshape(1, -1), return_var=True)
+        mu[i] = m_[0]; var[i] = v_[0]
+        with np.errstate(all="ignore"):
+            u_agp[i] = f(ut.AGPUtility(t, y, gp, prior))
+            u_bape[i] = f(ut.BAPEUtility(t, y, gp, prior))
+            u_jones[i] = f(ut.JonesUtility(t, y, gp, prior))
+    x = gp._x
+    K = gp.kernel.get_value(x)
+    K[np.diag_indices_from(K)] += np.exp(gp.white_noise.value)
+    cond = float(np.linalg.cond(K))
+    ll = gp.log_likelihood(y, quiet=True)
+    grad = gp.grad_log_likelihood(y, quiet=True)
+    alpha = gp._compute_alpha(y, False)
+    out = dict(theta=np.atleast_2d(theta.T).T if theta.ndim == 1 else theta, y=y,
+               p=gp.get_parameter_vector(),
+               names=np.array(gp.get_parameter_names()),
+               white_noise=gp.white_noise.value, cands=cands,
+               lo=np.asarray(lo, dtype=float), hi=np.asarray(hi, dtype=float),
+               mu=mu, var=var, u_agp=u_agp, u_bape=u_bape, u_jones=u_jones,
+               ll=ll, grad=grad, alpha=alpha, logdet=gp.log_determinant,
+               cond=cond, fit_amp=int(hasattr(gp.kernel, "k1")))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    meta[name] = dict(N=int(len(y)), D=int(x.shape[1]), M=int(M), cond=cond,
+                      ll=float(ll))
+    print("wrote", name, meta[name])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    meta = {"generator": "oracle/make_golden.py",
+            "reference": "dflemin3/approxposterior v0.4 (/root/reference)",
+            "george": george.__version__,
+            "shims": ["Q1/Q2: utility.minimize rebound to ravel x0 / float objective"]}
+    pins = {}
+
+    # ---- known-answer constants held by the reference's own tests ----------
+    pins["reference_test_constants"] = {
+        "test_InitGP.py:43": [-31.02658091, 9.78479362, -1.0552327, -1.16092752],
+        "test_InitGP.py:76": [-31.02658091, -1.0552327, -1.16092752],
+        "test_GPUtil.py:50": 31.92055252, "test_GPUtil.py:56": -114623.57332731,
+        "test_GPUtil.py:62": -77.37826545, "test_GPUtil.py:101": 37.41585067,
+        "test_GPUtil.py:107": 76.15271103, "test_GPUtil.py:113": 0.0,
+        "test_OptimizeGP.py:50": [19.99668368, 4.18856645, 10.78000803],
+        "test_OptimizeGP.py:91": [-1.54256578, 3.24723589],
+        "test_findNewPoint.py:60": [-2.03449242, -3.07172107],
+        "test_findNewPoint.py:107": [0.79813416, 0.85542199],
+        "theta_test": [-2.3573, 4.673],
+    }
+
+    # ---- replay of the reference tests on the harness ----------------------
+    replay = {}
+    for amp in (True, False):
+        tag = "amp" if amp else "noamp"
+        np.random.seed(57)
+        theta, y = rosen_set(50)
+        gp = gpUtils.defaultGP(theta, y, fitAmp=amp)
+        replay["initgp_" + tag] = dict(p=gp.get_parameter_vector().tolist(),
+                                       names=list(gp.get_parameter_names()))
+        np.random.seed(57)
+        theta, y = rosen_set(20)
+        gp = gpUtils.defaultGP(theta, y, fitAmp=amp)
+        tt = np.array([-2.3573, 4.673])
+        replay["util_" + tag] = dict(
+            theta=theta.tolist(), y=y.tolist(), p=gp.get_parameter_vector().tolist(),
+            agp=f(ut.AGPUtility(tt, y, gp, lh.rosenbrockLnprior)),
+            bape=f(ut.BAPEUtility(tt, y, gp, lh.rosenbrockLnprior)),
+            jones=f(ut.JonesUtility(tt, y, gp, lh.rosenbrockLnprior)))
+        np.random.seed(57)
+        theta, y = rosen_set(50)
+        gp = gpUtils.defaultGP(theta, y, fitAmp=amp)
+        with np.errstate(all="ignore"):
+            gp = gpUtils.optimizeGP(gp, theta, y, seed=57, nGPRestarts=5)
+        replay["optgp_" + tag] = dict(p=gp.get_parameter_vector().tolist(),
+                                      ll=float(gp.log_likelihood(y, quiet=True)))
+        # findNextPoint (test_findNewPoint.py)
+        np.random.seed(57)
+        theta, y = rosen_set(50, corners=True)
+        gp = gpUtils.defaultGP(theta, y, fitAmp=amp)
+        apo = approx.ApproxPosterior(theta=theta, y=y, gp=gp,
+                                     lnprior=lh.rosenbrockLnprior,
+                                     lnlike=lh.rosenbrockLnlike,
+                                     priorSample=lh.rosenbrockSample,
+                                     bounds=((-5, 5), (-5, 5)), algorithm="bape")
+        with np.errstate(all="ignore"):
+            thetaT = apo.findNextPoint(computeLnLike=False, bounds=((-5, 5), (-5, 5)),
+                                       seed=57)
+        replay["findnext_" + tag] = dict(thetaT=np.asarray(thetaT).tolist(),
+                                         p=gp.get_parameter_vector().tolist())
+        # _gpll guard cases (approx.py:148-189)
+        gpll = []
+        for t in ([0.5, 0.5], [-2.3573, 4.673], [6.0, 0.0], [np.inf, np.nan],
+                  [np.nan, 1.0]):
+            with np.errstate(all="ignore"):
+                try:
+                    r = apo._gpll(np.array(t))
+                except Exception as e:  # pragma: no cover
+                    r = ("raise", type(e).__name__)
+            gpll.append(dict(theta=[None if not np.isfinite(v) else v for v in t],
+                             theta_repr=[repr(float(v)) for v in t],
+                             out=[repr(float(np.ravel(v)[0])) if not isinstance(v, str) else v
+                                  for v in r]))
+        replay["gpll_" + tag] = gpll
+    pins["harness_replay"] = replay
+
+    # ---- per-candidate sweep fixtures --------------------------------------
+    rng = np.random.RandomState(1234)
+
+    # S1/S2: 2-D Rosenbrock, N=50, default (seeded) hypers, with / without amp.
+    for amp in (False, True):
+        np.random.seed(57)
+        theta, y = rosen_set(50)
+        gp = gpUtils.defaultGP(theta, y, fitAmp=amp)
+        cands = rng.uniform(-5.5, 5.5, size=(192, 2))
+        cands[:8] = theta[:8] + 1e-3  # near-training points: tiny variance
+        cands[8] = theta[3]           # exact training point: var ~ white noise
+        sweep_case("rosen2d_n50_" + ("amp" if amp else "noamp"), theta, y, gp, cands,
+                   [-5, -5], [5, 5], meta)
+
+    # S3: 2-D Rosenbrock, N=50, optimised hypers (fitAmp=False: cond ~ 5e3).
+    np.random.seed(57)
+    theta, y = rosen_set(50)
+    gp = gpUtils.defaultGP(theta, y, fitAmp=False)
+    with np.errstate(all="ignore"):
+        gp = gpUtils.optimizeGP(gp, theta, y, seed=57, nGPRestarts=2)
+    cands = rng.uniform(-5.5, 5.5, size=(192, 2))
+    sweep_case("rosen2d_n50_noamp_opt", theta, y, gp, cands, [-5, -5], [5, 5], meta)
+
+    # S4: C2-small -- 2-D Rosenbrock, N=200 (not a multiple of any tile).
+    np.random.seed(57)
+    theta, y = rosen_set(200)
+    gp = gpUtils.defaultGP(theta, y, fitAmp=False)
+    gp.set_parameter_vector([np.median(y), np.log(2.0), np.log(3.0)])
+    gp.recompute()
+    cands = rng.uniform(-5.2, 5.2, size=(300, 2))
+    sweep_case("c2small_d2_n200", theta, y, gp, cands, [-5, -5], [5, 5], meta)
+
+    # S5: C3-small -- synthetic D=8, N=300, BASELINE.md section 4 recipe.
+    rs = np.random.RandomState(0)
+    X = rs.uniform(-5, 5, size=(300, 8))
+    y8 = np.array([-rosen(x) / 100.0 for x in X])
+    kernel = george.kernels.ExpSquaredKernel(metric=np.full(8, 8.0), ndim=8)
+    gp = george.GP(kernel=kernel, fit_mean=True, mean=np.median(y8),
+                   white_noise=-12, fit_white_noise=False)
+    gp.compute(X)
+    cands = np.random.RandomState(1).uniform(-5.2, 5.2, size=(320, 8))
+    sweep_case("c3small_d8_n300", X, y8, gp, cands, [-5] * 8, [5] * 8, meta)
+
+    # S6: D=5 (padded feature dim), N=130, with amplitude, anisotropic metric.
+    rs = np.random.RandomState(5)
+    X = rs.uniform(-5, 5, size=(130, 5))
+    y5 = np.array([-rosen(x) / 100.0 for x in X])
+    kernel = 2.5 * george.kernels.ExpSquaredKernel(metric=[3.0, 5.0, 8.0, 2.0, 6.0], ndim=5)
+    gp = george.GP(kernel=kernel, fit_mean=True, mean=np.median(y5),
+                   white_noise=-12, fit_white_noise=False)
+    gp.compute(X)
+    cands = rs.uniform(-5.2, 5.2, size=(257, 5))
+    sweep_case("d5_n130_amp", X, y5, gp, cands, [-5] * 5, [5] * 5, meta)
+
+    # S7: D=1 Bayesian-optimisation test function (likelihood.py:120-170), Jones.
+    np.random.seed(91)
+    th1 = np.array(lh.testBOFnSample(12))
+    y1 = np.array([lh.testBOFn(t) + lh.testBOFnLnPrior(t) for t in th1])
+    gp = gpUtils.defaultGP(th1, y1, fitAmp=True)
+    cands = np.linspace(-1.2, 2.2, 150).reshape(-1, 1)
+    sweep_case("bo1d_n12_amp", th1, y1, gp, cands, [-1], [2], meta)
+
+    with open(os.path.join(OUT, "pins.json"), "w") as fh:
+        json.dump(pins, fh, indent=1)
+    with open(os.path.join(OUT, "meta.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
