@@ -1,0 +1,195 @@
+// K4 "grad": gradient of the GP log-likelihood with respect to the kernel
+// hyper-parameters, george GP.grad_log_likelihood semantics
+// (gpUtils._grad_nll, gpUtils.py:83-111):
+//   g_mean = sum(alpha)
+//   g_k    = 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta_k
+//   dK/dlog_constant = amp * k_se           (white noise excluded)
+//   dK/dlog_M_d      = K * 0.5 * dx_d^2 / M_d
+// K^-1 = W^T W (W = L^-1) is formed with an MFMA-f64 GEMM; K and dK are
+// regenerated in registers from X (no N x N x P tensor in HBM).
+#include "apgp_common.h"
+
+// Kinv[i][j] = sum_{k >= max(i,j)} W[k][i] W[k][j]   (W lower triangular)
+struct SyrkArgs {
+    const double* W;
+    double* Kinv;
+    long long ldw, np, n;
+};
+
+__global__ __launch_bounds__(256) void syrk_wtw_kernel(SyrkArgs a) {
+    __shared__ double As[16][80];   // W[k][i0 + .]  (k-major: A^T tile)
+    __shared__ double Bs[16][80];   // W[k][j0 + .]
+    const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const long long k0 = i0 > j0 ? i0 : j0;
+    for (long long kk = k0; kk < a.np; kk += 16) {
+        const int kr = t >> 4, cq = (t & 15) * 4;
+        const double* pa = a.W + (kk + kr) * a.ldw + i0 + cq;
+        const double* pb = a.W + (kk + kr) * a.ldw + j0 + cq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { As[kr][cq + e] = pa[e]; Bs[kr][cq + e] = pb[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[ks * 4 + (lane >> 4)][wr + 16 * i + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[ks * 4 + (lane >> 4)][wc + 16 * j + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                long long gr = i0 + wr + 16 * i + (lane >> 4) + 4 * rg;
+                long long gc = j0 + wc + 16 * j + (lane & 15);
+                if (gr < a.n && gc < a.n) a.Kinv[gr * a.n + gc] = acc[i][j][rg];
+            }
+}
+
+struct GradArgs {
+    const double* X;
+    const double* alpha;
+    const double* Kinv;
+    double* partial;     // nblocks x (1 + DPAD)
+    long long n;
+    KernConst kc;
+};
+
+template <int DPAD>
+__global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
+    __shared__ double xi[64][DPAD + 1];
+    __shared__ double xj[64][DPAD + 1];
+    __shared__ double ai[64], aj[64];
+    __shared__ double red[4][1 + DPAD];
+    const int t = threadIdx.x;
+    const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
+    for (int e = t; e < 64 * DPAD; e += 256) {
+        int r = e / DPAD, d = e % DPAD;
+        long long gi = i0 + r, gj = j0 + r;
+        double vi = 0.0, vj = 0.0;
+        if (d < a.kc.ndim) {
+            if (gi < a.n) vi = a.X[gi * a.kc.ndim + d] * a.kc.sc[d];
+            if (gj < a.n) vj = a.X[gj * a.kc.ndim + d] * a.kc.sc[d];
+        }
+        xi[r][d] = vi;
+        xj[r][d] = vj;
+    }
+    if (t < 64) {
+        ai[t] = (i0 + t < a.n) ? a.alpha[i0 + t] : 0.0;
+        aj[t] = (j0 + t < a.n) ? a.alpha[j0 + t] : 0.0;
+    }
+    __syncthreads();
+    const int c = t & 63, g = t >> 6;
+    double xc[DPAD];
+#pragma unroll
+    for (int d = 0; d < DPAD; ++d) xc[d] = xj[c][d];
+    const long long gj = j0 + c;
+    double gsum[1 + DPAD];
+#pragma unroll
+    for (int p = 0; p < 1 + DPAD; ++p) gsum[p] = 0.0;
+    for (int q = 0; q < 16; ++q) {
+        const int r = g + 4 * q;
+        const long long gi = i0 + r;
+        if (gi < a.n && gj < a.n) {
+            double df2[DPAD];
+            double s = -a.kc.log_amp;
+#pragma unroll
+            for (int d = 0; d < DPAD; ++d) {
+                double df = xi[r][d] - xc[d];
+                df2[d] = df * df;
+                s = fma(df, df, s);
+            }
+            const double k = exp(-s);
+            const double A = ai[r] * aj[c] - a.Kinv[gi * a.n + gj];
+            const double Ak = A * k;
+            gsum[0] += Ak;
+#pragma unroll
+            for (int d = 0; d < DPAD; ++d) gsum[1 + d] = fma(Ak, df2[d], gsum[1 + d]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 1 + DPAD; ++p) {
+        double v = gsum[p];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((t & 63) == 0) red[g][p] = v;
+    }
+    __syncthreads();
+    if (t < 1 + DPAD) {
+        double v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        const long long blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        a.partial[blk * (1 + DPAD) + t] = v;
+    }
+}
+
+// out[0] = sum alpha ; out[1] = 0.5 * sum A K ; out[2+d] = 0.5 * sum A K dx_d^2 w_d / 2
+__global__ __launch_bounds__(1024) void grad_final_kernel(const double* partial, long long nblk, int pw,
+                                                          const double* alpha, long long n, int ndim,
+                                                          double* out) {
+    __shared__ double red[16];
+    const int t = threadIdx.x;
+    for (int p = 0; p <= pw; ++p) {   // p == pw: sum(alpha)
+        double v = 0.0;
+        if (p < pw) for (long long b = t; b < nblk; b += 1024) v += partial[b * pw + p];
+        else for (long long i = t; i < n; i += 1024) v += alpha[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((t & 63) == 0) red[t >> 6] = v;
+        __syncthreads();
+        if (t == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 16; ++i) s += red[i];
+            if (p == pw) out[0] = s;
+            else if (p == 0) out[1] = 0.5 * s;
+            else if (p - 1 < ndim) out[2 + (p - 1)] = 0.5 * s;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int64_t apgp_grad_work_len(int64_t n) {
+    int64_t nb = (n + 63) / 64;
+    return n * n + nb * nb * (1 + APGP_MAX_DIM);
+}
+
+extern "C" int apgp_grad_loglik(const double* X, const double* alpha, const double* winv, int64_t ldw,
+                                int64_t n, const apgp_kernel_t* kern, double* work, double* out,
+                                void* stream) {
+    APGP_CHECK_ARG(X && alpha && winv && kern && work && out, "null pointer");
+    APGP_CHECK_ARG(n >= 1, "n >= 1 required");
+    const long long np = apgp_round_up(n, 64);
+    APGP_CHECK_ARG(ldw >= np, "winv must be the padded dense inverse left in apgp_trtri_pack's work buffer");
+    GradArgs g;
+    APGP_CHECK_ARG(apgp_make_kernconst(kern, &g.kc) == 0, "kernel parameters");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nb = (unsigned)(np / 64);
+    SyrkArgs sa;
+    sa.W = winv; sa.Kinv = work; sa.ldw = ldw; sa.np = np; sa.n = n;
+    hipLaunchKernelGGL(syrk_wtw_kernel, dim3(nb, nb), dim3(256), 0, s, sa);
+    g.X = X; g.alpha = alpha; g.Kinv = work; g.partial = work + n * n; g.n = n;
+    const int pw = 1 + g.kc.dpad;
+    switch (g.kc.dpad) {
+        case 2: hipLaunchKernelGGL(grad_tile_kernel<2>, dim3(nb, nb), dim3(256), 0, s, g); break;
+        case 4: hipLaunchKernelGGL(grad_tile_kernel<4>, dim3(nb, nb), dim3(256), 0, s, g); break;
+        case 8: hipLaunchKernelGGL(grad_tile_kernel<8>, dim3(nb, nb), dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL(grad_tile_kernel<16>, dim3(nb, nb), dim3(256), 0, s, g); break;
+    }
+    hipLaunchKernelGGL(grad_final_kernel, dim3(1), dim3(1024), 0, s, (const double*)g.partial,
+                       (long long)nb * nb, pw, alpha, (long long)n, g.kc.ndim, out);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,87 @@
+// K1 "gram": N x N squared-exponential Gram matrix, LDS-tiled, coalesced row
+// writes.  HBM-write-bound (8 N^2 bytes out, 8 N D bytes in).
+// Reference semantics: george ExpSquaredKernel.get_value + the diagonal update
+// of GP.compute (called from gpUtils.py:178,244,254; approx.py:717).
+#include "apgp_common.h"
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void apgp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* apgp_last_error(void) { return g_err; }
+extern "C" int apgp_abi_version(void) { return APGP_ABI_VERSION; }
+
+struct GramArgs {
+    const double* X;
+    double* K;
+    long long n, ldk;
+    KernConst kc;
+};
+
+// 64 x 64 output tile per workgroup, 256 threads: thread = (column c, row
+// group g); each thread produces 16 rows of its column so that a wavefront
+// writes 64 consecutive doubles (512 B) of one row at a time.
+template <int DPAD>
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+    __shared__ double xi[64][DPAD + 1];
+    __shared__ double xj[64][DPAD + 1];
+    const int t = threadIdx.x;
+    const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
+    for (int e = t; e < 64 * DPAD; e += 256) {
+        int r = e / DPAD, d = e % DPAD;
+        long long gi = i0 + r, gj = j0 + r;
+        double vi = 0.0, vj = 0.0;
+        if (d < a.kc.ndim) {
+            if (gi < a.n) vi = a.X[gi * a.kc.ndim + d] * a.kc.sc[d];
+            if (gj < a.n) vj = a.X[gj * a.kc.ndim + d] * a.kc.sc[d];
+        }
+        xi[r][d] = vi;
+        xj[r][d] = vj;
+    }
+    __syncthreads();
+    const int c = t & 63, g = t >> 6;
+    double xc[DPAD];
+#pragma unroll
+    for (int d = 0; d < DPAD; ++d) xc[d] = xj[c][d];
+    const long long gj = j0 + c;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int r = g + 4 * q;
+        const long long gi = i0 + r;
+        double s = -a.kc.log_amp;
+#pragma unroll
+        for (int d = 0; d < DPAD; ++d) {
+            double df = xi[r][d] - xc[d];
+            s = fma(df, df, s);
+        }
+        double k = exp(-s);
+        if (gi == gj) k += a.kc.diag_add;
+        if (gi < a.n && gj < a.n) a.K[gi * a.ldk + gj] = k;
+    }
+}
+
+extern "C" int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern, double* K,
+                         int64_t ldk, void* stream) {
+    APGP_CHECK_ARG(X && K && kern, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && ldk >= n, "n >= 1 and ldk >= n required");
+    GramArgs a;
+    APGP_CHECK_ARG(apgp_make_kernconst(kern, &a.kc) == 0, "kernel parameters");
+    a.X = X; a.K = K; a.n = n; a.ldk = ldk;
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (a.kc.dpad) {
+        case 2: hipLaunchKernelGGL(gram_kernel<2>, grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL(gram_kernel<4>, grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL(gram_kernel<8>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(gram_kernel<16>, grid, block, 0, s, a); break;
+    }
+    APGP_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,431 @@
+// K2/K3 + factor-side helpers: log-determinant, triangular solves, blocked
+// triangular inversion (MFMA-f64 GEMM merges) and the packed layouts the sweep
+// kernel streams.  Reference semantics: george BasicSolver.compute /
+// apply_inverse (scipy cholesky + cho_solve) as used by GP.log_likelihood,
+// GP._compute_alpha and GP.predict (gpUtils.py:78; utility.py:131,178,224).
+#include "apgp_common.h"
+
+// ---------------------------------------------------------------------------
+// sizes
+// ---------------------------------------------------------------------------
+extern "C" int64_t apgp_npad(int64_t n) { return apgp_round_up(n, APGP_ROW_BLOCK); }
+
+extern "C" int64_t apgp_packed_linv_len(int64_t n) {
+    int64_t nrb = apgp_npad(n) / APGP_ROW_BLOCK;
+    // row block ib holds (ib+1)*4 tiles of 128 x 32 doubles
+    return 2 * nrb * (nrb + 1) * (int64_t)(APGP_ROW_BLOCK * APGP_K_CHUNK);
+}
+
+extern "C" int64_t apgp_packed_train_len(int64_t n, int32_t ndim) {
+    return apgp_npad(n) * apgp_xs_stride(ndim);
+}
+
+extern "C" int64_t apgp_trtri_work_len(int64_t n) {
+    int64_t np = apgp_round_up(n, 64);
+    return 2 * np * np;
+}
+
+// ---------------------------------------------------------------------------
+// K2: logdet + diagonal range.  One workgroup; the diagonal is N doubles.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void logdet_kernel(const double* L, long long n, long long ldl,
+                                                      double* out) {
+    __shared__ double ssum[16], smin[16], smax[16];
+    double s = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        double d = L[i * ldl + i];
+        s += log(d);
+        mn = fmin(mn, d);
+        mx = fmax(mx, d);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        mn = fmin(mn, __shfl_xor(mn, o));
+        mx = fmax(mx, __shfl_xor(mx, o));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { ssum[w] = s; smin[w] = mn; smax[w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = 0.0; mn = INFINITY; mx = -INFINITY;
+        for (int i = 0; i < 16; ++i) { s += ssum[i]; mn = fmin(mn, smin[i]); mx = fmax(mx, smax[i]); }
+        out[0] = 2.0 * s;
+        out[1] = mn;
+        out[2] = mx;
+    }
+}
+
+extern "C" int apgp_logdet(const double* L, int64_t n, int64_t ldl, double* out3, void* stream) {
+    APGP_CHECK_ARG(L && out3, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, (long long)n,
+                       (long long)ldl, out3);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// K3: triangular solve with the lower Cholesky factor, one workgroup.
+// The right-hand side lives in LDS for the whole solve; the factor's lower
+// triangle is streamed once (8 * N^2/2 bytes).
+// ---------------------------------------------------------------------------
+#define TRSV_B 64
+struct TrsvArgs {
+    const double* L;
+    const double* b;
+    double* x;
+    double* sumsq;
+    long long n, ldl;
+    double shift;
+    int trans;
+};
+
+__global__ __launch_bounds__(1024) void trsv_kernel(TrsvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* r = smem;                                   // n (rounded up to 64)
+    const long long n = a.n;
+    const long long nr = (n + 63) / 64 * 64;
+    double (*Lb)[TRSV_B + 1] = (double (*)[TRSV_B + 1])(smem + nr);   // 64 x 65
+    double* red = smem + nr + TRSV_B * (TRSV_B + 1);    // 16 x 64 partials / 16 sums
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    for (long long i = t; i < nr; i += 1024) r[i] = i < n ? a.b[i] - a.shift : 0.0;
+    __syncthreads();
+    const long long nb = (n + TRSV_B - 1) / TRSV_B;
+
+    if (!a.trans) {
+        // forward, left-looking: r_blk -= L[blk, 0:j0] z[0:j0]; then 64x64 solve
+        for (long long jb = 0; jb < nb; ++jb) {
+            const long long j0 = jb * TRSV_B;
+            const int row = t >> 4, part = t & 15;       // 64 rows x 16 threads
+            const long long gi = j0 + row;
+            double acc = 0.0;
+            if (gi < n) {
+                const double* lrow = a.L + gi * a.ldl;
+                for (long long k = part * 2; k < j0; k += 32) {
+                    acc = fma(lrow[k], r[k], acc);
+                    acc = fma(lrow[k + 1], r[k + 1], acc);
+                }
+            }
+            acc += __shfl_xor(acc, 8);
+            acc += __shfl_xor(acc, 4);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 1);
+            // stage the diagonal block
+            for (int e = t; e < TRSV_B * TRSV_B; e += 1024) {
+                int i = e >> 6, k = e & 63;
+                long long gr = j0 + i, gc = j0 + k;
+                double v = (i == k) ? 1.0 : 0.0;
+                if (gr < n && gc < n && k <= i) v = a.L[gr * a.ldl + gc];
+                Lb[i][k] = v;
+            }
+            __syncthreads();   // all reads of r[0:j0] done, Lb staged
+            if (part == 0 && gi < n) r[gi] -= acc;
+            __syncthreads();
+            if (t < 64) {
+                double ri = r[j0 + lane];
+                for (int k = 0; k < TRSV_B; ++k) {
+                    double zk = __shfl(ri, k) / Lb[k][k];
+                    if (lane == k) ri = zk;
+                    else if (lane > k) ri = fma(-Lb[lane][k], zk, ri);
+                }
+                r[j0 + lane] = ri;
+            }
+            __syncthreads();
+        }
+    } else {
+        // backward (L^T x = r), right-looking over row blocks from the bottom
+        for (long long jb = nb - 1; jb >= 0; --jb) {
+            const long long j0 = jb * TRSV_B;
+            for (int e = t; e < TRSV_B * TRSV_B; e += 1024) {
+                int i = e >> 6, k = e & 63;
+                long long gr = j0 + i, gc = j0 + k;
+                double v = (i == k) ? 1.0 : 0.0;
+                if (gr < n && gc < n && k <= i) v = a.L[gr * a.ldl + gc];
+                Lb[i][k] = v;
+            }
+            __syncthreads();
+            if (t < 64) {
+                double ri = r[j0 + lane];
+                for (int k = TRSV_B - 1; k >= 0; --k) {
+                    double xk = __shfl(ri, k) / Lb[k][k];
+                    if (lane == k) ri = xk;
+                    else if (lane < k) ri = fma(-Lb[k][lane], xk, ri);   // (L^T)[lane][k] = L[k][lane]
+                }
+                r[j0 + lane] = ri;
+            }
+            __syncthreads();
+            // r[c] -= sum_k L[j0+k, c] x_k  for c < j0  (coalesced along c)
+            const long long kmax = (n - j0) < TRSV_B ? (n - j0) : TRSV_B;
+            for (long long c = t; c < j0; c += 1024) {
+                double acc = 0.0;
+                const double* lcol = a.L + j0 * a.ldl + c;
+#pragma unroll 8
+                for (long long k = 0; k < kmax; ++k) acc = fma(lcol[k * a.ldl], r[j0 + k], acc);
+                r[c] -= acc;
+            }
+            __syncthreads();
+        }
+    }
+    double ss = 0.0;
+    for (long long i = t; i < n; i += 1024) {
+        double v = r[i];
+        a.x[i] = v;
+        ss = fma(v, v, ss);
+    }
+    if (a.sumsq) {
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) red[t >> 6] = ss;
+        __syncthreads();
+        if (t == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 16; ++i) s += red[i];
+            *a.sumsq = s;
+        }
+    }
+}
+
+extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
+                         int trans, double* x, double* sumsq, void* stream) {
+    APGP_CHECK_ARG(L && b && x, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    APGP_CHECK_ARG(n <= 15360, "n <= 15360 (right-hand side is kept in LDS)");
+    TrsvArgs a;
+    a.L = L; a.b = b; a.x = x; a.sumsq = sumsq; a.n = n; a.ldl = ldl; a.shift = shift;
+    a.trans = trans;
+    size_t nr = (size_t)apgp_round_up(n, 64);
+    size_t lds = (nr + TRSV_B * (TRSV_B + 1) + 16 * 64) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)trsv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(trsv_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, a);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Triangular inversion W = L^-1.
+//   (1) invert every 64x64 diagonal block (one wavefront per block, LDS);
+//   (2) log2 merge levels: for adjacent blocks A (first) and B (second) with
+//       C = L[second, first]:  W[second, first] = -B^-1 (C A^-1)
+//       as two MFMA-f64 GEMM launches per level that skip the structurally
+//       zero parts of the triangular operands;
+//   (3) pack into the sweep's tile layout.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const double* L, long long n, long long ldl,
+                                                        double* W, long long ldw) {
+    __shared__ double Lb[64][65];
+    __shared__ double Xb[64][65];
+    const long long j0 = (long long)blockIdx.x * 64;
+    const int c = threadIdx.x;
+    for (int i = 0; i < 64; ++i) {
+        long long gr = j0 + i, gc = j0 + c;
+        double v = (i == c) ? 1.0 : 0.0;
+        if (gr < n && gc < n && c <= i) v = L[gr * ldl + gc];
+        Lb[i][c] = v;
+    }
+    __syncthreads();
+    for (int i = 0; i < 64; ++i) {
+        double v;
+        if (i < c) v = 0.0;
+        else if (i == c) v = 1.0 / Lb[c][c];
+        else {
+            double s = 0.0;
+            for (int k = c; k < i; ++k) s = fma(Lb[i][k], Xb[k][c], s);
+            v = -s / Lb[i][i];
+        }
+        Xb[i][c] = v;   // column c is private to this lane
+    }
+    for (int i = 0; i < 64; ++i) W[(j0 + i) * ldw + j0 + c] = Xb[i][c];
+}
+
+struct MergeArgs {
+    const double* L;
+    double* W;
+    double* T;
+    long long ldl, ldw, n;
+    int nb;      // number of 64-blocks
+    int s;       // level: blocks per half
+    int phase;   // 1: T = C * Ainv ; 2: W[second,first] = -Binv * T
+};
+
+// 64 x 64 output tile, 4 wavefronts (2 x 2), each 32 x 32 = 2 x 2 MFMA
+// 16x16x4 f64 tiles; K staged through LDS in chunks of 16.
+__global__ __launch_bounds__(256) void trtri_merge_kernel(MergeArgs a) {
+    __shared__ double As[64][17];
+    __shared__ double Bs[16][80];
+    const int q = blockIdx.z;
+    const long long first0 = (long long)2 * q * a.s;          // in 64-blocks
+    const long long second0 = first0 + a.s;
+    if (second0 >= a.nb) return;
+    const long long rb = second0 + blockIdx.y;               // output row block
+    if (rb >= a.nb || rb >= first0 + 2 * a.s) return;
+    const long long cb = first0 + blockIdx.x;                // output col block
+    const long long r0 = rb * 64, c0 = cb * 64;
+    long long k0, k1;
+    const double *Ap, *Bp;
+    long long lda, ldb;
+    if (a.phase == 1) {   // T[r, c] = sum_k L[r, k] W[k, c], k in first, W lower => k >= c
+        k0 = c0; k1 = second0 * 64;
+        Ap = a.L; lda = a.ldl; Bp = a.W; ldb = a.ldw;
+    } else {              // W[r, c] = -sum_k W[r, k] T[k, c], k in second, W lower => k <= r
+        k0 = second0 * 64; k1 = r0 + 64;
+        Ap = a.W; lda = a.ldw; Bp = a.T; ldb = a.ldw;
+    }
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (long long kk = k0; kk < k1; kk += 16) {
+        {   // A tile: 64 rows x 16 k ; thread -> (row = t>>2, 4 consecutive k)
+            int row = t >> 2, kq = (t & 3) * 4;
+            const double* p = Ap + (r0 + row) * lda + kk + kq;
+            const bool ok = (a.phase != 1) || (r0 + row < a.n);   // L has only n rows
+            As[row][kq + 0] = ok ? p[0] : 0.0; As[row][kq + 1] = ok ? p[1] : 0.0;
+            As[row][kq + 2] = ok ? p[2] : 0.0; As[row][kq + 3] = ok ? p[3] : 0.0;
+        }
+        {   // B tile: 16 k x 64 cols ; thread -> (k = t>>4, 4 consecutive cols)
+            int kr = t >> 4, cq = (t & 15) * 4;
+            const double* p = Bp + (kk + kr) * ldb + c0 + cq;
+            Bs[kr][cq + 0] = p[0]; Bs[kr][cq + 1] = p[1];
+            Bs[kr][cq + 2] = p[2]; Bs[kr][cq + 3] = p[3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[wr + 16 * i + (lane & 15)][ks * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[ks * 4 + (lane >> 4)][wc + 16 * j + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double* Cp = (a.phase == 1) ? a.T : a.W;
+    const double sgn = (a.phase == 1) ? 1.0 : -1.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+                long long gr = r0 + wr + 16 * i + (lane >> 4) + 4 * rg;
+                long long gc = c0 + wc + 16 * j + (lane & 15);
+                Cp[gr * a.ldw + gc] = sgn * acc[i][j][rg];
+            }
+}
+
+// Packed tile (ib, kc): 128 rows x 32 k as [kk 0..7][s 0..7][lane 0..63] with
+// element = W[ib*128 + 16 s + (lane & 15)][kc*32 + 4 kk + (lane >> 4)]
+// (exactly the v_mfma_f64_16x16x4_f64 A-operand order, so the sweep reads one
+// ds_read_b64 per fragment at lane * 8, conflict-free).
+__global__ __launch_bounds__(256) void pack_linv_kernel(const double* W, long long ldw, long long n,
+                                                        double* packed) {
+    const long long tile = blockIdx.x;
+    // invert tile = 2*ib*(ib+1) + kc
+    long long ib = (long long)((sqrt(2.0 * (double)tile + 1.0) - 1.0) * 0.5);
+    while (2 * (ib + 1) * (ib + 2) <= tile) ++ib;
+    while (2 * ib * (ib + 1) > tile) --ib;
+    const long long kc = tile - 2 * ib * (ib + 1);
+    double* out = packed + tile * (long long)(APGP_ROW_BLOCK * APGP_K_CHUNK);
+    for (int e = threadIdx.x; e < APGP_ROW_BLOCK * APGP_K_CHUNK; e += 256) {
+        int lane = e & 63, s = (e >> 6) & 7, kk = e >> 9;
+        long long row = ib * APGP_ROW_BLOCK + 16 * s + (lane & 15);
+        long long col = kc * APGP_K_CHUNK + 4 * kk + (lane >> 4);
+        double v = 0.0;
+        if (row < n && col <= row) v = W[row * ldw + col];
+        out[e] = v;
+    }
+}
+
+extern "C" int apgp_trtri_pack(const double* L, int64_t n, int64_t ldl, double* work,
+                               double* packed, double* winv_dense, void* stream) {
+    APGP_CHECK_ARG(L && work, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    hipStream_t s = (hipStream_t)stream;
+    const long long np = apgp_round_up(n, 64);
+    const int nb = (int)(np / 64);
+    double* W = work;
+    double* T = work + np * np;
+    if (hipMemsetAsync(W, 0, sizeof(double) * np * np, s) != hipSuccess) {
+        apgp_set_error("apgp_trtri_pack: memset failed");
+        return -2;
+    }
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nb), dim3(64), 0, s, L, (long long)n, (long long)ldl, W, np);
+    for (int lev = 1; lev < nb; lev *= 2) {
+        MergeArgs a;
+        a.L = L; a.W = W; a.T = T; a.ldl = ldl; a.ldw = np; a.n = n; a.nb = nb; a.s = lev;
+        int pairs = (nb + 2 * lev - 1) / (2 * lev);
+        dim3 grid(lev, lev, pairs);
+        a.phase = 1;
+        hipLaunchKernelGGL(trtri_merge_kernel, grid, dim3(256), 0, s, a);
+        a.phase = 2;
+        hipLaunchKernelGGL(trtri_merge_kernel, grid, dim3(256), 0, s, a);
+    }
+    if (packed) {
+        long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
+        long long ntiles = 2 * nrb * (nrb + 1);
+        hipLaunchKernelGGL(pack_linv_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, W, np,
+                           (long long)n, packed);
+    }
+    if (winv_dense) {
+        if (hipMemcpy2DAsync(winv_dense, n * sizeof(double), W, np * sizeof(double),
+                             n * sizeof(double), n, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            apgp_set_error("apgp_trtri_pack: copy of dense inverse failed");
+            return -2;
+        }
+    }
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// packed training stream: rows [ x_k * sc (Dpad) | alpha_k | 0 ], zero past N
+// ---------------------------------------------------------------------------
+struct PackTrainArgs {
+    const double* X;
+    const double* alpha;
+    double* xs;
+    long long n, npad;
+    KernConst kc;
+};
+
+__global__ __launch_bounds__(256) void pack_train_kernel(PackTrainArgs a) {
+    const int stride = a.kc.dpad + 2;
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.npad * stride) return;
+    long long k = e / stride;
+    int d = (int)(e % stride);
+    double v = 0.0;
+    if (k < a.n) {
+        if (d < a.kc.ndim) v = a.X[k * a.kc.ndim + d] * a.kc.sc[d];
+        else if (d == a.kc.dpad) v = a.alpha[k];
+    }
+    a.xs[e] = v;
+}
+
+extern "C" int apgp_pack_train(const double* X, const double* alpha, int64_t n,
+                               const apgp_kernel_t* kern, double* xs, void* stream) {
+    APGP_CHECK_ARG(X && alpha && xs && kern, "null pointer");
+    APGP_CHECK_ARG(n >= 1, "n >= 1 required");
+    PackTrainArgs a;
+    APGP_CHECK_ARG(apgp_make_kernconst(kern, &a.kc) == 0, "kernel parameters");
+    a.X = X; a.alpha = alpha; a.xs = xs; a.n = n; a.npad = apgp_npad(n);
+    long long total = a.npad * (a.kc.dpad + 2);
+    hipLaunchKernelGGL(pack_train_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}

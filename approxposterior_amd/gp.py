@@ -1,0 +1,586 @@
+# -*- coding: utf-8 -*-
+"""
+:py:mod:`gp.py` - MI355X-backed drop-in for the ``george.GP`` members that
+approxposterior touches
+--------------------------------------------------------------------------------
+
+The reference (dflemin3/approxposterior) has no plugin/FFI interface: its seam is
+the duck-typed ``george.GP`` instance passed as ``gp=`` (approx.py:77,140-144)
+and re-created at approx.py:712-715.  This module provides objects exposing
+exactly the members the reference calls:
+
+  ``kernels.ExpSquaredKernel(metric, ndim)``, ``float * kernel``   gpUtils.py:160-165
+  ``GP(kernel, fit_mean, mean, white_noise, fit_white_noise)``     gpUtils.py:176-177
+  ``gp.compute(x)`` / ``gp.recompute()``                           gpUtils.py:178,244,254
+  ``set/get_parameter_vector``, ``get_parameter_names``, ``len``   gpUtils.py:74,227,243
+  ``gp.log_likelihood(y, quiet=True)``                             gpUtils.py:78,247
+  ``gp.grad_log_likelihood(y, quiet=True)``                        gpUtils.py:110
+  ``gp.predict(y, t, return_var=True)`` / mean only                utility.py:131; approx.py:178
+  ``gp.computed``, ``gp.kernel``, ``gp.mean``, ``gp.white_noise``  utility.py:130; approx.py:712-714
+
+All arithmetic runs in the hand-written HIP kernels of ``libapgp.so``
+(include/apgp.h) on one MI355X; the Cholesky factorisation is rocSOLVER's
+dpotrf through ``torch.linalg.cholesky_ex``.  PyTorch is otherwise only the
+device allocator / stream provider.  There is no CPU fallback: without a GPU or
+without the built extension every compute entry point raises.
+
+Beyond george's API the GP also offers the batched counterparts the reference
+lacks: ``acquire`` (fused predict + utility + arg-min over a candidate matrix)
+and array-valued ``predict``.
+"""
+
+import ctypes
+
+import numpy as np
+from numpy.linalg import LinAlgError
+
+from . import _lib
+
+__all__ = ["GP", "ExpSquaredKernel", "ConstantKernel", "Product", "ConstantModel",
+           "kernels", "UTILITY_KINDS"]
+
+UTILITY_KINDS = {"agp": _lib.UTIL_AGP, "bape": _lib.UTIL_BAPE, "jones": _lib.UTIL_JONES}
+
+# Above this condition estimate ((max L_ii / min L_ii)^2) the explicit L^-1
+# contraction is no longer trusted for the predictive variance (SURVEY.md
+# section 7, "Conditioning vs. formulation").
+COND_WARN = 1.0e12
+
+
+# ---------------------------------------------------------------------------
+# Host-side parameter objects (no arithmetic lives here)
+# ---------------------------------------------------------------------------
+
+class ConstantModel(object):
+    """Mirror of george.modeling.ConstantModel (``gp.mean``, ``gp.white_noise``)."""
+
+    def __init__(self, value):
+        self.value = float(value)
+
+    def get_value(self, x):
+        return self.value + np.zeros(len(x))
+
+    def __len__(self):
+        return 1
+
+    def __repr__(self):
+        return "ConstantModel(value=%r)" % self.value
+
+
+def _as_model(obj, default):
+    if obj is None:
+        return ConstantModel(default)
+    if isinstance(obj, ConstantModel) or (hasattr(obj, "value") and hasattr(obj, "get_value")):
+        return obj
+    return ConstantModel(float(obj))
+
+
+class Kernel(object):
+    is_kernel = True
+    ndim = 1
+
+    def __rmul__(self, b):
+        # george: ``c * kernel`` -> Product(ConstantKernel(log(c/ndim)), kernel);
+        # the constant kernel evaluates to ndim*exp(log_constant) = c
+        # (gpUtils.py:165; pinned by test_InitGP.py:43 + test_GPUtil.py:50-62).
+        if hasattr(b, "is_kernel"):
+            return Product(b, self)
+        return Product(ConstantKernel(log_constant=np.log(float(b) / self.ndim),
+                                      ndim=self.ndim), self)
+
+    __mul__ = __rmul__
+
+    def __add__(self, other):
+        raise NotImplementedError(
+            "kernel sums (the optional LinearKernel of defaultGP(order=...), "
+            "gpUtils.py:169-173) are not part of the MI355X hot path yet")
+
+    __radd__ = __add__
+
+    def __len__(self):
+        return len(self.get_parameter_vector())
+
+
+class ConstantKernel(Kernel):
+    def __init__(self, log_constant, ndim=1):
+        self.log_constant = float(log_constant)
+        self.ndim = int(ndim)
+        self.dirty = True
+
+    def get_parameter_names(self):
+        return ("log_constant",)
+
+    def get_parameter_vector(self):
+        return np.array([self.log_constant])
+
+    def set_parameter_vector(self, v):
+        self.log_constant = float(v[0])
+        self.dirty = True
+
+
+class ExpSquaredKernel(Kernel):
+    """k(x,x') = exp(-0.5 sum_d (x_d-x'_d)^2 / M_d); parameters are log M_d."""
+
+    def __init__(self, metric, ndim=1):
+        self.ndim = int(ndim)
+        metric = np.atleast_1d(np.asarray(metric, dtype=np.float64))
+        if metric.size == 1 and self.ndim > 1:
+            metric = np.full(self.ndim, float(metric[0]))
+        if metric.size != self.ndim:
+            raise ValueError("Dimension mismatch")
+        self.log_M = np.log(metric)
+        self.dirty = True
+
+    def get_parameter_names(self):
+        return tuple("metric:log_M_%d_%d" % (d, d) for d in range(self.ndim))
+
+    def get_parameter_vector(self):
+        return np.array(self.log_M)
+
+    def set_parameter_vector(self, v):
+        self.log_M = np.array(v, dtype=np.float64)
+        self.dirty = True
+
+
+class Product(Kernel):
+    def __init__(self, k1, k2):
+        self.k1 = k1
+        self.k2 = k2
+        self.ndim = k2.ndim
+
+    @property
+    def dirty(self):
+        return self.k1.dirty or self.k2.dirty
+
+    @dirty.setter
+    def dirty(self, v):
+        self.k1.dirty = v
+        self.k2.dirty = v
+
+    def get_parameter_names(self):
+        return tuple(["k1:" + n for n in self.k1.get_parameter_names()] +
+                     ["k2:" + n for n in self.k2.get_parameter_names()])
+
+    def get_parameter_vector(self):
+        return np.concatenate([self.k1.get_parameter_vector(),
+                               self.k2.get_parameter_vector()])
+
+    def set_parameter_vector(self, v):
+        n1 = len(self.k1)
+        self.k1.set_parameter_vector(v[:n1])
+        self.k2.set_parameter_vector(v[n1:])
+
+
+class _KernelsNamespace(object):
+    """Stands in for ``george.kernels``."""
+    ExpSquaredKernel = ExpSquaredKernel
+    ConstantKernel = ConstantKernel
+    Product = Product
+
+
+kernels = _KernelsNamespace()
+
+
+def _flatten_kernel(kernel):
+    """(amp, log_M) of an ExpSquared kernel, optionally times constants."""
+    amp = 1.0
+    se = None
+    stack = [kernel]
+    while stack:
+        k = stack.pop()
+        if isinstance(k, Product):
+            stack += [k.k1, k.k2]
+        elif isinstance(k, ConstantKernel):
+            amp *= k.ndim * np.exp(k.log_constant)
+        elif isinstance(k, ExpSquaredKernel):
+            if se is not None:
+                raise NotImplementedError("product of two ExpSquaredKernels")
+            se = k
+        else:
+            raise NotImplementedError("kernel type %r is not on the MI355X hot path" % type(k))
+    if se is None:
+        raise NotImplementedError("an ExpSquaredKernel factor is required")
+    return float(amp), np.asarray(se.log_M, dtype=np.float64)
+
+
+# ---------------------------------------------------------------------------
+# GP
+# ---------------------------------------------------------------------------
+
+class GP(object):
+    """``george.GP``-shaped object whose arithmetic runs on one MI355X."""
+
+    def __init__(self, kernel=None, fit_kernel=True, mean=None, fit_mean=None,
+                 white_noise=None, fit_white_noise=None, solver=None, device=None,
+                 **kwargs):
+        if kernel is None:
+            raise ValueError("a kernel is required")
+        self.kernel = kernel
+        self.mean = _as_model(mean, 0.0)
+        self.white_noise = _as_model(white_noise, np.log(1.25e-12))
+        self.fit_mean = bool(fit_mean)
+        self.fit_white_noise = bool(fit_white_noise)
+        self._device_arg = device
+        self._computed = False
+        self._x = None
+        self._yerr2 = 0.0
+        self._reset_device_state()
+
+    # -- device plumbing -------------------------------------------------------
+    def _reset_device_state(self):
+        self._L = None            # (N,N) lower Cholesky factor (device)
+        self._alpha_y = None      # host copy of the y alpha/z were computed for
+        self._alpha_mean = None
+        self._z = None
+        self._alpha = None
+        self._packed = None       # packed L^-1 tiles
+        self._work = None         # trtri work (dense L^-1 in first panel)
+        self._xs = None           # packed training stream (depends on alpha)
+        self._xs_key = None
+        self.cond_estimate = None
+        self.log_determinant = None
+
+    def _rt(self):
+        """(torch, device, lib) -- fails loudly without GPU / extension."""
+        import torch
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.ApgpError("no MI355X visible: approxposterior_amd has no CPU fallback")
+        dev = self._device_arg
+        if dev is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        elif not isinstance(dev, torch.device):
+            dev = torch.device(dev)
+        return torch, dev, lib
+
+    @staticmethod
+    def _stream(torch):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _kernel_struct(self):
+        amp, log_M = _flatten_kernel(self.kernel)
+        ks = _lib.KernelStruct()
+        ks.ndim = len(log_M)
+        ks.amp = amp
+        ks.diag_add = float(self._yerr2) + float(np.exp(self.white_noise.value))
+        for d in range(_lib.MAX_DIM):
+            ks.inv_metric[d] = float(np.exp(-log_M[d])) if d < len(log_M) else 0.0
+        return ks
+
+    # -- parameter-vector protocol (george) -------------
+    def get_parameter_names(self):
+        names = []
+        if self.fit_mean:
+            names.append("mean:value")
+        if self.fit_white_noise:
+            names.append("white_noise:value")
+        names += ["kernel:" + n for n in self.kernel.get_parameter_names()]
+        return tuple(names)
+
+    def get_parameter_vector(self):
+        v = []
+        if self.fit_mean:
+            v.append(self.mean.value)
+        if self.fit_white_noise:
+            v.append(self.white_noise.value)
+        return np.concatenate([np.array(v, dtype=np.float64),
+                               self.kernel.get_parameter_vector()])
+
+    def set_parameter_vector(self, p):
+        p = np.asarray(p, dtype=np.float64).ravel()
+        if len(p) != len(self):
+            raise ValueError("dimension mismatch")
+        n = 0
+        if self.fit_mean:
+            self.mean.value = float(p[n]); n += 1
+        if self.fit_white_noise:
+            self.white_noise.value = float(p[n]); n += 1
+        self.kernel.set_parameter_vector(p[n:])
+        self.kernel.dirty = True   # marks dirty; no compute (george semantics)
+
+    def __len__(self):
+        return int(self.fit_mean) + int(self.fit_white_noise) + len(self.kernel)
+
+    @property
+    def computed(self):
+        return self._computed and not self.kernel.dirty
+
+    # -- helpers -----------------------------------------------------------------
+    def parse_samples(self, t):
+        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        if t.ndim == 1:
+            t = t[:, None]
+        if t.ndim != 2 or t.shape[1] != self.kernel.ndim:
+            raise ValueError("Dimension mismatch")
+        return np.ascontiguousarray(t)
+
+    def _check_dimensions(self, y):
+        y = np.atleast_1d(np.asarray(y, dtype=np.float64))
+        if self._x is None or y.shape[0] != len(self._x):
+            raise ValueError("Dimension mismatch")
+        return np.ascontiguousarray(y)
+
+    # -- compute / recompute: K1 gram + rocSOLVER potrf + K2 logdet ---------------
+    def compute(self, x, yerr=0.0, **kwargs):
+        torch, dev, lib = self._rt()
+        x = self.parse_samples(x)
+        if x.shape[1] > _lib.MAX_DIM:
+            raise ValueError("at most %d dimensions are supported" % _lib.MAX_DIM)
+        self._x = x
+        self._yerr2 = float(yerr) ** 2
+        self._reset_device_state()
+        self._computed = False
+        n = len(x)
+        ks = self._kernel_struct()
+        with torch.cuda.device(dev):
+            st = self._stream(torch)
+            self._x_d = torch.from_numpy(x).to(dev)
+            K = torch.empty((n, n), dtype=torch.float64, device=dev)
+            _lib.check(lib.apgp_gram(self._x_d.data_ptr(), n, ctypes.byref(ks), K.data_ptr(), n, st),
+                       "apgp_gram")
+            # rocSOLVER potrf works column-major: asking for the UPPER factor makes
+            # its memory image the row-major LOWER factor the kernels stream.
+            U, info = torch.linalg.cholesky_ex(K, upper=True, check_errors=False)
+            L = U.mT
+            if not L.is_contiguous():
+                L = L.contiguous()
+            out3 = torch.empty(3, dtype=torch.float64, device=dev)
+            _lib.check(lib.apgp_logdet(L.data_ptr(), n, n, out3.data_ptr(), st), "apgp_logdet")
+            info = int(info.item())
+            if info != 0:
+                # same failure mode as scipy.linalg.cholesky inside george
+                raise LinAlgError("%d-th leading minor of the array is not positive definite" % info)
+            o = out3.cpu().numpy()
+        if not np.isfinite(o[0]):
+            raise LinAlgError("non-finite log-determinant")
+        self._L = L
+        self.log_determinant = float(o[0])
+        self.cond_estimate = float((o[2] / o[1]) ** 2)
+        self._const = -0.5 * (n * np.log(2.0 * np.pi) + self.log_determinant)
+        self._computed = True
+        self.kernel.dirty = False
+
+    def recompute(self, quiet=False, **kwargs):
+        if self.kernel.dirty or not self._computed:
+            if self._x is None:
+                raise RuntimeError("You need to compute the model first")
+            try:
+                self.compute(self._x, np.sqrt(self._yerr2), **kwargs)
+            except (ValueError, LinAlgError):
+                if quiet:
+                    return False
+                raise
+        return True
+
+    # -- K3: z = L^-1 (y - mean), alpha = L^-T z -----------------------------------
+    def _solve(self, y, need_alpha):
+        """Ensures z (and alpha) for this y; returns device sum-of-squares tensor."""
+        torch, dev, lib = self._rt()
+        y = self._check_dimensions(y)
+        n = len(y)
+        same = (self._alpha_y is not None and self._alpha_mean == self.mean.value
+                and np.array_equal(self._alpha_y, y))
+        with torch.cuda.device(dev):
+            st = self._stream(torch)
+            if not same or self._z is None:
+                y_d = torch.from_numpy(y).to(dev)
+                self._z = torch.empty(n, dtype=torch.float64, device=dev)
+                self._ztz = torch.empty(1, dtype=torch.float64, device=dev)
+                _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, y_d.data_ptr(),
+                                         float(self.mean.value), 0, self._z.data_ptr(),
+                                         self._ztz.data_ptr(), st), "apgp_trsv(forward)")
+                self._alpha = None
+                self._xs = None
+                self._alpha_y = np.array(y, copy=True)
+                self._alpha_mean = self.mean.value
+            if need_alpha and self._alpha is None:
+                self._alpha = torch.empty(n, dtype=torch.float64, device=dev)
+                _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, self._z.data_ptr(), 0.0, 1,
+                                         self._alpha.data_ptr(), None, st), "apgp_trsv(backward)")
+                self._xs = None
+        return self._ztz
+
+    def log_likelihood(self, y, quiet=False):
+        """george GP.log_likelihood (gpUtils.py:78,247): never raises when quiet."""
+        try:
+            if not self.recompute(quiet=quiet):
+                return -np.inf
+            ztz = self._solve(y, need_alpha=False)
+            ll = self._const - 0.5 * float(ztz.item())
+        except (ValueError, LinAlgError):
+            if quiet:
+                return -np.inf
+            raise
+        return ll if np.isfinite(ll) else -np.inf
+
+    # -- packed factor / training stream for the sweep -------------------------------
+    def _ensure_linv(self):
+        torch, dev, lib = self._rt()
+        if self._packed is not None:
+            return
+        n = len(self._x)
+        with torch.cuda.device(dev):
+            st = self._stream(torch)
+            self._work = torch.empty(lib.apgp_trtri_work_len(n), dtype=torch.float64, device=dev)
+            self._packed = torch.empty(lib.apgp_packed_linv_len(n), dtype=torch.float64, device=dev)
+            _lib.check(lib.apgp_trtri_pack(self._L.data_ptr(), n, n, self._work.data_ptr(),
+                                           self._packed.data_ptr(), None, st), "apgp_trtri_pack")
+
+    def _ensure_xs(self, y):
+        torch, dev, lib = self._rt()
+        self._solve(y, need_alpha=True)
+        if self._xs is not None:
+            return
+        n = len(self._x)
+        ks = self._kernel_struct()
+        with torch.cuda.device(dev):
+            st = self._stream(torch)
+            self._xs = torch.empty(lib.apgp_packed_train_len(n, ks.ndim), dtype=torch.float64,
+                                   device=dev)
+            _lib.check(lib.apgp_pack_train(self._x_d.data_ptr(), self._alpha.data_ptr(), n,
+                                           ctypes.byref(ks), self._xs.data_ptr(), st),
+                       "apgp_pack_train")
+
+    # -- predict (george GP.predict) ----------------------------
+    def predict(self, y, t, return_cov=True, return_var=False, cache=True, **kwargs):
+        self.recompute()
+        xs = self.parse_samples(t)
+        if return_cov and not return_var:
+            raise NotImplementedError(
+                "full predictive covariance is not on the MI355X hot path; "
+                "approxposterior only ever asks for return_var=True or the mean")
+        if not return_var:
+            mu, = self._sweep(y, xs, kind=None, want=("mu",))
+            return mu
+        mu, var = self._sweep(y, xs, kind=None, want=("mu", "var"))
+        return mu, var
+
+    def acquire(self, y, t, kind, bounds=None, mask=None, zeta=0.01, return_all=False,
+                idx_offset=0):
+        """Fused predict + utility + arg-min over the candidate matrix ``t`` (M,D).
+
+        The batched counterpart of utility.minimizeObjective (utility.py:253-372)
+        for ``kind`` in {"agp","bape","jones"}.  ``bounds`` (sequence of (lo,hi))
+        is the box prior fused into the kernel (candidates outside get +inf as
+        utility.py:126-127 does); ``mask`` (M,) uint8/bool marks admissible
+        candidates for arbitrary priors evaluated on the host.
+
+        Returns (best_index, best_u) or, with return_all, additionally the
+        arrays (u, mu, var).  best_index is -1 when no candidate is admissible.
+        """
+        if not self.computed:
+            raise RuntimeError("ERROR: Need to compute GP before using it!")
+        xs = self.parse_samples(t)
+        kind_id = UTILITY_KINDS[str(kind).lower()]
+        want = ("best", "u", "mu", "var") if return_all else ("best",)
+        res = self._sweep(y, xs, kind=kind_id, want=want, bounds=bounds, mask=mask,
+                          zeta=zeta, idx_offset=idx_offset)
+        return res
+
+    def _sweep(self, y, cand, kind, want, bounds=None, mask=None, zeta=0.01, idx_offset=0,
+               cand_device=None):
+        torch, dev, lib = self._rt()
+        y = self._check_dimensions(y)
+        n = len(self._x)
+        need_var = kind is not None or "var" in want
+        ks = self._kernel_struct()
+        with torch.cuda.device(dev):
+            st = self._stream(torch)
+            self._ensure_xs(y)
+            T = cand_device if cand_device is not None else torch.from_numpy(cand).to(dev)
+            m = T.shape[0]
+            if not need_var:
+                mu = torch.empty(m, dtype=torch.float64, device=dev)
+                _lib.check(lib.apgp_predict_mean(T.data_ptr(), m, self._xs.data_ptr(), n,
+                                                 ctypes.byref(ks), float(self.mean.value),
+                                                 mu.data_ptr(), st), "apgp_predict_mean")
+                return (mu.cpu().numpy(),)
+            self._ensure_linv()
+            mu = torch.empty(m, dtype=torch.float64, device=dev) if "mu" in want else None
+            var = torch.empty(m, dtype=torch.float64, device=dev) if "var" in want else None
+            u = torch.empty(m, dtype=torch.float64, device=dev) if "u" in want else None
+            nblk = (m + 127) // 128
+            part = torch.empty(2 * nblk, dtype=torch.float64, device=dev)
+            best = torch.empty(2, dtype=torch.float64, device=dev)
+            lo = hi = None
+            if bounds is not None:
+                b = np.asarray(bounds, dtype=np.float64).reshape(-1, 2)
+                if len(b) != ks.ndim:
+                    raise ValueError("bounds must have one (lo, hi) pair per dimension")
+                lo = (ctypes.c_double * _lib.MAX_DIM)(*b[:, 0])
+                hi = (ctypes.c_double * _lib.MAX_DIM)(*b[:, 1])
+            mask_d = None
+            if mask is not None:
+                mk = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+                if mk.shape != (m,):
+                    raise ValueError("mask must have one entry per candidate")
+                mask_d = torch.from_numpy(mk).to(dev)
+            kid = _lib.UTIL_NONE if kind is None else kind
+            ybest = float(np.max(y))
+            _lib.check(lib.apgp_acquire(
+                T.data_ptr(), m, int(idx_offset), self._packed.data_ptr(), self._xs.data_ptr(), n,
+                ctypes.byref(ks), float(self.mean.value), kid, lo, hi,
+                mask_d.data_ptr() if mask_d is not None else None, float(zeta), ybest,
+                mu.data_ptr() if mu is not None else None,
+                var.data_ptr() if var is not None else None,
+                u.data_ptr() if u is not None else None,
+                part.data_ptr(), best.data_ptr(), st), "apgp_acquire")
+            out = []
+            for w in want:
+                if w == "best":
+                    bb = best.cpu().numpy()
+                    out.append(int(bb[1:2].view(np.int64)[0]))
+                    out.append(float(bb[0]))
+                elif w == "mu":
+                    out.append(mu.cpu().numpy())
+                elif w == "var":
+                    out.append(var.cpu().numpy())
+                elif w == "u":
+                    out.append(u.cpu().numpy())
+        return tuple(out)
+
+    # -- K4: gradient of the log-likelihood ------------------------------------------
+    def grad_log_likelihood(self, y, quiet=False):
+        """george GP.grad_log_likelihood (gpUtils.py:110): zeros on failure when quiet."""
+        try:
+            if not self.recompute(quiet=quiet):
+                return np.zeros(len(self), dtype=np.float64)
+            torch, dev, lib = self._rt()
+            y = self._check_dimensions(y)
+            n = len(y)
+            ks = self._kernel_struct()
+            with torch.cuda.device(dev):
+                st = self._stream(torch)
+                self._solve(y, need_alpha=True)
+                self._ensure_linv()
+                work = torch.empty(lib.apgp_grad_work_len(n), dtype=torch.float64, device=dev)
+                out = torch.empty(2 + _lib.MAX_DIM, dtype=torch.float64, device=dev)
+                np64 = (n + 63) // 64 * 64
+                _lib.check(lib.apgp_grad_loglik(self._x_d.data_ptr(), self._alpha.data_ptr(),
+                                                self._work.data_ptr(), np64, n, ctypes.byref(ks),
+                                                work.data_ptr(), out.data_ptr(), st),
+                           "apgp_grad_loglik")
+                o = out.cpu().numpy()
+        except (ValueError, LinAlgError):
+            if quiet:
+                return np.zeros(len(self), dtype=np.float64)
+            raise
+        return self._assemble_gradient(o, ks.ndim)
+
+    def _assemble_gradient(self, o, ndim):
+        """Order device results as george orders its parameter vector."""
+        if self.fit_white_noise:
+            raise NotImplementedError("fit_white_noise=True is not on the MI355X hot path")
+        grad = []
+        if self.fit_mean:
+            grad.append(o[0])
+
+        def walk(k):
+            if isinstance(k, Product):
+                walk(k.k1); walk(k.k2)
+            elif isinstance(k, ConstantKernel):
+                grad.append(o[1])
+            else:
+                grad.extend(o[2:2 + ndim])
+        walk(self.kernel)
+        return np.array(grad, dtype=np.float64)

@@ -1,0 +1,165 @@
+/*
+ * apgp.h -- C ABI of the MI355X-native GP-surrogate hot path (libapgp.so).
+ *
+ * This is the drop-in boundary UNDER the duck-typed ``george.GP`` object that
+ * dflemin3/approxposterior calls (the reference has no FFI of its own: its
+ * seam is the Python object passed as ``gp=``, approx.py:77,140-144, and the
+ * arithmetic lives in the third-party george wheel).  Every entry point below
+ * replaces one piece of what george does for the reference's call sites; the
+ * Python class ``approxposterior_amd.gp.GP`` (host side, ctypes) strings them
+ * together behind george's method names.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  All matrices are IEEE
+ *     fp64, row-major.  Pointers are DEVICE pointers owned by the caller unless
+ *     the parameter is documented as "host".  ``stream`` is a hipStream_t
+ *     passed as void* (NULL = the default stream).  Calls only ENQUEUE work;
+ *     they do not synchronise unless documented.
+ *   - return value: 0 = OK, <0 = bad argument (-1) / HIP error (-2);
+ *     apgp_last_error() gives a thread-local message.  No exceptions cross
+ *     the ABI.  Not thread-safe per stream.
+ *   - gfx950 (MI355X) only; there is no CPU fallback in this library.
+ */
+#ifndef APGP_H
+#define APGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APGP_ABI_VERSION 1
+#define APGP_MAX_DIM 16          /* feature dimension D supported by the kernels */
+#define APGP_ROW_BLOCK 128       /* rows per packed L^-1 row block (sweep tile)  */
+#define APGP_K_CHUNK 32          /* contraction depth per packed tile            */
+
+/* Acquisition kinds (utility.py:99-250). */
+#define APGP_UTIL_AGP 0          /* utility.AGPUtility   utility.py:99-142  */
+#define APGP_UTIL_BAPE 1         /* utility.BAPEUtility  utility.py:145-189 */
+#define APGP_UTIL_JONES 2        /* utility.JonesUtility utility.py:192-250 */
+#define APGP_UTIL_NONE 3         /* predict only (george.GP.predict)        */
+
+/*
+ * ExpSquared(+Constant) kernel hyper-parameters in evaluated form
+ * (george.kernels.ExpSquaredKernel with axis-aligned metric, optionally
+ * ``c * kernel``; gpUtils.py:160-165):
+ *   k(x,x') = amp * exp(-0.5 * sum_d (x_d-x'_d)^2 * inv_metric[d])
+ *   amp        = ndim*exp(log_constant) when fitAmp, else 1
+ *   inv_metric = exp(-log_M_d_d)
+ *   diag_add   = yerr^2 + exp(white_noise), added to K_ii only (never to k(t,t))
+ */
+typedef struct apgp_kernel {
+    int32_t ndim;
+    int32_t _pad;
+    double amp;
+    double diag_add;
+    double inv_metric[APGP_MAX_DIM];
+} apgp_kernel_t;
+
+/* Result record of apgp_acquire (device or host memory, 16 bytes). */
+typedef struct apgp_best {
+    double u;        /* smallest utility found (+inf if no admissible candidate) */
+    int64_t index;   /* its GLOBAL candidate index (idx_offset + row), -1 if none */
+} apgp_best_t;
+
+int apgp_abi_version(void);
+const char* apgp_last_error(void);
+
+/* ---- sizes ------------------------------------------------------------- */
+/* N rounded up to the packed row block (128).                               */
+int64_t apgp_npad(int64_t n);
+/* doubles in the packed lower-triangular L^-1 image for N training points.  */
+int64_t apgp_packed_linv_len(int64_t n);
+/* doubles in the packed training stream (scaled X | alpha) for N, D.        */
+int64_t apgp_packed_train_len(int64_t n, int32_t ndim);
+/* doubles of scratch apgp_trtri_pack needs (two dense Np64 x Np64 panels).  */
+int64_t apgp_trtri_work_len(int64_t n);
+
+/* ---- K1: Gram matrix ------------------------------------------------------
+ * Replaces george ``kernel.get_value(X)`` + the diagonal update inside
+ * ``GP.compute`` (called from gpUtils.py:178,244,254; approx.py:717 and every
+ * _nll evaluation, gpUtils.py:74-78).  Writes the full symmetric N x N matrix
+ * K (leading dimension ldk >= N).                                            */
+int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
+              double* K, int64_t ldk, void* stream);
+
+/* ---- K2: log-determinant and diagonal range of the Cholesky factor -------
+ * Replaces BasicSolver.compute's ``2*sum(log(diag(U)))`` (george; feeds
+ * GP._const used by gpUtils._nll, gpUtils.py:78).  L is the lower factor
+ * (row-major; the Cholesky itself is rocSOLVER dpotrf driven by the host).
+ * out[0] = log det K = 2*sum log L_ii, out[1] = min L_ii, out[2] = max L_ii
+ * (so (out[2]/out[1])^2 is a condition estimate).                           */
+int apgp_logdet(const double* L, int64_t n, int64_t ldl, double* out3, void* stream);
+
+/* ---- K3: triangular solves for z = L^-1 (b - shift), alpha = L^-T z --------
+ * Replaces BasicSolver.apply_inverse / dot_solve on a vector (scipy cho_solve;
+ * george GP.log_likelihood and _compute_alpha; gpUtils.py:78, utility.py:131).
+ * trans = 0: solve L x = (b - shift); trans = 1: solve L^T x = (b - shift).
+ * If sumsq != NULL, *sumsq = x.x (device scalar).  x may alias b.  n <= 16384. */
+int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
+              int trans, double* x, double* sumsq, void* stream);
+
+/* ---- L^-1 in the sweep's packed tile layout --------------------------------
+ * Computes W = L^-1 (blocked recursive triangular inversion, MFMA-f64 GEMM
+ * merges) and writes it as lower-triangular 128 x 32 tiles in MFMA A-fragment
+ * order (see DESIGN.md "packed factor").  This is what lets the sweep evaluate
+ * BasicSolver.apply_inverse(Kxs.T) (george GP.predict, utility.py:131,178,224)
+ * for millions of candidates without materialising Kxs.
+ * work: apgp_trtri_work_len(n) doubles; on return its first panel holds the
+ * dense row-major L^-1 with leading dimension n rounded up to 64.
+ * packed: apgp_packed_linv_len(n) doubles (may be NULL).
+ * If winv_dense != NULL (n x n, ld n) a compact copy of L^-1 is also stored. */
+int apgp_trtri_pack(const double* L, int64_t n, int64_t ldl, double* work,
+                    double* packed, double* winv_dense, void* stream);
+
+/* ---- packed training stream ------------------------------------------------
+ * rows k = 0..npad-1 of [ x_k * sqrt(inv_metric/2) (Dpad) | alpha_k | 0 ].   */
+int apgp_pack_train(const double* X, const double* alpha, int64_t n,
+                    const apgp_kernel_t* kern /*host*/, double* xs, void* stream);
+
+/* ---- K5/K6: fused predict + acquisition sweep + arg-min --------------------
+ * For every candidate row t of T (m x ndim):
+ *   mu  = k(t,X).alpha + mean                     (george GP.predict)
+ *   var = amp - || L^-1 k(t,X)^T ||^2             (return_var=True)
+ *   u   = utility(kind)(mu, var)                  (utility.py:136,183,229-244)
+ *   u   = +inf if t is outside [lo,hi] (box prior; utility.py:126,173,219) or
+ *         mask[i] == 0
+ * and the arg-min over candidates (ties -> lowest index, NaN never wins):
+ * the batched counterpart of utility.minimizeObjective (utility.py:253-372).
+ * mu / var / u may be NULL (not stored).  lo/hi are host arrays or NULL.
+ * part: scratch of 2 * ceil(m/128) doubles-sized slots (16 B each).
+ * best: device apgp_best_t, written by the final reduction kernel.
+ * ybest = max(y) and zeta are used by JONES only.                            */
+int apgp_acquire(const double* T, int64_t m, int64_t idx_offset,
+                 const double* packed_linv, const double* xs, int64_t n,
+                 const apgp_kernel_t* kern /*host*/, double mean, int32_t kind,
+                 const double* lo /*host*/, const double* hi /*host*/,
+                 const uint8_t* mask, double zeta, double ybest,
+                 double* mu, double* var, double* u,
+                 void* part, apgp_best_t* best, void* stream);
+
+/* ---- mean-only prediction (the batched ApproxPosterior._gpll path) --------
+ * mu_i = k(t_i,X).alpha + mean for m candidates (approx.py:178-180).         */
+int apgp_predict_mean(const double* T, int64_t m, const double* xs, int64_t n,
+                      const apgp_kernel_t* kern /*host*/, double mean,
+                      double* mu, void* stream);
+
+/* ---- K4: gradient of the log-likelihood wrt kernel hyper-parameters -------
+ * Replaces george GP.grad_log_likelihood (gpUtils._grad_nll, gpUtils.py:110):
+ *   g_k = 0.5 * sum_ij (alpha alpha^T - K^-1)_ij dK_ij/dtheta_k.
+ * winv/ldw: the dense L^-1 that apgp_trtri_pack leaves in the first panel of
+ * its work buffer (ldw = n rounded up to 64).  work: apgp_grad_work_len(n)
+ * doubles (K^-1 = W^T W is formed there).  out (device, 2+ndim doubles):
+ *   out[0] = sum(alpha) (d/d mean), out[1] = d/d log_constant (amp part),
+ *   out[2+d] = d/d log_M_d_d.                                               */
+int64_t apgp_grad_work_len(int64_t n);
+int apgp_grad_loglik(const double* X, const double* alpha, const double* winv, int64_t ldw,
+                     int64_t n, const apgp_kernel_t* kern /*host*/,
+                     double* work, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APGP_H */
