@@ -12,8 +12,9 @@ extern "C" int64_t apgp_npad(int64_t n) { return apgp_round_up(n, APGP_ROW_BLOCK
 
 extern "C" int64_t apgp_packed_linv_len(int64_t n) {
     int64_t nrb = apgp_npad(n) / APGP_ROW_BLOCK;
-    // row block ib holds (ib+1)*4 tiles of 128 x 32 doubles
-    return 2 * nrb * (nrb + 1) * (int64_t)(APGP_ROW_BLOCK * APGP_K_CHUNK);
+    // row block ib holds (ib+1)*CPB tiles of ROW_BLOCK x K_CHUNK doubles
+    const int64_t cpb = APGP_ROW_BLOCK / APGP_K_CHUNK;
+    return cpb * nrb * (nrb + 1) / 2 * (int64_t)(APGP_ROW_BLOCK * APGP_K_CHUNK);
 }
 
 extern "C" int64_t apgp_packed_train_len(int64_t n, int32_t ndim) {
@@ -327,21 +328,24 @@ __global__ __launch_bounds__(256) void trtri_merge_kernel(MergeArgs a) {
             }
 }
 
-// Packed tile (ib, kc): 128 rows x 32 k as [kk 0..7][s 0..7][lane 0..63] with
-// element = W[ib*128 + 16 s + (lane & 15)][kc*32 + 4 kk + (lane >> 4)]
-// (exactly the v_mfma_f64_16x16x4_f64 A-operand order, so the sweep reads one
-// ds_read_b64 per fragment at lane * 8, conflict-free).
+// Packed tile (ib, kc): ROW_BLOCK rows x K_CHUNK k as [kk][s][lane 0..63] with
+// element = W[ib*ROW_BLOCK + 16 s + (lane & 15)][kc*K_CHUNK + 4 kk + (lane >> 4)]
+// (the MFMA A-operand order, lane = row-in-16 + 16 k, so the sweep reads one
+// ds_read_b64 per fragment at lane * 8, conflict-free).  Tiles are stored row
+// block by row block, k-chunks 0 .. (ib+1)*CPB-1 each.
 __global__ __launch_bounds__(256) void pack_linv_kernel(const double* W, long long ldw, long long n,
                                                         double* packed) {
+    constexpr int CPB = APGP_ROW_BLOCK / APGP_K_CHUNK;
+    constexpr int RS = APGP_ROW_BLOCK / 16;
     const long long tile = blockIdx.x;
-    // invert tile = 2*ib*(ib+1) + kc
-    long long ib = (long long)((sqrt(2.0 * (double)tile + 1.0) - 1.0) * 0.5);
-    while (2 * (ib + 1) * (ib + 2) <= tile) ++ib;
-    while (2 * ib * (ib + 1) > tile) --ib;
-    const long long kc = tile - 2 * ib * (ib + 1);
+    // invert tile = CPB*ib*(ib+1)/2 + kc
+    long long ib = (long long)((sqrt(8.0 * (double)tile / CPB + 1.0) - 1.0) * 0.5);
+    while (CPB * (ib + 1) * (ib + 2) / 2 <= tile) ++ib;
+    while (CPB * ib * (ib + 1) / 2 > tile) --ib;
+    const long long kc = tile - CPB * ib * (ib + 1) / 2;
     double* out = packed + tile * (long long)(APGP_ROW_BLOCK * APGP_K_CHUNK);
     for (int e = threadIdx.x; e < APGP_ROW_BLOCK * APGP_K_CHUNK; e += 256) {
-        int lane = e & 63, s = (e >> 6) & 7, kk = e >> 9;
+        int lane = e & 63, s = (e >> 6) % RS, kk = (e >> 6) / RS;
         long long row = ib * APGP_ROW_BLOCK + 16 * s + (lane & 15);
         long long col = kc * APGP_K_CHUNK + 4 * kk + (lane >> 4);
         double v = 0.0;
@@ -376,7 +380,7 @@ extern "C" int apgp_trtri_pack(const double* L, int64_t n, int64_t ldl, double* 
     }
     if (packed) {
         long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
-        long long ntiles = 2 * nrb * (nrb + 1);
+        long long ntiles = (APGP_ROW_BLOCK / APGP_K_CHUNK) * nrb * (nrb + 1) / 2;
         hipLaunchKernelGGL(pack_linv_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, W, np,
                            (long long)n, packed);
     }

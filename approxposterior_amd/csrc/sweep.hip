@@ -5,25 +5,28 @@
 //   utility.AGPUtility / BAPEUtility / JonesUtility (utility.py:99-250)
 //   utility.minimizeObjective's arg-min             (utility.py:369-371)
 //
-// Data flow per workgroup (256 threads = 4 wavefronts, 128 candidates):
-//   * wavefront w owns candidates [32 w, 32 w + 32) as two MFMA column blocks;
+// Data flow per workgroup (256 threads = 4 wavefronts, 64 candidates):
+//   * wavefront w owns candidates [16 w, 16 w + 16) (one MFMA column block);
 //     the scaled candidate coordinates live in registers for the whole kernel.
-//   * the packed factor W = L^-1 is streamed tile by tile (128 rows x 32 k,
+//   * the packed factor W = L^-1 is streamed tile by tile (256 rows x 16 k,
 //     32 KiB, A-fragment order) HBM/L2 -> LDS with global_load_lds (no VGPR
 //     round trip), double buffered, shared by the four wavefronts.
 //   * K* is NEVER materialised: each lane generates the k*(t_m, x_k) value it
 //     must feed as the MFMA B operand (lane -> candidate lane&15, k lane>>4)
-//     on the VALU (D FMAs + exp) while the matrix pipe runs the previous step.
-//   * V = W K*^T is accumulated 128 rows x 32 candidates per wavefront in 16
-//     v_mfma_f64_16x16x4_f64 accumulators; at the end of a row block the
+//     on the VALU (D sub + D fma + exp).
+//   * V = W K*^T is accumulated 256 rows x 16 candidates per wavefront in 64
+//     v_mfma_f64_4x4x4_4b_f64 accumulators; at the end of a row block the
 //     squares are folded into a per-candidate sum; V itself is never stored.
 //   * mu is a VALU by-product of the last row block (which visits every k).
 #include "apgp_common.h"
+#include <stdlib.h>
+#include <type_traits>
+#include <string.h>
 
-#define SW_ROWS APGP_ROW_BLOCK       // 128 rows of W per tile
-#define SW_KC APGP_K_CHUNK           // 32 k per tile
+#define SW_ROWS APGP_ROW_BLOCK       // 256 rows of W per tile
+#define SW_KC APGP_K_CHUNK           // 16 k per tile
 #define SW_TILE (SW_ROWS * SW_KC)    // doubles per tile (32 KiB)
-#define SW_CAND 128                  // candidates per workgroup
+#define SW_CAND 64                   // candidates per workgroup (16 per wavefront)
 #define SW_THREADS 256
 
 struct SweepArgs {
@@ -71,46 +74,64 @@ __device__ __forceinline__ void best_merge(double& bu, long long& bi, double u, 
     if (i >= 0 && (u < bu || (u == bu && (bi < 0 || i < bi)))) { bu = u; bi = i; }
 }
 
+// Matrix-core instruction choice (measured on MI355X, tools/mfma_peak.hip and
+// tools/mfma_probe.hip):
+//   v_mfma_f64_16x16x4_f64     36 TF/chip  (~138 cycles, 7.4 MAC/clk/SIMD)
+//   v_mfma_f64_4x4x4_4b_f64    70-74 TF    (16.5 cycles, 15.5 MAC/clk/SIMD = FP64 FMA peak)
+//   v_fma_f64 (VALU)           64-70 TF, and MFMA + VALU f64 do NOT overlap: they
+//                              share the DP pipes (sum stays ~70 TF for any mix).
+// So the contraction uses the 4x4x4 four-block instruction.  Its blocks are
+// independent (CBSZ/ABID broadcast is ignored for f64 on gfx950), so a
+// 16 x 16 x 4 product takes four instructions whose A operand is the same
+// 16 x 4 fragment with its 4-row groups rotated across the blocks:
+//   A lane = i + 4 b + 16 k,  B lane = j + 4 b + 16 k,  D lane = j + 4 b + 16 i.
+// The candidate of a lane is lane & 15 for every rotation, which is all the
+// variance reduction needs (sum over rows of V^2).
+// Because K* generation costs DP cycles too, each generated value must feed as
+// many rows as possible: a wavefront owns 256 rows x 16 candidates (64 f64
+// accumulators per lane), so one generated B fragment feeds 64 MFMAs.
 template <int DPAD>
-__global__ __launch_bounds__(SW_THREADS, 2) void sweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     constexpr int XS = DPAD + 2;
+    constexpr int RS = SW_ROWS / 16;           // 16-row sub-blocks per tile
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Abuf = smem;                       // 2 x SW_TILE
     double* Xbuf = smem + 2 * SW_TILE;         // 2 x SW_KC x XS
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cl = lane & 15, kq = lane >> 4;
 
-    // ---- candidates of this lane (two column blocks) ----------------------
-    double tt[2][DPAD];
-    bool ok[2];
-    long long cidx[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const long long row = (long long)blockIdx.x * SW_CAND + w * 32 + j * 16 + cl;
-        cidx[j] = row;
-        bool inb = row < a.m;
-        bool adm = inb;
+    // ---- candidate of this lane -------------------------------------------
+    double tt[DPAD];
+    const long long crow = (long long)blockIdx.x * SW_CAND + w * 16 + cl;
+    bool adm = crow < a.m;
+    {
+        const bool inb = adm;
 #pragma unroll
         for (int d = 0; d < DPAD; ++d) {
             double v = 0.0;
             if (inb && d < a.ndim) {
-                v = a.T[row * a.ndim + d];
+                v = a.T[crow * a.ndim + d];
                 if (a.has_box && !(v >= a.lo[d] && v <= a.hi[d])) adm = false;
             }
-            tt[j][d] = v * a.sc[d];
+            tt[d] = v * a.sc[d];
         }
-        if (inb && a.mask && a.mask[row] == 0) adm = false;
-        ok[j] = adm;
+        if (inb && a.mask && a.mask[crow] == 0) adm = false;
     }
 
-    f64x4 acc[8][2];
+    // V accumulators: 256 rows x 16 candidates per wavefront
+    double acc[RS][4];
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < RS; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[s][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    double qpart[2] = {0.0, 0.0}, mupart[2] = {0.0, 0.0};
+        for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
+    double qpart = 0.0, mupart = 0.0;
+    // lane index of the A element this lane feeds for rotation r
+    int rot[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rot[r] = (lane & ~12) | ((((lane >> 2) + r) & 3) << 2);
 
-    const long long ntiles = 2LL * a.nrb * (a.nrb + 1);
+    constexpr int CPB = SW_ROWS / SW_KC;       // k-chunks per row-block width
+    const long long ntiles = (long long)CPB * a.nrb * (a.nrb + 1) / 2;
     // stage_issue(tile, kc, buf): W tile via LDS-DMA (each wavefront moves 8 KiB
     // as 8 x 1 KiB, no VGPR round trip); the small training-stream chunk is
     // fetched into registers now and written to LDS by stage_commit() after the
@@ -148,7 +169,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_kernel(SweepArgs a) {
     long long tile = 0;
     int buf = 0;
     for (int ib = 0; ib < a.nrb; ++ib) {
-        const int nkc = 4 * (ib + 1);
+        const int nkc = CPB * (ib + 1);
         const bool last_rb = (ib == a.nrb - 1);
         for (int kc = 0; kc < nkc; ++kc, ++tile) {
             // prefetch the next tile (possibly the first tile of the next row block)
@@ -156,48 +177,61 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_kernel(SweepArgs a) {
             if (more) stage_issue(tile + 1, (kc + 1 < nkc) ? kc + 1 : 0, buf ^ 1);
             const double* Ab = Abuf + buf * SW_TILE;
             const double* Xb = Xbuf + buf * SW_KC * XS;
+            // W is lower triangular: inside the diagonal row block the 16-row
+            // sub-blocks above the chunk's k range are structurally zero and are
+            // skipped (DIAG path); off-diagonal tiles run the branch-free path.
+            const int smin = (kc - CPB * ib) * (SW_KC / 16);   // <= 0 off the diagonal
+            auto tile_body = [&](auto diag_tag) {
+                constexpr bool DIAG = decltype(diag_tag)::value;
+                constexpr int NKK = SW_KC / 4, NG = NKK * RS;
+                // ---- generate the B operands of the tile's k-steps:
+                //      k*(candidate cl, x_k), k = kc*KC + 4 kk + kq
+                double bfv[NKK];
 #pragma unroll
-            for (int kk = 0; kk < SW_KC / 4; ++kk) {
-                // ---- generate the B operand: k*(candidate cl(+16), x_k), k = kc*32+4kk+kq
-                const double* xr = Xb + (kk * 4 + kq) * XS;
-                double xv[DPAD];
-#pragma unroll
-                for (int d = 0; d < DPAD; ++d) xv[d] = xr[d];
-                const double al = xr[DPAD];
-                double bf[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    double s = -a.log_amp;
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const double* xr = Xb + (kk * 4 + kq) * XS;
+                    double s2 = -a.log_amp;
 #pragma unroll
                     for (int d = 0; d < DPAD; ++d) {
-                        double df = tt[j][d] - xv[d];
-                        s = fma(df, df, s);
+                        const double df = tt[d] - xr[d];
+                        s2 = fma(df, df, s2);
                     }
-                    bf[j] = exp(-s);
+                    bfv[kk] = exp(-s2);
+                    if (last_rb) mupart = fma(bfv[kk], xr[DPAD], mupart);
                 }
-                if (last_rb) {
-                    mupart[0] = fma(bf[0], al, mupart[0]);
-                    mupart[1] = fma(bf[1], al, mupart[1]);
-                }
-                // ---- A fragments (W rows) and the 16 matrix-core steps
-                double af[8];
+                // ---- A fragments (W rows, four rotations each) software-pipelined two
+                //      groups ahead of the matrix-core steps that consume them
+                double afr[3][4];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) af[s] = Ab[(kk * 8 + s) * 64 + lane];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[0], acc[s][0], 0, 0, 0);
-                    acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[1], acc[s][1], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    afr[0][r] = Ab[0 * 64 + rot[r]];
+                    afr[1][r] = Ab[1 * 64 + rot[r]];
                 }
-            }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 2 < NG) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) afr[(g + 2) % 3][r] = Ab[(g + 2) * 64 + rot[r]];
+                    }
+                    const int kk = g / RS, sb = g % RS;
+                    if (!DIAG || sb >= smin) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[sb][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(afr[g % 3][r], bfv[kk], acc[sb][r], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (smin > 0) tile_body(std::true_type{});
+            else tile_body(std::false_type{});
             if (kc == nkc - 1) {
-                // row block finished: fold ||V||^2 into the per-candidate sums
+                // row block finished: fold ||V||^2 into the per-candidate sum
 #pragma unroll
-                for (int s = 0; s < 8; ++s)
+                for (int s = 0; s < RS; ++s)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) qpart[j] = fma(acc[s][j][r], acc[s][j][r], qpart[j]);
-                        acc[s][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+                    for (int r = 0; r < 4; ++r) {
+                        qpart = fma(acc[s][r], acc[s][r], qpart);
+                        acc[s][r] = 0.0;
                     }
             }
             if (more) stage_commit(buf ^ 1);
@@ -207,31 +241,22 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_kernel(SweepArgs a) {
         }
     }
 
-    // ---- reduce over the four k-quarters of the wavefront -----------------
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        qpart[j] += __shfl_xor(qpart[j], 16);
-        qpart[j] += __shfl_xor(qpart[j], 32);
-        mupart[j] += __shfl_xor(mupart[j], 16);
-        mupart[j] += __shfl_xor(mupart[j], 32);
-    }
+    // ---- reduce over the four k-quarters / row-quarters of the wavefront ------
+    qpart += __shfl_xor(qpart, 16);
+    qpart += __shfl_xor(qpart, 32);
+    mupart += __shfl_xor(mupart, 16);
+    mupart += __shfl_xor(mupart, 32);
     double bu = INFINITY;
     long long bi = -1;
-    if (kq == 0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long row = cidx[j];
-            if (row < a.m) {
-                const double mu = mupart[j] + a.mean;
-                const double var = a.amp - qpart[j];
-                if (a.mu) a.mu[row] = mu;
-                if (a.var) a.var[row] = var;
-                if (a.kind != APGP_UTIL_NONE) {
-                    double uu = ok[j] ? util_value(a.kind, mu, var, a.zeta, a.ybest) : INFINITY;
-                    if (a.u) a.u[row] = uu;
-                    best_merge(bu, bi, uu, a.idx_offset + row);
-                }
-            }
+    if (kq == 0 && crow < a.m) {
+        const double mu = mupart + a.mean;
+        const double var = a.amp - qpart;
+        if (a.mu) a.mu[crow] = mu;
+        if (a.var) a.var[crow] = var;
+        if (a.kind != APGP_UTIL_NONE) {
+            double uu = adm ? util_value(a.kind, mu, var, a.zeta, a.ybest) : INFINITY;
+            if (a.u) a.u[crow] = uu;
+            best_merge(bu, bi, uu, a.idx_offset + crow);
         }
     }
     if (a.kind == APGP_UTIL_NONE) return;
@@ -279,8 +304,8 @@ static int launch_sweep(const SweepArgs& a, hipStream_t s) {
     const size_t lds = (2 * SW_TILE + 2 * SW_KC * (DPAD + 2)) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)sweep_kernel<DPAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+        (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const unsigned nblk = (unsigned)((a.m + SW_CAND - 1) / SW_CAND);

@@ -470,12 +470,17 @@ class GP(object):
         """
         if not self.computed:
             raise RuntimeError("ERROR: Need to compute GP before using it!")
-        xs = self.parse_samples(t)
         kind_id = UTILITY_KINDS[str(kind).lower()]
         want = ("best", "u", "mu", "var") if return_all else ("best",)
-        res = self._sweep(y, xs, kind=kind_id, want=want, bounds=bounds, mask=mask,
-                          zeta=zeta, idx_offset=idx_offset)
-        return res
+        if hasattr(t, "data_ptr"):      # candidates already resident in HBM (torch tensor)
+            if t.dim() != 2 or t.shape[1] != self.kernel.ndim or not t.is_contiguous() \
+                    or str(t.dtype) != "torch.float64" or not t.is_cuda:
+                raise ValueError("device candidates must be a contiguous (M, D) float64 CUDA tensor")
+            return self._sweep(y, None, kind=kind_id, want=want, bounds=bounds, mask=mask,
+                               zeta=zeta, idx_offset=idx_offset, cand_device=t)
+        xs = self.parse_samples(t)
+        return self._sweep(y, xs, kind=kind_id, want=want, bounds=bounds, mask=mask,
+                           zeta=zeta, idx_offset=idx_offset)
 
     def _sweep(self, y, cand, kind, want, bounds=None, mask=None, zeta=0.01, idx_offset=0,
                cand_device=None):
@@ -499,7 +504,7 @@ class GP(object):
             mu = torch.empty(m, dtype=torch.float64, device=dev) if "mu" in want else None
             var = torch.empty(m, dtype=torch.float64, device=dev) if "var" in want else None
             u = torch.empty(m, dtype=torch.float64, device=dev) if "u" in want else None
-            nblk = (m + 127) // 128
+            nblk = (m + 63) // 64
             part = torch.empty(2 * nblk, dtype=torch.float64, device=dev)
             best = torch.empty(2, dtype=torch.float64, device=dev)
             lo = hi = None
@@ -517,6 +522,10 @@ class GP(object):
                 mask_d = torch.from_numpy(mk).to(dev)
             kid = _lib.UTIL_NONE if kind is None else kind
             ybest = float(np.max(y))
+            ev = getattr(self, "kernel_events", None)   # bench.py: HIP events around the launch
+            if ev is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             _lib.check(lib.apgp_acquire(
                 T.data_ptr(), m, int(idx_offset), self._packed.data_ptr(), self._xs.data_ptr(), n,
                 ctypes.byref(ks), float(self.mean.value), kid, lo, hi,
@@ -525,6 +534,10 @@ class GP(object):
                 var.data_ptr() if var is not None else None,
                 u.data_ptr() if u is not None else None,
                 part.data_ptr(), best.data_ptr(), st), "apgp_acquire")
+            if ev is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                ev.append((e0, e1))
             out = []
             for w in want:
                 if w == "best":
