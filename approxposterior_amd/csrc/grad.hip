@@ -77,6 +77,8 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
     __shared__ double xj[64][DPAD + 1];
     __shared__ double ai[64], aj[64];
     __shared__ double red[4][1 + DPAD];
+    __shared__ double etab[APGP_EXP_TAB_N];
+    apgp_exp_tab_load(etab);
     const int t = threadIdx.x;
     const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
     for (int e = t; e < 64 * DPAD; e += 256) {
@@ -108,14 +110,17 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
         const long long gi = i0 + r;
         if (gi < a.n && gj < a.n) {
             double df2[DPAD];
-            double s = -a.kc.log_amp;
+            double s = -a.kc.log_amp, s3 = 0.0;
 #pragma unroll
-            for (int d = 0; d < DPAD; ++d) {
-                double df = xi[r][d] - xc[d];
-                df2[d] = df * df;
-                s = fma(df, df, s);
+            for (int d = 0; d < DPAD; d += 2) {
+                double df0 = xi[r][d] - xc[d];
+                double df1 = xi[r][d + 1] - xc[d + 1];
+                df2[d] = df0 * df0;
+                df2[d + 1] = df1 * df1;
+                s = fma(df0, df0, s);
+                s3 = fma(df1, df1, s3);
             }
-            const double k = exp(-s);
+            const double k = apgp_exp(-(s + s3), etab);
             const double A = ai[r] * aj[c] - a.Kinv[gi * a.n + gj];
             const double Ak = A * k;
             gsum[0] += Ak;

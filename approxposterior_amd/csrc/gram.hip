@@ -32,6 +32,8 @@ template <int DPAD>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     __shared__ double xi[64][DPAD + 1];
     __shared__ double xj[64][DPAD + 1];
+    __shared__ double etab[APGP_EXP_TAB_N];
+    apgp_exp_tab_load(etab);
     const int t = threadIdx.x;
     const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
     for (int e = t; e < 64 * DPAD; e += 256) {
@@ -55,13 +57,16 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     for (int q = 0; q < 16; ++q) {
         const int r = g + 4 * q;
         const long long gi = i0 + r;
-        double s = -a.kc.log_amp;
+        // same association as the sweep / mean kernels: two interleaved sums
+        double s = -a.kc.log_amp, s3 = 0.0;
 #pragma unroll
-        for (int d = 0; d < DPAD; ++d) {
-            double df = xi[r][d] - xc[d];
-            s = fma(df, df, s);
+        for (int d = 0; d < DPAD; d += 2) {
+            double df0 = xi[r][d] - xc[d];
+            double df1 = xi[r][d + 1] - xc[d + 1];
+            s = fma(df0, df0, s);
+            s3 = fma(df1, df1, s3);
         }
-        double k = exp(-s);
+        double k = apgp_exp(-(s + s3), etab);
         if (gi == gj) k += a.kc.diag_add;
         if (gi < a.n && gj < a.n) a.K[gi * a.ldk + gj] = k;
     }

@@ -328,15 +328,20 @@ __global__ __launch_bounds__(256) void trtri_merge_kernel(MergeArgs a) {
             }
 }
 
-// Packed tile (ib, kc): ROW_BLOCK rows x K_CHUNK k as [kk][s][lane 0..63] with
-// element = W[ib*ROW_BLOCK + 16 s + (lane & 15)][kc*K_CHUNK + 4 kk + (lane >> 4)]
-// (the MFMA A-operand order, lane = row-in-16 + 16 k, so the sweep reads one
-// ds_read_b64 per fragment at lane * 8, conflict-free).  Tiles are stored row
-// block by row block, k-chunks 0 .. (ib+1)*CPB-1 each.
+// Packed tile (ib, kc): ROW_BLOCK rows x K_CHUNK(=16) k stored as
+//   [s 0..RS-1][kp 0..1][p 0..63][q 0..1]   (doubles)
+// holding W[ib*ROW_BLOCK + 16 s + (p & 15)][kc*16 + 4*(2 kp + q) + (p >> 4)]:
+// p is the MFMA A-operand lane (row-in-16 + 16 * k-in-4) and (kp, q) the k-step
+// kk = 2 kp + q.  One ds_read_b128 at ((s*2+kp)*64 + p)*16 B therefore returns
+// the A values of k-steps 2kp and 2kp+1 for lane position p; consecutive lanes
+// read consecutive 16-byte slots (conflict-free, full LDS rate from one
+// wavefront per SIMD).  Tiles are stored row block by row block, k-chunks
+// 0 .. (ib+1)*CPB-1 each.
 __global__ __launch_bounds__(256) void pack_linv_kernel(const double* W, long long ldw, long long n,
                                                         double* packed) {
     constexpr int CPB = APGP_ROW_BLOCK / APGP_K_CHUNK;
     constexpr int RS = APGP_ROW_BLOCK / 16;
+    static_assert(APGP_K_CHUNK == 16 && RS * 256 == APGP_ROW_BLOCK * APGP_K_CHUNK, "tile layout");
     const long long tile = blockIdx.x;
     // invert tile = CPB*ib*(ib+1)/2 + kc
     long long ib = (long long)((sqrt(8.0 * (double)tile / CPB + 1.0) - 1.0) * 0.5);
@@ -345,7 +350,8 @@ __global__ __launch_bounds__(256) void pack_linv_kernel(const double* W, long lo
     const long long kc = tile - CPB * ib * (ib + 1) / 2;
     double* out = packed + tile * (long long)(APGP_ROW_BLOCK * APGP_K_CHUNK);
     for (int e = threadIdx.x; e < APGP_ROW_BLOCK * APGP_K_CHUNK; e += 256) {
-        int lane = e & 63, s = (e >> 6) % RS, kk = (e >> 6) / RS;
+        const int q = e & 1, lane = (e >> 1) & 63, kp = (e >> 7) & 1, s = e >> 8;
+        const int kk = 2 * kp + q;
         long long row = ib * APGP_ROW_BLOCK + 16 * s + (lane & 15);
         long long col = kc * APGP_K_CHUNK + 4 * kk + (lane >> 4);
         double v = 0.0;

@@ -5,27 +5,27 @@
 //   utility.AGPUtility / BAPEUtility / JonesUtility (utility.py:99-250)
 //   utility.minimizeObjective's arg-min             (utility.py:369-371)
 //
-// Data flow per workgroup (256 threads = 4 wavefronts, 64 candidates):
+// Data flow per workgroup (256 threads = 4 wavefronts, one per SIMD, 64 candidates):
 //   * wavefront w owns candidates [16 w, 16 w + 16) (one MFMA column block);
 //     the scaled candidate coordinates live in registers for the whole kernel.
-//   * the packed factor W = L^-1 is streamed tile by tile (256 rows x 16 k,
-//     32 KiB, A-fragment order) HBM/L2 -> LDS with global_load_lds (no VGPR
-//     round trip), double buffered, shared by the four wavefronts.
+//   * the packed factor W = L^-1 is streamed tile by tile (512 rows x 16 k,
+//     64 KiB, A-fragment order) L2/MALL -> registers -> LDS, double buffered,
+//     shared by the four wavefronts (one barrier per tile).
 //   * K* is NEVER materialised: each lane generates the k*(t_m, x_k) value it
 //     must feed as the MFMA B operand (lane -> candidate lane&15, k lane>>4)
-//     on the VALU (D sub + D fma + exp).
-//   * V = W K*^T is accumulated 256 rows x 16 candidates per wavefront in 64
-//     v_mfma_f64_4x4x4_4b_f64 accumulators; at the end of a row block the
-//     squares are folded into a per-candidate sum; V itself is never stored.
+//     on the VALU (D sub + D fma + table-driven exp).
+//   * V = W K*^T is accumulated 512 rows x 16 candidates per wavefront in 128
+//     v_mfma_f64_4x4x4_4b_f64 accumulators (AGPRs); at the end of a row block
+//     the squares are folded into a per-candidate sum; V is never stored.
 //   * mu is a VALU by-product of the last row block (which visits every k).
 #include "apgp_common.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>
 
-#define SW_ROWS APGP_ROW_BLOCK       // 256 rows of W per tile
+#define SW_ROWS APGP_ROW_BLOCK       // 512 rows of W per tile
 #define SW_KC APGP_K_CHUNK           // 16 k per tile
-#define SW_TILE (SW_ROWS * SW_KC)    // doubles per tile (32 KiB)
+#define SW_TILE (SW_ROWS * SW_KC)    // doubles per tile (64 KiB)
 #define SW_CAND 64                   // candidates per workgroup (16 per wavefront)
 #define SW_THREADS 256
 
@@ -40,9 +40,10 @@ struct SweepArgs {
     double* part_u;
     long long* part_i;
     long long m, idx_offset;
-    int ndim, nrb, kind, has_box;
+    int ndim, nrb, kind, has_box, n;
     double mean, amp, log_amp, zeta, ybest;
     double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM];
+    unsigned long long* dbg;   // phase cycle counters (APGP_SWEEP_TIMING=1 builds only)
 };
 
 __device__ __forceinline__ double util_value(int kind, double mu, double var, double zeta,
@@ -77,7 +78,7 @@ __device__ __forceinline__ void best_merge(double& bu, long long& bi, double u, 
 // Matrix-core instruction choice (measured on MI355X, tools/mfma_peak.hip and
 // tools/mfma_probe.hip):
 //   v_mfma_f64_16x16x4_f64     36 TF/chip  (~138 cycles, 7.4 MAC/clk/SIMD)
-//   v_mfma_f64_4x4x4_4b_f64    70-74 TF    (16.5 cycles, 15.5 MAC/clk/SIMD = FP64 FMA peak)
+//   v_mfma_f64_4x4x4_4b_f64    70-75 TF    (16.5 cycles, 15.5 MAC/clk/SIMD = FP64 FMA peak)
 //   v_fma_f64 (VALU)           64-70 TF, and MFMA + VALU f64 do NOT overlap: they
 //                              share the DP pipes (sum stays ~70 TF for any mix).
 // So the contraction uses the 4x4x4 four-block instruction.  Its blocks are
@@ -88,22 +89,30 @@ __device__ __forceinline__ void best_merge(double& bu, long long& bi, double u, 
 // The candidate of a lane is lane & 15 for every rotation, which is all the
 // variance reduction needs (sum over rows of V^2).
 // Because K* generation costs DP cycles too, each generated value must feed as
-// many rows as possible: a wavefront owns 256 rows x 16 candidates (64 f64
-// accumulators per lane), so one generated B fragment feeds 64 MFMAs.
-template <int DPAD>
+// many rows as possible: a wavefront owns 512 rows x 16 candidates (128 f64
+// accumulators per lane = the whole AGPR file), so one generated B value feeds
+// 128 MFMAs; one wavefront per SIMD, everything latency-critical is prefetched.
+template <int DPAD, bool TIMING = false>
 __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
+    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq = 0;
+#define SW_TICK(i) do { if (TIMING) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); tph[i] += n_ - tq; tq = n_; } } while (0)
     constexpr int XS = DPAD + 2;
-    constexpr int RS = SW_ROWS / 16;           // 16-row sub-blocks per tile
+    constexpr int RS = SW_ROWS / 16;           // 16-row sub-blocks per tile (32)
+    constexpr int NKK = SW_KC / 4;             // k-steps per tile (4)
+    static_assert(NKK == 4 && (RS % 2) == 0, "tile layout");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Abuf = smem;                       // 2 x SW_TILE
     double* Xbuf = smem + 2 * SW_TILE;         // 2 x SW_KC x XS
+    double* Etab = Xbuf + 2 * SW_KC * XS;      // exp table
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cl = lane & 15, kq = lane >> 4;
+    apgp_exp_tab_load(Etab);
 
     // ---- candidate of this lane -------------------------------------------
     double tt[DPAD];
     const long long crow = (long long)blockIdx.x * SW_CAND + w * 16 + cl;
     bool adm = crow < a.m;
+    bool has_nan = false;
     {
         const bool inb = adm;
 #pragma unroll
@@ -112,135 +121,210 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
             if (inb && d < a.ndim) {
                 v = a.T[crow * a.ndim + d];
                 if (a.has_box && !(v >= a.lo[d] && v <= a.hi[d])) adm = false;
+                if (v != v) has_nan = true;
             }
             tt[d] = v * a.sc[d];
         }
         if (inb && a.mask && a.mask[crow] == 0) adm = false;
     }
 
-    // V accumulators: 256 rows x 16 candidates per wavefront
-    double acc[RS][4];
-#pragma unroll
-    for (int s = 0; s < RS; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
     double qpart = 0.0, mupart = 0.0;
     // lane index of the A element this lane feeds for rotation r
     int rot[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) rot[r] = (lane & ~12) | ((((lane >> 2) + r) & 3) << 2);
 
-    constexpr int CPB = SW_ROWS / SW_KC;       // k-chunks per row-block width
-    const long long ntiles = (long long)CPB * a.nrb * (a.nrb + 1) / 2;
-    // stage_issue(tile, kc, buf): W tile via LDS-DMA (each wavefront moves 8 KiB
-    // as 8 x 1 KiB, no VGPR round trip); the small training-stream chunk is
-    // fetched into registers now and written to LDS by stage_commit() after the
-    // tile's matrix work, so its HBM/L2 latency hides under the MFMAs.
-    constexpr int XCHUNK16 = SW_KC * XS / 2;                    // 16-byte pieces per chunk
-    constexpr int XNP = (XCHUNK16 + SW_THREADS - 1) / SW_THREADS;
-    f64x2 xpend[XNP];
-    auto stage_issue = [&](long long tile, int kc, int buf) {
-        const char* g = (const char*)(a.linv + tile * SW_TILE) + w * 8192 + lane * 16;
-        char* l = (char*)(Abuf + buf * SW_TILE) + w * 8192;
+    constexpr int CPB = SW_ROWS / SW_KC;       // k-chunks per row-block width (32)
+    const int kc_lim = (a.n + SW_KC - 1) / SW_KC;     // chunks that hold real columns
+    const int sb_lim = (a.n + 15) / 16;               // sub-blocks (global) that hold real rows
+
+    // Tile staging through registers (global_load_dwordx4 early, ds_write_b128
+    // late): an LDS-DMA (global_load_lds) costs ~55 issue cycles per KiB on the
+    // issuing wavefront, and with one wavefront per SIMD nothing hides that.
+    // The 64 KiB tile moves in two halves of 8 x 16 B per thread.
+    constexpr int HALF16 = SW_TILE / 2 / 2;          // 16-byte pieces per half tile (2048)
+    constexpr int NST = HALF16 / SW_THREADS;         // pieces per thread per half (8)
+    constexpr int XCHUNK16 = SW_KC * XS / 2;         // 16-byte pieces of the x chunk
+    static_assert(XCHUNK16 <= SW_THREADS, "x chunk staging");
+    f64x2 st[NST];
+    f64x2 xpend;
+    auto half_load = [&](long long tile, int half) {
+        const f64x2* g = (const f64x2*)(a.linv + tile * SW_TILE) + half * HALF16 + t;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g + i * 1024),
-                (__attribute__((address_space(3))) void*)(l + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int p = 0; p < XNP; ++p) {
-            const int e = t + p * SW_THREADS;
-            if (e < XCHUNK16) xpend[p] = *((const f64x2*)(a.xs + (long long)kc * SW_KC * XS) + e);
-        }
+        for (int i = 0; i < NST; ++i) st[i] = g[i * SW_THREADS];
     };
-    auto stage_commit = [&](int buf) {
+    auto half_store = [&](int buf, int half) {
+        f64x2* l = (f64x2*)(Abuf + buf * SW_TILE) + half * HALF16 + t;
 #pragma unroll
-        for (int p = 0; p < XNP; ++p) {
-            const int e = t + p * SW_THREADS;
-            if (e < XCHUNK16) *((f64x2*)(Xbuf + buf * SW_KC * XS) + e) = xpend[p];
-        }
+        for (int i = 0; i < NST; ++i) l[i * SW_THREADS] = st[i];
+    };
+    // NOTE: every load below is UNCONDITIONAL (indices are clamped instead): a load
+    // under an `if` makes hipcc merge "loaded or old" values and drain vmcnt(0) at
+    // the join, exposing the full memory latency (cdna guide, .s-level trap (c)).
+    const int xt = t < XCHUNK16 ? t : 0;
+    auto x_load = [&](int kc) {
+        xpend = *((const f64x2*)(a.xs + (long long)kc * SW_KC * XS) + xt);
+    };
+    auto x_store = [&](int buf) {
+        if (t < XCHUNK16) *((f64x2*)(Xbuf + buf * SW_KC * XS) + t) = xpend;
     };
 
-    stage_issue(0, 0, 0);
-    stage_commit(0);
-    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) lgkmcnt(0) expcnt(0)
+    // tile sequence: row block ib, chunks kc = 0 .. min((ib+1)*CPB, kc_lim) - 1;
+    // packed tile index = CPB*ib*(ib+1)/2 + kc
+    auto tile_index = [&](int ib, int kc) { return (long long)CPB * ib * (ib + 1) / 2 + kc; };
+    auto nkc_of = [&](int ib) { const int v = CPB * (ib + 1); return v < kc_lim ? v : kc_lim; };
+
+    half_load(0, 0); half_store(0, 0);
+    half_load(0, 1); half_store(0, 1);
+    x_load(0); x_store(0);
     __syncthreads();
 
-    long long tile = 0;
     int buf = 0;
     for (int ib = 0; ib < a.nrb; ++ib) {
-        const int nkc = CPB * (ib + 1);
-        const bool last_rb = (ib == a.nrb - 1);
-        for (int kc = 0; kc < nkc; ++kc, ++tile) {
-            // prefetch the next tile (possibly the first tile of the next row block)
-            const bool more = tile + 1 < ntiles;
-            if (more) stage_issue(tile + 1, (kc + 1 < nkc) ? kc + 1 : 0, buf ^ 1);
-            const double* Ab = Abuf + buf * SW_TILE;
+        const int nkc = nkc_of(ib);
+        double acc[RS][4];
+#pragma unroll
+        for (int s = 0; s < RS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
+        // mu = k* . alpha: only the last row block's pass (which visits every k)
+        // survives -- mupart is reset at the top of each pass
+        mupart = 0.0;
+        int kc = 0;
+        auto do_tile = [&](auto diag_tag) {
+            constexpr bool DIAG = decltype(diag_tag)::value;
+            if (TIMING) tq = __builtin_amdgcn_s_memtime();
+            // next tile in the sequence (possibly the first of the next row block)
+            int nib = ib, nk = kc + 1;
+            if (nk >= nkc) { nib = ib + 1; nk = 0; }
+            const bool more = nib < a.nrb;
+            if (!more) { nib = 0; nk = 0; }          // harmless dummy prefetch on the last tile
+            const long long ntile = tile_index(nib, nk);
+            half_load(ntile, 0);
+            x_load(nk);
             const double* Xb = Xbuf + buf * SW_KC * XS;
-            // W is lower triangular: inside the diagonal row block the 16-row
-            // sub-blocks above the chunk's k range are structurally zero and are
-            // skipped (DIAG path); off-diagonal tiles run the branch-free path.
-            const int smin = (kc - CPB * ib) * (SW_KC / 16);   // <= 0 off the diagonal
-            auto tile_body = [&](auto diag_tag) {
-                constexpr bool DIAG = decltype(diag_tag)::value;
-                constexpr int NKK = SW_KC / 4, NG = NKK * RS;
-                // ---- generate the B operands of the tile's k-steps:
-                //      k*(candidate cl, x_k), k = kc*KC + 4 kk + kq
-                double bfv[NKK];
+            const f64x2* A2 = (const f64x2*)(Abuf + buf * SW_TILE);
+            SW_TICK(0);
+            // ---- generate the B operands of the tile's four k-steps:
+            //      k*(candidate cl, x_k), k = kc*16 + 4 kk + kq
+            double bfv[NKK];
+            {
+                // written across the four k-steps so the four dependent fp64 chains
+                // interleave; two partial sums per chain halve its length
+                double s2[NKK], s3[NKK], al[NKK];
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) { s2[kk] = -a.log_amp; s3[kk] = 0.0; }
+#pragma unroll
+                for (int d = 0; d < DPAD; d += 2) {
+#pragma unroll
+                    for (int kk = 0; kk < NKK; ++kk) {
+                        const double* xr = Xb + (kk * 4 + kq) * XS;
+                        const double df0 = tt[d] - xr[d];
+                        const double df1 = tt[d + 1] - xr[d + 1];
+                        s2[kk] = fma(df0, df0, s2[kk]);
+                        s3[kk] = fma(df1, df1, s3[kk]);
+                    }
+                }
+                double ex[NKK];
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) {
-                    const double* xr = Xb + (kk * 4 + kq) * XS;
-                    double s2 = -a.log_amp;
-#pragma unroll
-                    for (int d = 0; d < DPAD; ++d) {
-                        const double df = tt[d] - xr[d];
-                        s2 = fma(df, df, s2);
-                    }
-                    bfv[kk] = exp(-s2);
-                    if (last_rb) mupart = fma(bfv[kk], xr[DPAD], mupart);
+                    ex[kk] = -(s2[kk] + s3[kk]);
+                    al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
                 }
-                // ---- A fragments (W rows, four rotations each) software-pipelined two
-                //      groups ahead of the matrix-core steps that consume them
-                double afr[3][4];
+                apgp_exp4(ex, bfv, Etab);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    afr[0][r] = Ab[0 * 64 + rot[r]];
-                    afr[1][r] = Ab[1 * 64 + rot[r]];
-                }
+                for (int kk = 0; kk < NKK; ++kk) mupart = fma(bfv[kk], al[kk], mupart);
+            }
+            // keep the A-fragment prefetch below the generation phase (register pressure)
+            __builtin_amdgcn_sched_barrier(0);
+            if (TIMING) { asm volatile("" :: "v"(bfv[0]), "v"(bfv[1]), "v"(bfv[2]), "v"(bfv[3])); SW_TICK(1); }
+            // ---- A fragments: per 16-row sub-block, eight ds_read_b128 fetch the
+            //      four rotations x four k-steps (tile layout [s][kp][lane][q]).
+            auto load_a = [&](f64x2 (&dst)[4][2], int sb) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g + 2 < NG) {
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) afr[(g + 2) % 3][r] = Ab[(g + 2) * 64 + rot[r]];
+                    for (int kp = 0; kp < 2; ++kp) dst[r][kp] = A2[(sb * 2 + kp) * 64 + rot[r]];
+            };
+            if (!DIAG) {
+                // sub-blocks in pairs: 8 independent accumulators per (kk, r) sweep keep
+                // the dependent-accumulate distance at 8 MFMAs; A fragments are
+                // software-pipelined one pair ahead.
+                f64x2 av[2][2][4][2];
+                load_a(av[0][0], 0);
+                load_a(av[0][1], 1);
+#pragma unroll
+                for (int pr = 0; pr < RS / 2; ++pr) {
+                    if (pr + 1 < RS / 2) {
+                        load_a(av[(pr + 1) & 1][0], 2 * pr + 2);
+                        load_a(av[(pr + 1) & 1][1], 2 * pr + 3);
                     }
-                    const int kk = g / RS, sb = g % RS;
-                    if (!DIAG || sb >= smin) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[sb][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(afr[g % 3][r], bfv[kk], acc[sb][r], 0, 0, 0);
+                    for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[2 * pr][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                                av[pr & 1][0][r][kk >> 1][kk & 1], bfv[kk], acc[2 * pr][r], 0, 0, 0);
+                            acc[2 * pr + 1][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                                av[pr & 1][1][r][kk >> 1][kk & 1], bfv[kk], acc[2 * pr + 1][r], 0, 0, 0);
+                        }
+                    if (pr == RS / 4 - 1) {
+                        // mid-tile: first half has landed long ago; park it in LDS and
+                        // reuse the staging registers for the second half
+                        half_store(buf ^ 1, 0);
+                        half_load(ntile, 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            };
-            if (smin > 0) tile_body(std::true_type{});
-            else tile_body(std::false_type{});
-            if (kc == nkc - 1) {
-                // row block finished: fold ||V||^2 into the per-candidate sum
+            } else {
+                // diagonal row block: W is lower triangular, so 16-row sub-blocks above
+                // the chunk's k range are structurally zero, and rows >= N are padding.
+                const int smin = kc - CPB * ib;
+                const int smax = sb_lim - RS * ib;
+                f64x2 av[2][4][2];
+                load_a(av[0], 0);
 #pragma unroll
-                for (int s = 0; s < RS; ++s)
+                for (int sb = 0; sb < RS; ++sb) {
+                    if (sb + 1 < RS) load_a(av[(sb + 1) & 1], sb + 1);
+                    if (sb >= smin && sb < smax) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        qpart = fma(acc[s][r], acc[s][r], qpart);
-                        acc[s][r] = 0.0;
+                        for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc[sb][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                                    av[sb & 1][r][kk >> 1][kk & 1], bfv[kk], acc[sb][r], 0, 0, 0);
                     }
+                    if (sb == RS / 2 - 1) {
+                        half_store(buf ^ 1, 0);
+                        half_load(ntile, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if (more) stage_commit(buf ^ 1);
-            __builtin_amdgcn_s_waitcnt(0);
+            SW_TICK(2);
+            half_store(buf ^ 1, 1);
+            x_store(buf ^ 1);
+            SW_TICK(3);
             __syncthreads();
+            SW_TICK(4);
             buf ^= 1;
-        }
+        };
+        const int ndiag0 = CPB * ib;   // first chunk of the diagonal block
+        for (; kc < nkc && kc < ndiag0; ++kc) do_tile(std::false_type{});
+        for (; kc < nkc; ++kc) do_tile(std::true_type{});
+        // row block finished: fold ||V||^2 into the per-candidate sum
+#pragma unroll
+        for (int s = 0; s < RS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qpart = fma(acc[s][r], acc[s][r], qpart);
     }
 
+    if (TIMING && a.dbg && blockIdx.x == 0 && t == 0) {
+        for (int i = 0; i < 5; ++i) a.dbg[i] = tph[i];
+        long long nt = 0;
+        for (int ib = 0; ib < a.nrb; ++ib) nt += nkc_of(ib);
+        a.dbg[5] = (unsigned long long)nt;
+    }
     // ---- reduce over the four k-quarters / row-quarters of the wavefront ------
     qpart += __shfl_xor(qpart, 16);
     qpart += __shfl_xor(qpart, 32);
@@ -249,8 +333,9 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     double bu = INFINITY;
     long long bi = -1;
     if (kq == 0 && crow < a.m) {
-        const double mu = mupart + a.mean;
-        const double var = a.amp - qpart;
+        double mu = mupart + a.mean;
+        double var = a.amp - qpart;
+        if (has_nan) { mu = NAN; var = NAN; }     // george propagates NaN coordinates
         if (a.mu) a.mu[crow] = mu;
         if (a.var) a.var[crow] = var;
         if (a.kind != APGP_UTIL_NONE) {
@@ -301,15 +386,33 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 
 template <int DPAD>
 static int launch_sweep(const SweepArgs& a, hipStream_t s) {
-    const size_t lds = (2 * SW_TILE + 2 * SW_KC * (DPAD + 2)) * sizeof(double);
+    const size_t lds = (2 * SW_TILE + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD>,
+        (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const unsigned nblk = (unsigned)((a.m + SW_CAND - 1) / SW_CAND);
-    hipLaunchKernelGGL(sweep_kernel<DPAD>, dim3(nblk), dim3(SW_THREADS), lds, s, a);
+    static int timing = -1;
+    if (timing < 0) { const char* e = getenv("APGP_SWEEP_TIMING"); timing = (e && e[0] == '1') ? 1 : 0; }
+    if (timing && DPAD == 8) {
+        // developer instrumentation: per-phase s_memtime cycles of block 0 / wave 0
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, 8 * sizeof(unsigned long long));
+        SweepArgs b = a;
+        b.dbg = dbg;
+        (void)hipFuncSetAttribute((const void*)sweep_kernel<8, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((sweep_kernel<8, true>), dim3(nblk), dim3(SW_THREADS), lds, s, b);
+        unsigned long long h[8];
+        (void)hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "[apgp sweep timing] tiles %llu | per tile cycles: stage %.0f gen %.0f mfma %.0f commit %.0f wait+barrier %.0f\n",
+                h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
+        return 0;
+    }
+    hipLaunchKernelGGL((sweep_kernel<DPAD, false>), dim3(nblk), dim3(SW_THREADS), lds, s, a);
     return 0;
 }
 
@@ -326,13 +429,13 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     KernConst kc;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
     SweepArgs a;
-    a.T = T; a.linv = packed_linv; a.xs = xs; a.mask = mask;
+    a.T = T; a.linv = packed_linv; a.xs = xs; a.mask = mask; a.dbg = NULL;
     a.mu = mu; a.var = var; a.u = u;
     const long long nblk = (m + SW_CAND - 1) / SW_CAND;
     a.part_u = (double*)part;
     a.part_i = part ? (long long*)((double*)part + nblk) : NULL;
     a.m = m; a.idx_offset = idx_offset;
-    a.ndim = kc.ndim; a.nrb = (int)(apgp_npad(n) / APGP_ROW_BLOCK); a.kind = kind;
+    a.ndim = kc.ndim; a.nrb = (int)(apgp_npad(n) / APGP_ROW_BLOCK); a.kind = kind; a.n = (int)n;
     a.has_box = lo != NULL;
     a.mean = mean; a.amp = kc.amp; a.log_amp = kc.log_amp; a.zeta = zeta; a.ybest = ybest;
     for (int d = 0; d < APGP_MAX_DIM; ++d) {
@@ -370,6 +473,9 @@ struct MeanArgs {
 template <int DPAD>
 __global__ __launch_bounds__(256) void predict_mean_kernel(MeanArgs a) {
     constexpr int XS = DPAD + 2;
+    __shared__ double etab[APGP_EXP_TAB_N];
+    apgp_exp_tab_load(etab);
+    __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long row = (long long)blockIdx.x * 4 + w;
     if (row >= a.m) return;
@@ -379,16 +485,20 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(MeanArgs a) {
     double acc = 0.0;
     for (long long k = lane; k < a.npad; k += 64) {
         const double* xr = a.xs + k * XS;
-        double s = -a.log_amp;
+        double s = -a.log_amp, s3 = 0.0;
 #pragma unroll
-        for (int d = 0; d < DPAD; ++d) {
-            double df = tt[d] - xr[d];
-            s = fma(df, df, s);
+        for (int d = 0; d < DPAD; d += 2) {
+            double df0 = tt[d] - xr[d];
+            double df1 = tt[d + 1] - xr[d + 1];
+            s = fma(df0, df0, s);
+            s3 = fma(df1, df1, s3);
         }
-        acc = fma(exp(-s), xr[DPAD], acc);
+        acc = fma(apgp_exp(-(s + s3), etab), xr[DPAD], acc);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) a.mu[row] = acc + a.mean;
+    bool bad = false;
+    for (int d = 0; d < DPAD; ++d) bad = bad || (tt[d] != tt[d]);
+    if (lane == 0) a.mu[row] = bad ? NAN : acc + a.mean;
 }
 
 extern "C" int apgp_predict_mean(const double* T, int64_t m, const double* xs, int64_t n,

@@ -32,7 +32,7 @@ extern "C" {
 
 #define APGP_ABI_VERSION 1
 #define APGP_MAX_DIM 16          /* feature dimension D supported by the kernels */
-#define APGP_ROW_BLOCK 256       /* rows per packed L^-1 row block (sweep tile)  */
+#define APGP_ROW_BLOCK 512       /* rows per packed L^-1 row block (sweep tile)  */
 #define APGP_K_CHUNK 16          /* contraction depth per packed tile            */
 #define APGP_CAND_BLOCK 64       /* candidates per sweep workgroup                */
 
@@ -69,7 +69,7 @@ int apgp_abi_version(void);
 const char* apgp_last_error(void);
 
 /* ---- sizes ------------------------------------------------------------- */
-/* N rounded up to the packed row block (256).                               */
+/* N rounded up to the packed row block (512).                               */
 int64_t apgp_npad(int64_t n);
 /* doubles in the packed lower-triangular L^-1 image for N training points.  */
 int64_t apgp_packed_linv_len(int64_t n);
@@ -104,7 +104,7 @@ int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double s
 
 /* ---- L^-1 in the sweep's packed tile layout --------------------------------
  * Computes W = L^-1 (blocked recursive triangular inversion, MFMA-f64 GEMM
- * merges) and writes it as lower-triangular 256 x 16 tiles in MFMA A-fragment
+ * merges) and writes it as lower-triangular 512 x 16 tiles in MFMA A-fragment
  * order (see DESIGN.md "packed factor").  This is what lets the sweep evaluate
  * BasicSolver.apply_inverse(Kxs.T) (george GP.predict, utility.py:131,178,224)
  * for millions of candidates without materialising Kxs.

@@ -34,13 +34,12 @@ __global__ __launch_bounds__(256) void peak(double* out, unsigned long long* cyc
 }
 
 template <int NACC, int NV, int RV, int SMALL>
-void run(const char* name, int blocks_per_cu) {
+void run(const char* name, int blocks_per_cu, int iters = 4000) {
     double* out;
     unsigned long long* cyc;
     int nblk = 256 * blocks_per_cu;
     (void)hipMalloc(&out, sizeof(double) * nblk * 256);
     (void)hipMalloc(&cyc, 8);
-    int iters = 4000;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     hipLaunchKernelGGL((peak<NACC, NV, RV, SMALL>), dim3(nblk), dim3(256), 0, 0, out, cyc, 100, 0.5);
@@ -69,6 +68,10 @@ int main() {
     run<16, 0, 0, 0>("mfma16x16x4 x16", 2);
     run<16, 0, 0, 1>("mfma4x4x4_4b x16", 1);
     run<16, 0, 0, 1>("mfma4x4x4_4b x16", 2);
+    run<4, 0, 0, 1>("mfma4x4x4_4b x4 (dep dist 4)", 1);
+    run<8, 0, 0, 1>("mfma4x4x4_4b x8 (dep dist 8)", 1);
+    run<2, 0, 0, 1>("mfma4x4x4_4b x2 (dep dist 2)", 1);
+    run<1, 0, 0, 1>("mfma4x4x4_4b x1 (dep dist 1)", 1);
     run<0, 16, 8, 0>("valu fma x128", 1);
     run<0, 16, 8, 0>("valu fma x128", 2);
     run<0, 16, 8, 0>("valu fma x128", 4);
@@ -80,5 +83,6 @@ int main() {
     run<16, 16, 8, 0>("mfma x16 + valu x128", 2);
     run<16, 16, 16, 0>("mfma x16 + valu x256", 2);
     run<16, 16, 24, 0>("mfma x16 + valu x384", 2);
+    run<16, 0, 0, 1>("mfma4x4x4_4b x16 SUSTAINED", 1, 1000000);
     return 0;
 }
