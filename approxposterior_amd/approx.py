@@ -1,0 +1,224 @@
+# -*- coding: utf-8 -*-
+"""
+:py:mod:`approx.py` - ApproxPosterior: the callers of the GP-surrogate hot path
+-------------------------------------------------------------------------------
+
+Mirror of the hot-path callers of the reference's ``approxposterior/approx.py``:
+``ApproxPosterior.__init__`` (:77-145), ``_gpll`` (:148-189), ``optGP``
+(:192-226) and ``findNextPoint`` (:527-754), with the same signatures, defaults,
+return shapes and error behaviour, running on the HIP-backed GP of
+:py:mod:`approxposterior_amd.gp`.
+
+Additions the reference does not have (all off by default so reference-style
+scripts behave the same):
+
+* ``findNextPoint(nCandidates=M)`` replaces the restarted Nelder-Mead search by
+  the fused device sweep over ``M`` prior draws (optionally polished by one
+  Nelder-Mead run from the winner);
+* ``_gpllBatch`` evaluates the surrogate log-probability for a whole walker
+  ensemble in one launch (what an ensemble sampler calls with vectorize=True).
+
+The MCMC / outer-loop glue (``run``, ``runMCMC``, ``findMAP``, ``bayesOpt``) is
+"next"-row scope and lives in later rounds.
+"""
+
+import numpy as np
+from scipy.optimize import minimize
+
+from . import gp as george
+from . import gpUtils
+from . import utility as ut
+
+__all__ = ["ApproxPosterior"]
+
+
+class ApproxPosterior(object):
+    """Approximate-posterior driver around a GP surrogate (approx.py:29-145).
+
+    Parameters are those of the reference: the training set ``theta`` (N, D) /
+    ``y`` (N,), the callables ``lnprior``, ``lnlike``, ``priorSample``, the box
+    ``bounds`` (one (lo, hi) per dimension), an optional pre-built ``gp`` and
+    the point-selection ``algorithm`` in {"bape", "agp", "alternate", "jones"}.
+    """
+
+    def __init__(self, theta, y, lnprior, lnlike, priorSample, bounds, gp=None,
+                 algorithm="bape"):
+        if theta is None or y is None:
+            raise ValueError("Must supply both theta and y for initial GP training set.")
+        self.theta = np.array(theta).squeeze()
+        self.y = np.array(y).squeeze()
+        self.ndim = 1 if self.theta.ndim <= 1 else theta.shape[-1]
+        if np.any(~np.isfinite(self.theta)) or np.any(~np.isfinite(self.y)):
+            print("theta, y:", theta, y)
+            raise ValueError("All theta and y values must be finite!")
+        if len(bounds) != self.ndim:
+            raise ValueError("ERROR: bounds provided but len(bounds) != ndim.\n"
+                             "ndim = %d, len(bounds) = %d" % (self.ndim, len(bounds)))
+        self.bounds = bounds
+        self._lnprior = lnprior
+        self._lnlike = lnlike
+        self.priorSample = priorSample
+        self.algorithm = str(algorithm).lower()
+        table = {"bape": ut.BAPEUtility, "agp": ut.AGPUtility,
+                 "alternate": ut.AGPUtility, "jones": ut.JonesUtility}
+        if self.algorithm not in table:
+            raise ValueError("Unknown algorithm. Valid options: bape, agp, naive, or alternate.")
+        self.utility = table[self.algorithm]
+        self.iburns = list()
+        self.ithins = list()
+        self.backends = list()
+        self.sampler = None
+        self.gpPar = list()
+        if gp is None:
+            print("INFO: No GP specified. Initializing GP using ExpSquaredKernel.")
+            self.gp = gpUtils.defaultGP(self.theta, self.y)
+        else:
+            self.gp = gp
+
+    # ------------------------------------------------------------------ _gpll
+    def _gpll(self, theta, *args, **kwargs):
+        """Surrogate log-probability for one point: ``(mu(theta), lnprior)`` or
+        ``(-inf, nan)`` under the reference's three guards (approx.py:148-189):
+        all-non-finite theta, non-finite prior, non-finite / failed prediction."""
+        if not np.any(np.isfinite(theta)):
+            return -np.inf, np.nan
+        lnprior = self._lnprior(theta)
+        if not np.isfinite(lnprior):
+            return -np.inf, np.nan
+        try:
+            mu = self.gp.predict(self.y, np.array(theta).reshape(1, -1),
+                                 return_cov=False, return_var=False)
+        except ValueError:
+            return -np.inf, np.nan
+        if not np.isfinite(mu):
+            return -np.inf, np.nan
+        return mu, lnprior
+
+    def _gpllBatch(self, thetas):
+        """Vectorised :meth:`_gpll` for a walker ensemble ``thetas`` (W, D): one
+        mean-only device launch.  Returns ``(logp (W,), lnprior (W,))`` with the
+        same guard semantics row by row."""
+        thetas = np.asarray(thetas, dtype=float)
+        if thetas.ndim == 1:
+            thetas = thetas.reshape(-1, self.ndim)
+        W = len(thetas)
+        lp = np.full(W, -np.inf)
+        blob = np.full(W, np.nan)
+        pri = np.array([self._lnprior(t) if np.any(np.isfinite(t)) else -np.inf for t in thetas],
+                       dtype=float)
+        ok = np.isfinite(pri)
+        if ok.any():
+            safe = np.where(np.isfinite(thetas[ok]), thetas[ok], 0.0)
+            mu = self.gp.predict(self.y, safe, return_cov=False, return_var=False)
+            mu = np.where(np.all(np.isfinite(thetas[ok]), axis=1), mu, np.nan)
+            good = np.isfinite(mu)
+            idx = np.flatnonzero(ok)
+            lp[idx[good]] = mu[good]
+            blob[idx[good]] = pri[idx[good]]
+        return lp, blob
+
+    # ------------------------------------------------------------------ optGP
+    def optGP(self, seed=None, method="powell", options=None, p0=None,
+              nGPRestarts=1, gpHyperPrior=gpUtils.defaultHyperPrior):
+        """Re-fit the GP hyper-parameters in place (approx.py:192-226)."""
+        self.gp = gpUtils.optimizeGP(self.gp, self.theta, self.y, seed=seed,
+                                     method=method, options=options, p0=p0,
+                                     nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
+
+    # ---------------------------------------------------------- findNextPoint
+    def findNextPoint(self, theta0=None, computeLnLike=True, seed=None,
+                      cache=True, gpOptions=None, gpP0=None, verbose=True,
+                      nGPRestarts=1, nMinObjRestarts=5, gpMethod="powell",
+                      minObjMethod="nelder-mead", minObjOptions=None,
+                      runName="apRun", numNewPoints=1, optGPEveryN=1,
+                      gpHyperPrior=gpUtils.defaultHyperPrior, args=None,
+                      nCandidates=None, polish=False, **kwargs):
+        """Select ``numNewPoints`` design points by minimising the (negative)
+        utility, optionally evaluate the forward model there, append to the
+        training set, re-factorise and periodically re-fit the GP
+        (approx.py:527-754; same return shapes :745-753).
+
+        With ``nCandidates`` the point search is the fused device sweep over
+        that many ``priorSample`` draws (box ``bounds`` fused as the prior)
+        instead of ``nMinObjRestarts`` Nelder-Mead runs; ``polish`` then refines
+        the winner with one Nelder-Mead run of the scalar utility.
+        """
+        assert isinstance(numNewPoints, int) and numNewPoints >= 1
+        assert isinstance(optGPEveryN, int) and optGPEveryN >= 1
+        if verbose and numNewPoints < optGPEveryN:
+            print("WARNING: numNewPoints < optGPEveryN."
+                  "GP hyperparameters will not be re-optimized. Set "
+                  "numNewPoints < optGPEveryN to fix this, if important (it probably is).")
+        if args is None:
+            args = ()
+        newTheta = list()
+        newY = list()
+        for ii in range(numNewPoints):
+            if self.algorithm == "alternate":      # AGP on even, BAPE on odd (approx.py:656-661)
+                self.utility = ut.AGPUtility if ii % 2 == 0 else ut.BAPEUtility
+            if nCandidates is None:
+                thetaT, uT = ut.minimizeObjective(self.utility, self.y, self.gp,
+                                                  sampleFn=self.priorSample,
+                                                  priorFn=self._lnprior,
+                                                  nRestarts=nMinObjRestarts,
+                                                  method=minObjMethod,
+                                                  options=minObjOptions,
+                                                  bounds=self.bounds, theta0=theta0,
+                                                  args=(self.y, self.gp, self._lnprior))
+            else:
+                cands = np.asarray(self.priorSample(int(nCandidates)), dtype=float)
+                cands = cands.reshape(int(nCandidates), -1)
+                thetaT, uT = ut.sweepObjective(self.utility, self.y, self.gp, cands,
+                                               bounds=self.bounds)
+                if polish:
+                    thetaT, uT = ut.minimizeObjective(self.utility, self.y, self.gp,
+                                                      sampleFn=self.priorSample,
+                                                      priorFn=self._lnprior, nRestarts=1,
+                                                      method=minObjMethod, options=minObjOptions,
+                                                      bounds=self.bounds, theta0=thetaT,
+                                                      args=(self.y, self.gp, self._lnprior))
+            newTheta.append(thetaT)
+            if computeLnLike:
+                loglikeT = self._lnlike(thetaT, *args, **kwargs)
+                if hasattr(loglikeT, "__iter__"):
+                    yT = np.array([loglikeT[0] + self._lnprior(thetaT)])
+                else:
+                    yT = np.array([loglikeT + self._lnprior(thetaT)])
+                newY.append(yT)
+                if self.theta.ndim > 1:
+                    self.theta = np.vstack([self.theta, np.array(thetaT)])
+                else:
+                    self.theta = np.hstack([self.theta, thetaT])
+                self.y = np.hstack([self.y, yT])
+                try:
+                    currentHype = self.gp.get_parameter_vector()
+                    if verbose:
+                        print('hyperparameters', currentHype)
+                    if cache:
+                        self.gpPar.append(currentHype)
+                    # same kernel / mean / white-noise objects, new training set
+                    self.gp = george.GP(kernel=self.gp.kernel, fit_mean=True,
+                                        mean=self.gp.mean,
+                                        white_noise=self.gp.white_noise,
+                                        fit_white_noise=False)
+                    self.gp.set_parameter_vector(currentHype)
+                    self.gp.compute(self.theta)
+                    if ii % optGPEveryN == 0:
+                        self.optGP(seed=seed, method=gpMethod, options=gpOptions,
+                                   p0=gpP0, nGPRestarts=nGPRestarts,
+                                   gpHyperPrior=gpHyperPrior)
+                except ValueError:
+                    print("theta:", self.theta)
+                    print("y:", self.y)
+                    print("gp parameters names:", self.gp.get_parameter_names())
+                    print("gp parameters:", self.gp.get_parameter_vector())
+                    raise ValueError("GP couldn't optimize!")
+                if cache:
+                    np.savez(str(runName) + "APFModelCache.npz", theta=self.theta, y=self.y)
+        if numNewPoints == 1:
+            newTheta = newTheta[0]
+            if computeLnLike:
+                newY = newY[0]
+        if computeLnLike:
+            return np.asarray(newTheta), np.asarray(newY)
+        return np.asarray(newTheta)

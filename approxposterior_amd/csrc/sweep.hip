@@ -255,12 +255,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 load_a(av[0][1], 1);
 #pragma unroll
                 for (int pr = 0; pr < RS / 2; ++pr) {
-                    if (pr + 1 < RS / 2) {
-                        load_a(av[(pr + 1) & 1][0], 2 * pr + 2);
-                        load_a(av[(pr + 1) & 1][1], 2 * pr + 3);
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < NKK; ++kk)
+                    auto mfma_pair = [&](int kk) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             acc[2 * pr][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
@@ -268,6 +263,20 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                             acc[2 * pr + 1][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
                                 av[pr & 1][1][r][kk >> 1][kk & 1], bfv[kk], acc[2 * pr + 1][r], 0, 0, 0);
                         }
+                    };
+                    // The LDS counter saturates at 15: issuing the next pair's 16 reads
+                    // BEFORE this pair's first MFMA would force a wait on fresh reads.
+                    // So: first k-step (its operands landed during the previous pair),
+                    // then the prefetch, then the remaining three k-steps.
+                    mfma_pair(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pr + 1 < RS / 2) {
+                        load_a(av[(pr + 1) & 1][0], 2 * pr + 2);
+                        load_a(av[(pr + 1) & 1][1], 2 * pr + 3);
+                    }
+                    mfma_pair(1);
+                    mfma_pair(2);
+                    mfma_pair(3);
                     if (pr == RS / 4 - 1) {
                         // mid-tile: first half has landed long ago; park it in LDS and
                         // reuse the staging registers for the second half

@@ -1,0 +1,82 @@
+"""CPU, world_size 2 over gloo: the candidate-sharded acquisition's collective
+(approxposterior_amd.dist).  The per-shard evaluator is the oracle (there is no
+HIP on this box); what is tested is the sharding, the 16-byte all-gather record,
+the tie-break and that every rank gets the single-process answer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from approxposterior_amd.dist import combine_best, shard_bounds, sharded_acquire
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_everything():
+    for m in (0, 1, 7, 64, 1000003):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(m, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == m
+            for a, b in zip(spans[:-1], spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_combine_best_rules():
+    assert combine_best([(np.inf, -1), (np.nan, 5)]) == (-1, np.inf)
+    assert combine_best([(1.0, 9), (1.0, 3), (2.0, 0)]) == (3, 1.0)       # tie -> lowest index
+    assert combine_best([(np.nan, 0), (-2.0, 8)]) == (8, -2.0)            # NaN never wins
+    assert combine_best([(np.inf, 4), (np.inf, 2)]) == (2, np.inf)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, u_all, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(len(u_all), world, rank)
+
+    def local(off):
+        u = u_all[lo:hi]
+        um = np.where(np.isnan(u), np.inf, u)
+        if len(u) == 0 or not np.isfinite(um).any():
+            return -1, np.inf
+        i = int(np.argmin(um))
+        return off + i, float(um[i])
+
+    res = sharded_acquire(local, lo)
+    np.save(out_path % rank, np.array([res[0], res[1]], dtype=np.float64))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["random", "tie_across_ranks", "all_inadmissible"])
+def test_sharded_acquire_world2_gloo(tmp_path, case):
+    rs = np.random.RandomState(5)
+    u = rs.normal(size=1001)
+    u[17] = np.nan
+    if case == "tie_across_ranks":
+        u[10] = u[900] = u.min() - 1.0
+    if case == "all_inadmissible":
+        u[:] = np.inf
+    um = np.where(np.isnan(u), np.inf, u)
+    want = (int(np.argmin(um)), float(um.min())) if np.isfinite(um).any() else (-1, np.inf)
+    port = _free_port()
+    out = str(tmp_path / "r%d.npy")
+    mp.spawn(_worker, args=(2, port, u, out), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(out % r)
+        assert int(got[0]) == want[0] and got[1] == want[1]
