@@ -71,8 +71,8 @@ __device__ __forceinline__ double util_value(int kind, double mu, double var, do
 }
 
 __device__ __forceinline__ void best_merge(double& bu, long long& bi, double u, long long i) {
-    // NaN never wins; ties resolve to the lowest global index
-    if (i >= 0 && (u < bu || (u == bu && (bi < 0 || i < bi)))) { bu = u; bi = i; }
+    // NaN and +inf (inadmissible) never win; ties resolve to the lowest global index
+    if (i >= 0 && u < INFINITY && (u < bu || (u == bu && (bi < 0 || i < bi)))) { bu = u; bi = i; }
 }
 
 // Matrix-core instruction choice (measured on MI355X, tools/mfma_peak.hip and

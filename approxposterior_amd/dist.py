@@ -31,12 +31,13 @@ def shard_bounds(m, world_size, rank):
 
 
 def combine_best(pairs):
-    """Arg-min over (u, global_index) pairs: NaN never wins, index -1 = no
-    admissible candidate, ties -> lowest global index."""
+    """Arg-min over (u, global_index) pairs: NaN and +inf never win, index -1 =
+    no admissible candidate, ties -> lowest global index (same rule as the
+    device reduction)."""
     best_u, best_i = np.inf, -1
     for u, i in pairs:
         i = int(i)
-        if i < 0 or np.isnan(u):
+        if i < 0 or np.isnan(u) or u == np.inf:
             continue
         if u < best_u or (u == best_u and (best_i < 0 or i < best_i)):
             best_u, best_i = float(u), i

@@ -32,7 +32,7 @@ def test_combine_best_rules():
     assert combine_best([(np.inf, -1), (np.nan, 5)]) == (-1, np.inf)
     assert combine_best([(1.0, 9), (1.0, 3), (2.0, 0)]) == (3, 1.0)       # tie -> lowest index
     assert combine_best([(np.nan, 0), (-2.0, 8)]) == (8, -2.0)            # NaN never wins
-    assert combine_best([(np.inf, 4), (np.inf, 2)]) == (2, np.inf)
+    assert combine_best([(np.inf, 4), (np.inf, 2)]) == (-1, np.inf)          # +inf never wins
 
 
 def _free_port():
