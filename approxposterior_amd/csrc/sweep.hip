@@ -158,6 +158,19 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) l[i * SW_THREADS] = st[i];
     };
+    // two pieces (j0, j0+1) of a half tile: the staging traffic is dealt two
+    // instructions per sub-block pair into the MFMA stream (non-fp64 instructions
+    // cost ~1 cycle there; a cluster of them idles the matrix pipe)
+    auto piece_load = [&](long long tile, int half, int j0) {
+        const f64x2* g = (const f64x2*)(a.linv + tile * SW_TILE) + half * HALF16 + t;
+        st[j0] = g[j0 * SW_THREADS];
+        st[j0 + 1] = g[(j0 + 1) * SW_THREADS];
+    };
+    auto piece_store = [&](int buf, int half, int j0) {
+        f64x2* l = (f64x2*)(Abuf + buf * SW_TILE) + half * HALF16 + t;
+        l[j0 * SW_THREADS] = st[j0];
+        l[(j0 + 1) * SW_THREADS] = st[j0 + 1];
+    };
     // NOTE: every load below is UNCONDITIONAL (indices are clamped instead): a load
     // under an `if` makes hipcc merge "loaded or old" values and drain vmcnt(0) at
     // the join, exposing the full memory latency (cdna guide, .s-level trap (c)).
@@ -200,7 +213,6 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
             const bool more = nib < a.nrb;
             if (!more) { nib = 0; nk = 0; }          // harmless dummy prefetch on the last tile
             const long long ntile = tile_index(nib, nk);
-            half_load(ntile, 0);
             x_load(nk);
             const double* Xb = Xbuf + buf * SW_KC * XS;
             const f64x2* A2 = (const f64x2*)(Abuf + buf * SW_TILE);
@@ -277,12 +289,13 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                     mfma_pair(1);
                     mfma_pair(2);
                     mfma_pair(3);
-                    if (pr == RS / 4 - 1) {
-                        // mid-tile: first half has landed long ago; park it in LDS and
-                        // reuse the staging registers for the second half
-                        half_store(buf ^ 1, 0);
-                        half_load(ntile, 1);
-                    }
+                    // staging of the next tile, two instructions per pair:
+                    // pairs 0-3 load half 0, 4-7 store it, 8-11 load half 1, 12-15 store it
+                    if (pr < 4) piece_load(ntile, 0, 2 * pr);
+                    else if (pr < 8) piece_store(buf ^ 1, 0, 2 * (pr - 4));
+                    else if (pr < 12) piece_load(ntile, 1, 2 * (pr - 8));
+                    else piece_store(buf ^ 1, 1, 2 * (pr - 12));
+                    if (pr == RS / 2 - 1) x_store(buf ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -303,16 +316,18 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                                 acc[sb][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
                                     av[sb & 1][r][kk >> 1][kk & 1], bfv[kk], acc[sb][r], 0, 0, 0);
                     }
-                    if (sb == RS / 2 - 1) {
-                        half_store(buf ^ 1, 0);
-                        half_load(ntile, 1);
+                    if ((sb & 1) == 1) {
+                        const int pr = sb >> 1;
+                        if (pr < 4) piece_load(ntile, 0, 2 * pr);
+                        else if (pr < 8) piece_store(buf ^ 1, 0, 2 * (pr - 4));
+                        else if (pr < 12) piece_load(ntile, 1, 2 * (pr - 8));
+                        else piece_store(buf ^ 1, 1, 2 * (pr - 12));
+                        if (pr == RS / 2 - 1) x_store(buf ^ 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             SW_TICK(2);
-            half_store(buf ^ 1, 1);
-            x_store(buf ^ 1);
             SW_TICK(3);
             __syncthreads();
             SW_TICK(4);
