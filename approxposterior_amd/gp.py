@@ -46,6 +46,11 @@ UTILITY_KINDS = {"agp": _lib.UTIL_AGP, "bape": _lib.UTIL_BAPE, "jones": _lib.UTI
 # section 7, "Conditioning vs. formulation").
 COND_WARN = 1.0e12
 
+# APGP_CHOLESKY=rocsolver routes the factorisation through torch.linalg.cholesky_ex
+# (rocSOLVER dpotrf) instead of the in-tree blocked Cholesky -- for A/B checks only.
+import os as _os
+_USE_ROCSOLVER = _os.environ.get("APGP_CHOLESKY", "").lower() == "rocsolver"
+
 
 # ---------------------------------------------------------------------------
 # Host-side parameter objects (no arithmetic lives here)
@@ -338,12 +343,18 @@ class GP(object):
             K = torch.empty((n, n), dtype=torch.float64, device=dev)
             _lib.check(lib.apgp_gram(self._x_d.data_ptr(), n, ctypes.byref(ks), K.data_ptr(), n, st),
                        "apgp_gram")
-            # rocSOLVER potrf works column-major: asking for the UPPER factor makes
-            # its memory image the row-major LOWER factor the kernels stream.
-            U, info = torch.linalg.cholesky_ex(K, upper=True, check_errors=False)
-            L = U.mT
-            if not L.is_contiguous():
-                L = L.contiguous()
+            if _USE_ROCSOLVER:
+                # rocSOLVER potrf works column-major: asking for the UPPER factor makes
+                # its memory image the row-major LOWER factor the kernels stream.
+                U, info = torch.linalg.cholesky_ex(K, upper=True, check_errors=False)
+                L = U.mT
+                if not L.is_contiguous():
+                    L = L.contiguous()
+            else:
+                # own blocked Cholesky (csrc/potrf.hip), in place on the Gram matrix
+                info = torch.empty(1, dtype=torch.int32, device=dev)
+                _lib.check(lib.apgp_potrf(K.data_ptr(), n, n, info.data_ptr(), st), "apgp_potrf")
+                L = K
             out3 = torch.empty(3, dtype=torch.float64, device=dev)
             _lib.check(lib.apgp_logdet(L.data_ptr(), n, n, out3.data_ptr(), st), "apgp_logdet")
             info = int(info.item())

@@ -86,6 +86,14 @@ int64_t apgp_trtri_work_len(int64_t n);
 int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
               double* K, int64_t ldk, void* stream);
 
+/* ---- Cholesky factorisation (lower, row-major, in place) -------------------
+ * Replaces scipy.linalg.cholesky inside george BasicSolver.compute (every
+ * gpUtils._nll evaluation, gpUtils.py:74-78; GP.compute, gpUtils.py:178,
+ * approx.py:717).  Only the lower triangle of A is read and written.
+ * *info_dev (device int32): 0 = OK, k > 0 = leading minor of order k is not
+ * positive definite (LAPACK dpotrf convention; george/SciPy raise LinAlgError). */
+int apgp_potrf(double* A, int64_t n, int64_t lda, int32_t* info_dev, void* stream);
+
 /* ---- K2: log-determinant and diagonal range of the Cholesky factor -------
  * Replaces BasicSolver.compute's ``2*sum(log(diag(U)))`` (george; feeds
  * GP._const used by gpUtils._nll, gpUtils.py:78).  L is the lower factor
