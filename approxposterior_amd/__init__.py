@@ -12,8 +12,9 @@ there is no CPU fallback.
 
 __version__ = "0.1.0"
 
-from . import gp, gpUtils, utility, likelihood, approx, dist  # noqa: F401
+from . import gp, gpUtils, utility, likelihood, mcmc, mcmcUtils, approx, dist  # noqa: F401
 from .approx import ApproxPosterior  # noqa: F401
 from .gpUtils import defaultHyperPrior, defaultGP, optimizeGP  # noqa: F401
+from .mcmcUtils import validateMCMCKwargs, batchMeansMCSE, estimateBurnin  # noqa: F401
 from .utility import (logsubexp, AGPUtility, BAPEUtility, JonesUtility,  # noqa: F401
                       minimizeObjective, sweepObjective)

@@ -18,15 +18,22 @@ scripts behave the same):
 * ``_gpllBatch`` evaluates the surrogate log-probability for a whole walker
   ensemble in one launch (what an ensemble sampler calls with vectorize=True).
 
-The MCMC / outer-loop glue (``run``, ``runMCMC``, ``findMAP``, ``bayesOpt``) is
-"next"-row scope and lives in later rounds.
+The outer-loop glue -- ``run`` (:229-524), ``runMCMC`` (:757-859), ``findMAP``
+(:862-926), ``bayesOpt`` (:929-1151) -- follows the reference's control flow on
+top of the build-side ensemble sampler (:py:mod:`approxposterior_amd.mcmc`,
+emcee is not installable here) and writes the same ``.npz`` caches; the emcee
+HDF5 backend is replaced by a ``<runName>.npz`` chain dump (h5py is absent).
 """
 
 import numpy as np
 from scipy.optimize import minimize
 
+import time
+
 from . import gp as george
 from . import gpUtils
+from . import mcmc as emcee   # drop-in for the ``emcee`` names used below
+from . import mcmcUtils
 from . import utility as ut
 
 __all__ = ["ApproxPosterior"]
@@ -222,3 +229,223 @@ class ApproxPosterior(object):
         if computeLnLike:
             return np.asarray(newTheta), np.asarray(newY)
         return np.asarray(newTheta)
+
+    # ---------------------------------------------------------------- runMCMC
+    def runMCMC(self, samplerKwargs=None, mcmcKwargs=None, runName="apRun",
+                cache=True, estBurnin=True, thinChains=True, verbose=False,
+                args=None, batched=True, **kwargs):
+        """Sample the GP surrogate posterior with the stretch-move ensemble
+        sampler and estimate burn-in / thinning (approx.py:757-859).  Returns
+        ``(sampler, iburn, ithin)``.
+
+        ``batched=True`` (default) evaluates each half-ensemble with ONE
+        mean-only GP launch (``_gpllBatch``); ``batched=False`` calls the scalar
+        ``_gpll`` once per walker exactly as emcee does for the reference.
+        With ``cache=True`` the finished chain is written to ``<runName>.npz``
+        (keys chain, log_prob, blobs) where the reference writes ``<runName>.h5``.
+        """
+        samplerKwargs, mcmcKwargs = mcmcUtils.validateMCMCKwargs(self, samplerKwargs,
+                                                                 mcmcKwargs, verbose)
+        skw = dict(samplerKwargs)
+        if batched:
+            skw["log_prob_fn"] = lambda thetas, *a, **k: self._gpllBatch(thetas)
+            skw["vectorize"] = True
+        self.sampler = emcee.EnsembleSampler(**skw, backend=None, args=args, kwargs=kwargs,
+                                             blobs_dtype=[("lnprior", float)])
+        for _ in self.sampler.sample(**mcmcKwargs):
+            pass
+        if verbose:
+            print("mcmc finished")
+        if cache:
+            bname = str(runName) + ".npz"
+            self.backends.append(bname)
+            blobs = self.sampler.get_blobs()
+            np.savez(bname, chain=self.sampler.get_chain(), log_prob=self.sampler.get_log_prob(),
+                     blobs=np.array([]) if blobs is None else blobs)
+        iburn, ithin = mcmcUtils.estimateBurnin(self.sampler, estBurnin=estBurnin,
+                                                thinChains=thinChains, verbose=verbose)
+        return self.sampler, iburn, ithin
+
+    # -------------------------------------------------------------------- run
+    def run(self, m=10, nmax=2, seed=None, timing=False, verbose=True,
+            mcmcKwargs=None, samplerKwargs=None, estBurnin=False,
+            thinChains=False, runName="apRun", cache=True, gpMethod="powell",
+            gpOptions=None, gpP0=None, optGPEveryN=1, nGPRestarts=1,
+            nMinObjRestarts=5, onlyLastMCMC=False, initGPOpt=True, kmax=3,
+            gpHyperPrior=gpUtils.defaultHyperPrior, eps=1.0, convergenceCheck=False,
+            minObjMethod="nelder-mead", minObjOptions=None, args=None,
+            nCandidates=None, **kwargs):
+        """BAPE / AGP outer loop (approx.py:229-524): for ``nmax`` iterations find
+        ``m`` new design points (re-fitting the GP every ``optGPEveryN``), run the
+        surrogate MCMC, record burn-in / thinning and optionally stop when the
+        marginal posterior means move by less than ``eps`` previous standard
+        deviations for ``kmax`` consecutive iterations.  (The reference only
+        honours that stop rule when ``verbose`` is set -- quirk Q4; here it does
+        not depend on verbosity.)  ``nCandidates`` switches the point search to
+        the fused device sweep."""
+        if cache:
+            np.savez(str(runName) + "APFModelCache.npz", theta=self.theta, y=self.y)
+            self.gpPar = list()
+        if seed is not None:
+            np.random.seed(seed)
+        if timing:
+            self.trainingTime = list()
+            self.mcmcTime = list()
+        if convergenceCheck:
+            self.marginalMeans = list()
+            self.marginalStds = list()
+            self.marginalZScores = list()
+        if initGPOpt:
+            self.optGP(seed=seed, method=gpMethod, options=gpOptions, p0=gpP0,
+                       nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
+        kk = 0
+        if convergenceCheck and onlyLastMCMC:
+            raise RuntimeError("If convergenceCheck is True, must run an MCMC each iteration.\n"
+                               "convergenceCheck = %d onlyLastMCMC = %d" % (convergenceCheck, onlyLastMCMC))
+        for nn in range(nmax):
+            if verbose:
+                print("Iteration: %d" % nn)
+            start = time.time()
+            _, _ = self.findNextPoint(computeLnLike=True, seed=seed, cache=cache,
+                                      gpMethod=gpMethod, gpOptions=gpOptions,
+                                      nGPRestarts=nGPRestarts, nMinObjRestarts=nMinObjRestarts,
+                                      optGPEveryN=optGPEveryN, numNewPoints=m,
+                                      gpHyperPrior=gpHyperPrior, minObjMethod=minObjMethod,
+                                      minObjOptions=minObjOptions, runName=runName,
+                                      theta0=None, args=args, verbose=verbose,
+                                      nCandidates=nCandidates, **kwargs)
+            if timing:
+                self.trainingTime.append(time.time() - start)
+            if cache:
+                np.savez(str(runName) + "APGP.npz",
+                         gpParamNames=self.gp.get_parameter_names(),
+                         gpParamValues=self.gpPar)
+            if onlyLastMCMC and nn != (nmax - 1):
+                self.sampler = None
+                continue
+            start = time.time()
+            self.sampler, iburn, ithin = self.runMCMC(samplerKwargs=samplerKwargs,
+                                                      mcmcKwargs=mcmcKwargs,
+                                                      runName=str(runName) + str(nn),
+                                                      cache=cache, estBurnin=estBurnin,
+                                                      thinChains=thinChains, verbose=verbose,
+                                                      args=args, **kwargs)
+            self.iburns.append(iburn)
+            self.ithins.append(ithin)
+            if timing:
+                self.mcmcTime.append(time.time() - start)
+                if cache:
+                    np.savez(str(runName) + "APTiming.npz", trainingTime=self.trainingTime,
+                             mcmcTime=self.mcmcTime)
+            if convergenceCheck:
+                samples = self.sampler.get_chain(discard=self.iburns[-1], flat=True,
+                                                 thin=self.ithins[-1])
+                meanNN = np.mean(samples, axis=0)
+                stdNN = np.std(samples, axis=0)
+                self.marginalMeans.append(meanNN)
+                self.marginalStds.append(stdNN)
+                if nn > 0:
+                    zScore = np.fabs((meanNN - meanPrev) / stdPrev)
+                    self.marginalZScores.append(zScore)
+                    kk = kk + 1 if np.all(zScore < eps) else 0
+                meanPrev, stdPrev = meanNN, stdNN
+                if cache:
+                    np.savez(str(runName) + "ConvergenceCache.npz", means=self.marginalMeans,
+                             stds=self.marginalStds, zscores=self.marginalZScores,
+                             eps=eps, kmax=kmax, finalIteration=kk)
+                if kk >= kmax:
+                    if verbose:
+                        print("Approximate marginal posterior distributions converged.")
+                        print("Delta zScore threshold, eps: %e" % eps)
+                        print("kk, kmax: %d, %d" % (kk, kmax))
+                        print("Final abs(zScore):", zScore)
+                    break
+
+    # ---------------------------------------------------------------- findMAP
+    def findMAP(self, theta0=None, method="nelder-mead", options=None, nRestarts=15):
+        """Maximum a posteriori estimate of the function the GP has learned:
+        minimise minus the GP mean from ``nRestarts`` starts around the best
+        training point (approx.py:862-926).  Returns ``(MAP, MAPVal)``."""
+        if theta0 is not None:
+            theta0 = np.array(theta0).reshape(1, self.theta.shape[-1])
+        else:
+            theta0 = self.theta[np.argmax(self.y)]
+        if str(method).lower() == "nelder-mead" and options is None:
+            options = {"adaptive": True}
+
+        def fn(x):
+            if not np.isfinite(self._lnprior(x)):
+                return np.inf
+            return -(self._gpll(x)[0])
+
+        MAP, MAPVal = ut.minimizeObjective(fn, self.y, self.gp, self.priorSample,
+                                           self._lnprior, nRestarts=nRestarts, args=None,
+                                           method=method, options=options,
+                                           bounds=self.bounds, theta0=theta0)
+        return MAP, -MAPVal
+
+    # --------------------------------------------------------------- bayesOpt
+    def bayesOpt(self, nmax, theta0=None, tol=1.0e-3, kmax=3, seed=None,
+                 verbose=True, runName="apRun", cache=True, gpMethod="powell",
+                 gpOptions=None, gpP0=None, optGPEveryN=1, nGPRestarts=1,
+                 nMinObjRestarts=5, initGPOpt=True, minObjMethod="nelder-mead",
+                 gpHyperPrior=gpUtils.defaultHyperPrior, minObjOptions=None,
+                 findMAP=True, args=None, nCandidates=None, **kwargs):
+        """Bayesian optimisation loop (approx.py:929-1151): one new design point
+        per iteration by the object's utility (use algorithm="jones"), optional
+        MAP of the GP mean each iteration, stop after ``kmax`` consecutive
+        iterations whose best value changes by less than ``tol``.  Returns the
+        reference's solution dictionary."""
+        thetas, vals = list(), list()
+        thetasMAP, valsMAP = list(), list()
+        if cache:
+            np.savez(str(runName) + "APFModelCache.npz", theta=self.theta, y=self.y)
+        if seed is not None:
+            np.random.seed(seed)
+        if initGPOpt:
+            self.optGP(seed=seed, method=gpMethod, options=gpOptions, p0=gpP0,
+                       nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
+        kk = 0
+        nn = -1
+        for nn in range(nmax):
+            if verbose:
+                print("Iteration: %d" % nn)
+            optN = 1 if nn % optGPEveryN == 0 else 99999999
+            thetaT, yT = self.findNextPoint(computeLnLike=True, seed=seed, cache=cache,
+                                            gpMethod=gpMethod, gpOptions=gpOptions,
+                                            nGPRestarts=nGPRestarts,
+                                            nMinObjRestarts=nMinObjRestarts,
+                                            optGPEveryN=optN, numNewPoints=1,
+                                            gpHyperPrior=gpHyperPrior,
+                                            minObjMethod=minObjMethod,
+                                            minObjOptions=minObjOptions, runName=runName,
+                                            args=args, verbose=verbose,
+                                            nCandidates=nCandidates, **kwargs)
+            if verbose:
+                print("Forward model evaluation at: ", thetaT, ", function value: ", yT)
+            if cache:
+                np.savez(str(runName) + "APGP.npz",
+                         gpParamNames=self.gp.get_parameter_names(),
+                         gpParamValues=self.gp.get_parameter_vector())
+            thetas.append(self.theta[np.argmax(self.y)])
+            vals.append(self.y[np.argmax(self.y)])
+            if findMAP:
+                thetaN, valN = self.findMAP(theta0=theta0, method=minObjMethod,
+                                            options=minObjOptions, nRestarts=nMinObjRestarts)
+                if verbose:
+                    print("Current MAP solution: ", thetaN, valN)
+                thetasMAP.append(thetaN)
+                valsMAP.append(valN)
+            if nn > 0:
+                kk = kk + 1 if np.fabs(vals[-1] - vals[-2]) < tol else 0
+                if kk >= kmax:
+                    break
+        soln = {"thetaBest": thetas[-1], "valBest": vals[-1],
+                "thetas": np.asarray(thetas).squeeze(),
+                "vals": np.asarray(vals).squeeze(), "nev": nn + 1}
+        if findMAP:
+            soln["thetasMAP"] = np.asarray(thetasMAP).squeeze()
+            soln["valsMAP"] = np.asarray(valsMAP).squeeze()
+            soln["thetaMAPBest"] = soln["thetasMAP"][np.argmax(soln["valsMAP"])]
+            soln["valMAPBest"] = soln["valsMAP"][np.argmax(soln["valsMAP"])]
+        return soln

@@ -1,0 +1,107 @@
+"""GPU (``-m gpu``): the callers on either side of the hot path, end to end on
+the HIP-backed GP, tested the way the reference tests them (statistical /
+integration tests, SURVEY.md section 4 style 2):
+  test_APRun.py:58-73        posterior means within one 'true sigma' of (0.0, 1.31)
+  test_1DBayesOpt.py:55-73   bayesOpt reaches the optimum within 5 %
+  test_MAP.py:51-65          findMAP within 1e-3 of the sphere optimum
+plus the batched extras: sweep-based findNextPoint vs restarted Nelder-Mead and
+_gpllBatch vs scalar _gpll."""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+pytestmark = pytest.mark.gpu
+
+
+def _rosen_ap(m0, fit_amp=False, algorithm="bape"):
+    from approxposterior_amd import approx, gpUtils, likelihood as lh
+    theta = np.array(lh.rosenbrockSample(m0))
+    y = np.array([lh.rosenbrockLnlike(t) + lh.rosenbrockLnprior(t) for t in theta])
+    gp = gpUtils.defaultGP(theta, y, fitAmp=fit_amp)
+    return approx.ApproxPosterior(theta=theta, y=y, gp=gp, lnprior=lh.rosenbrockLnprior,
+                                  lnlike=lh.rosenbrockLnlike, priorSample=lh.rosenbrockSample,
+                                  bounds=[(-5, 5), (-5, 5)], algorithm=algorithm)
+
+
+def test_run_rosenbrock_posterior(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(57)
+    ap = _rosen_ap(50)
+    with np.errstate(all="ignore"):
+        ap.run(m=20, nmax=3, estBurnin=True, nGPRestarts=3, mcmcKwargs={"iterations": 5000},
+               cache=False, samplerKwargs={"nwalkers": 20}, verbose=False, thinChains=False,
+               onlyLastMCMC=False, kmax=2, eps=1, convergenceCheck=True)
+    samples = ap.sampler.get_chain(discard=ap.iburns[-1], flat=True, thin=ap.ithins[-1])
+    means = np.mean(samples, axis=0)
+    z = np.fabs((means - np.array([0.0, 1.31])) / np.array([1.5, 1.75]))
+    assert np.all(z < 1), (means, z)
+    assert len(ap.y) >= 50 + 40
+
+
+def test_bayesopt_1d(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    from approxposterior_amd import approx, gpUtils, likelihood as lh
+    np.random.seed(57)
+    fn = lambda x: -(lh.testBOFn(x) + lh.testBOFnLnPrior(x))   # noqa: E731
+    true = minimize(lambda x: float(np.ravel(fn(x))[0]), np.ravel(lh.testBOFnSample(1)), method="nelder-mead")
+    theta = lh.testBOFnSample(3)
+    y = np.array([lh.testBOFn(t) + lh.testBOFnLnPrior(t) for t in theta])
+    gp = gpUtils.defaultGP(theta, y, fitAmp=True)
+    ap = approx.ApproxPosterior(theta=theta, y=y, gp=gp, lnprior=lh.testBOFnLnPrior,
+                                lnlike=lh.testBOFn, priorSample=lh.testBOFnSample,
+                                bounds=[[-1, 2]], algorithm="jones")
+    with np.errstate(all="ignore"):
+        soln = ap.bayesOpt(nmax=10, tol=1.0e-3, seed=57, verbose=False, cache=False,
+                           gpMethod="powell", optGPEveryN=1, nGPRestarts=3, nMinObjRestarts=5,
+                           initGPOpt=True, minObjMethod="nelder-mead", findMAP=True)
+    assert np.allclose(soln["thetaBest"], true["x"], rtol=5.0e-2)
+    assert np.allclose(soln["valBest"], -true["fun"], rtol=5.0e-2)
+    assert np.allclose(soln["thetaMAPBest"], true["x"], rtol=5.0e-2)
+    assert np.allclose(soln["valMAPBest"], -true["fun"], rtol=5.0e-2)
+
+
+def test_find_map_sphere(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    from approxposterior_amd import approx, gpUtils, likelihood as lh
+    np.random.seed(57)
+    theta = np.array(lh.sphereSample(20))
+    y = np.array([lh.sphereLnlike(t) + lh.sphereLnprior(t) for t in theta])
+    gp = gpUtils.defaultGP(theta, y, fitAmp=True)
+    ap = approx.ApproxPosterior(theta=theta, y=y, gp=gp, lnprior=lh.sphereLnprior,
+                                lnlike=lh.sphereLnlike, priorSample=lh.sphereSample,
+                                bounds=[(-5, 5), (-5, 5)], algorithm="jones")
+    with np.errstate(all="ignore"):
+        ap.optGP(seed=57, method="powell", nGPRestarts=3)
+        ap.findNextPoint(numNewPoints=5, nGPRestarts=3, cache=False, verbose=False)
+        testMAP, testVal = ap.findMAP(nRestarts=15)
+    assert np.allclose([0.0, 0.0], testMAP, atol=1.0e-3)
+    assert np.allclose(0.0, testVal, atol=1.0e-3)
+
+
+def test_sweep_point_search_vs_nelder_mead():
+    """The fused sweep over 2e5 prior draws finds a utility at least as good as
+    the reference-style 5-restart Nelder-Mead search (up to the grid resolution),
+    and gpllBatch equals the scalar guard-by-guard path."""
+    from approxposterior_amd import utility as ut
+    np.random.seed(57)
+    ap = _rosen_ap(60)
+    with np.errstate(all="ignore"):
+        ap.optGP(seed=57, nGPRestarts=2)
+        thetaNM, uNM = ut.minimizeObjective(ap.utility, ap.y, ap.gp, sampleFn=ap.priorSample,
+                                            priorFn=ap._lnprior, nRestarts=5,
+                                            args=(ap.y, ap.gp, ap._lnprior))
+        thetaS = ap.findNextPoint(computeLnLike=False, nCandidates=200000, verbose=False)
+        uS = ut.BAPEUtility(thetaS, ap.y, ap.gp, ap._lnprior)
+        thetaP = ap.findNextPoint(computeLnLike=False, nCandidates=200000, polish=True, verbose=False)
+        uP = ut.BAPEUtility(thetaP, ap.y, ap.gp, ap._lnprior)
+    uNM, uS, uP = (float(np.ravel(v)[0]) for v in (uNM, uS, uP))
+    assert uS <= uNM + 0.05 * abs(uNM) + 1e-6, (uS, uNM)
+    assert uP <= uS + 1e-9 and uP <= uNM + 1e-6 * abs(uNM) + 1e-9, (uP, uS, uNM)
+    thetas = np.array([[0.5, 0.5], [-2.3573, 4.673], [6.0, 0.0], [np.inf, np.nan], [np.nan, 1.0]])
+    with np.errstate(all="ignore"):
+        lp, blob = ap._gpllBatch(thetas)
+        for i, t in enumerate(thetas):
+            a, b = ap._gpll(t)
+            a = float(np.ravel(a)[0]); b = float(np.ravel(b)[0])
+            assert (np.isnan(b) and np.isnan(blob[i])) or b == blob[i]
+            assert a == lp[i] or np.isclose(a, lp[i], rtol=1e-12)
