@@ -38,7 +38,7 @@ static inline int64_t apgp_round_up(int64_t n, int64_t b) { return (n + b - 1) /
 // Scaled-coordinate / amplitude constants shared by every kernel that
 // evaluates the squared-exponential kernel, so that K (Gram), K* (sweep) and
 // dK (gradient) use bit-identical expressions:
-//   k(x,x') = exp(-(sum_d (xs_d - xs'_d)^2 - log_amp)),  xs = x * sqrt(inv_metric/2)
+//   k(x,x') = amp * exp(-sum_d (xs_d - xs'_d)^2),  xs = x * sqrt(inv_metric/2)
 struct KernConst {
     double sc[APGP_MAX_DIM];
     double log_amp;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
         const long long gi = i0 + r;
         if (gi < a.n && gj < a.n) {
             double df2[DPAD];
-            double s = -a.kc.log_amp, s3 = 0.0;
+            double s = 0.0, s3 = 0.0;
 #pragma unroll
             for (int d = 0; d < DPAD; d += 2) {
                 double df0 = xi[r][d] - xc[d];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
                 s = fma(df0, df0, s);
                 s3 = fma(df1, df1, s3);
             }
-            const double k = apgp_exp(-(s + s3), etab);
+            const double k = a.kc.amp * apgp_exp(-(s + s3), etab);
             const double A = ai[r] * aj[c] - a.Kinv[gi * a.n + gj];
             const double Ak = A * k;
             gsum[0] += Ak;

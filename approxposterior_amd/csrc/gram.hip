@@ -1,4 +1,4 @@
-// K1 "gram": N x N squared-exponential Gram matrix, LDS-tiled, coalesced row
+// K1 "gram": N x N squared-exponential Gram matrix  K_ij = amp * exp(-|xs_i - xs_j|^2), LDS-tiled, coalesced row
 // writes.  HBM-write-bound (8 N^2 bytes out, 8 N D bytes in).
 // Reference semantics: george ExpSquaredKernel.get_value + the diagonal update
 // of GP.compute (called from gpUtils.py:178,244,254; approx.py:717).
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
         const int r = g + 4 * q;
         const long long gi = i0 + r;
         // same association as the sweep / mean kernels: two interleaved sums
-        double s = -a.kc.log_amp, s3 = 0.0;
+        double s = 0.0, s3 = 0.0;
 #pragma unroll
         for (int d = 0; d < DPAD; d += 2) {
             double df0 = xi[r][d] - xc[d];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
             s = fma(df0, df0, s);
             s3 = fma(df1, df1, s3);
         }
-        double k = apgp_exp(-(s + s3), etab);
+        double k = a.kc.amp * apgp_exp(-(s + s3), etab);
         if (gi == gj) k += a.kc.diag_add;
         if (gi < a.n && gj < a.n) a.K[gi * a.ldk + gj] = k;
     }

@@ -41,7 +41,7 @@ struct SweepArgs {
     long long* part_i;
     long long m, idx_offset;
     int ndim, nrb, kind, has_box, n;
-    double mean, amp, log_amp, zeta, ybest;
+    double mean, amp, zeta, ybest;
     double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM];
     unsigned long long* dbg;   // phase cycle counters (APGP_SWEEP_TIMING=1 builds only)
 };
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 // interleave; two partial sums per chain halve its length
                 double s2[NKK], s3[NKK], al[NKK];
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) { s2[kk] = -a.log_amp; s3[kk] = 0.0; }
+                for (int kk = 0; kk < NKK; ++kk) { s2[kk] = 0.0; s3[kk] = 0.0; }
 #pragma unroll
                 for (int d = 0; d < DPAD; d += 2) {
 #pragma unroll
@@ -244,8 +244,14 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                     al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
                 }
                 apgp_exp4(ex, bfv, Etab);
+                // the amplitude multiplies the exponential (folding log(amp) into the
+                // exponent would perturb every entry by ~|log amp| ulps, which matters
+                // once cond(K) approaches 1/eps)
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) mupart = fma(bfv[kk], al[kk], mupart);
+                for (int kk = 0; kk < NKK; ++kk) {
+                    bfv[kk] *= a.amp;
+                    mupart = fma(bfv[kk], al[kk], mupart);
+                }
             }
             // keep the A-fragment prefetch below the generation phase (register pressure)
             __builtin_amdgcn_sched_barrier(0);
@@ -461,7 +467,7 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     a.m = m; a.idx_offset = idx_offset;
     a.ndim = kc.ndim; a.nrb = (int)(apgp_npad(n) / APGP_ROW_BLOCK); a.kind = kind; a.n = (int)n;
     a.has_box = lo != NULL;
-    a.mean = mean; a.amp = kc.amp; a.log_amp = kc.log_amp; a.zeta = zeta; a.ybest = ybest;
+    a.mean = mean; a.amp = kc.amp; a.zeta = zeta; a.ybest = ybest;
     for (int d = 0; d < APGP_MAX_DIM; ++d) {
         a.sc[d] = kc.sc[d];
         a.lo[d] = (lo && d < kc.ndim) ? lo[d] : 0.0;
@@ -481,6 +487,159 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
 }
 
 // ---------------------------------------------------------------------------
+// Solve-based variant of the sweep for ill-conditioned factors.
+// The explicit-inverse contraction above is as accurate as a triangular solve
+// while cond(K) <~ 1e10; beyond that (the reference's own fitAmp=True optimum
+// reaches cond ~ 8e15) only the solve-based form keeps the
+// error at the level of george's cho_solve.  Here one wavefront owns one
+// candidate: k* lives in LDS, v = L^-1 k* by forward substitution against the
+// row-major factor (row i read coalesced, one wave reduction per row), then
+// sigma^2 = amp - |v|^2.  O(N^2/64) cycles per candidate and the factor is
+// re-read from L2 for every candidate, so this is a correctness path for the
+// small, badly conditioned training sets that need it, not a throughput path.
+// ---------------------------------------------------------------------------
+struct SolveArgs {
+    const double* T;
+    const double* L;
+    const double* xs;
+    const unsigned char* mask;
+    double* mu;
+    double* var;
+    double* u;
+    double* part_u;
+    long long* part_i;
+    long long m, idx_offset, ldl;
+    int ndim, n, kind, has_box;
+    double mean, amp, zeta, ybest;
+    double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM];
+};
+
+template <int DPAD>
+__global__ __launch_bounds__(256) void sweep_solve_kernel(SolveArgs a) {
+    constexpr int XS = DPAD + 2;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double etab[APGP_EXP_TAB_N];
+    __shared__ double red_u[4];
+    __shared__ long long red_i[4];
+    apgp_exp_tab_load(etab);
+    __syncthreads();
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    double* v = smem + (size_t)w * a.n;
+    const long long crow = (long long)blockIdx.x * 4 + w;
+    const bool inb = crow < a.m;
+    bool adm = inb, has_nan = false;
+    double tt[DPAD];
+#pragma unroll
+    for (int d = 0; d < DPAD; ++d) {
+        double x = 0.0;
+        if (inb && d < a.ndim) {
+            x = a.T[crow * a.ndim + d];
+            if (a.has_box && !(x >= a.lo[d] && x <= a.hi[d])) adm = false;
+            if (x != x) has_nan = true;
+        }
+        tt[d] = x * a.sc[d];
+    }
+    if (inb && a.mask && a.mask[crow] == 0) adm = false;
+    double bu = INFINITY;
+    long long bi = -1;
+    if (inb) {
+        double mup = 0.0;
+        for (int k = lane; k < a.n; k += 64) {
+            const double* xr = a.xs + (long long)k * XS;
+            double s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DPAD; d += 2) {
+                const double df0 = tt[d] - xr[d], df1 = tt[d + 1] - xr[d + 1];
+                s2 = fma(df0, df0, s2);
+                s3 = fma(df1, df1, s3);
+            }
+            const double kv = a.amp * apgp_exp(-(s2 + s3), etab);
+            v[k] = kv;
+            mup = fma(kv, xr[DPAD], mup);
+        }
+        for (int o = 32; o > 0; o >>= 1) mup += __shfl_xor(mup, o);
+        double q = 0.0;
+        for (int i = 0; i < a.n; ++i) {
+            const double* lrow = a.L + (long long)i * a.ldl;
+            double p = 0.0;
+            for (int j = lane; j < i; j += 64) p = fma(lrow[j], v[j], p);
+            for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+            const double vi = (v[i] - p) / lrow[i];
+            if (lane == 0) v[i] = vi;       // same wavefront: LDS ops are ordered
+            q = fma(vi, vi, q);
+        }
+        double mu = mup + a.mean;
+        double var = a.amp - q;
+        if (has_nan) { mu = NAN; var = NAN; }
+        if (lane == 0) {
+            if (a.mu) a.mu[crow] = mu;
+            if (a.var) a.var[crow] = var;
+            if (a.kind != APGP_UTIL_NONE) {
+                const double uu = adm ? util_value(a.kind, mu, var, a.zeta, a.ybest) : INFINITY;
+                if (a.u) a.u[crow] = uu;
+                best_merge(bu, bi, uu, a.idx_offset + crow);
+            }
+        }
+    }
+    if (a.kind == APGP_UTIL_NONE) return;
+    if (lane == 0) { red_u[w] = bu; red_i[w] = bi; }
+    __syncthreads();
+    if (t == 0) {
+        for (int i = 1; i < 4; ++i) best_merge(bu, bi, red_u[i], red_i[i]);
+        a.part_u[blockIdx.x] = bu;
+        a.part_i[blockIdx.x] = bi;
+    }
+}
+
+extern "C" int apgp_acquire_solve(const double* T, int64_t m, int64_t idx_offset, const double* L,
+                                  int64_t ldl, const double* xs, int64_t n, const apgp_kernel_t* kern,
+                                  double mean, int32_t kind, const double* lo, const double* hi,
+                                  const uint8_t* mask, double zeta, double ybest, double* mu, double* var,
+                                  double* u, void* part, apgp_best_t* best, void* stream) {
+    APGP_CHECK_ARG(T && L && xs && kern, "null pointer");
+    APGP_CHECK_ARG(m >= 1 && n >= 1 && ldl >= n, "m >= 1, n >= 1 and ldl >= n required");
+    APGP_CHECK_ARG(n <= 4096, "solve-based sweep keeps k* in LDS: n <= 4096");
+    APGP_CHECK_ARG(kind >= APGP_UTIL_AGP && kind <= APGP_UTIL_NONE, "unknown utility kind");
+    APGP_CHECK_ARG(kind == APGP_UTIL_NONE || (part && best), "part/best required for an acquisition");
+    APGP_CHECK_ARG((lo == NULL) == (hi == NULL), "lo and hi must be given together");
+    KernConst kc;
+    APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
+    SolveArgs a;
+    a.T = T; a.L = L; a.xs = xs; a.mask = mask; a.mu = mu; a.var = var; a.u = u;
+    const long long nblk = (m + 3) / 4;
+    a.part_u = (double*)part;
+    a.part_i = part ? (long long*)((double*)part + nblk) : NULL;
+    a.m = m; a.idx_offset = idx_offset; a.ldl = ldl;
+    a.ndim = kc.ndim; a.n = (int)n; a.kind = kind; a.has_box = lo != NULL;
+    a.mean = mean; a.amp = kc.amp; a.zeta = zeta; a.ybest = ybest;
+    for (int d = 0; d < APGP_MAX_DIM; ++d) {
+        a.sc[d] = kc.sc[d];
+        a.lo[d] = (lo && d < kc.ndim) ? lo[d] : 0.0;
+        a.hi[d] = (hi && d < kc.ndim) ? hi[d] : 0.0;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)4 * n * sizeof(double);
+    dim3 grid((unsigned)nblk), block(256);
+#define APGP_LAUNCH_SOLVE(DP)                                                                           \
+    do {                                                                                                \
+        (void)hipFuncSetAttribute((const void*)sweep_solve_kernel<DP>,                                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);              \
+        hipLaunchKernelGGL(sweep_solve_kernel<DP>, grid, block, lds, s, a);                             \
+    } while (0)
+    switch (kc.dpad) {
+        case 2: APGP_LAUNCH_SOLVE(2); break;
+        case 4: APGP_LAUNCH_SOLVE(4); break;
+        case 8: APGP_LAUNCH_SOLVE(8); break;
+        default: APGP_LAUNCH_SOLVE(16); break;
+    }
+#undef APGP_LAUNCH_SOLVE
+    if (kind != APGP_UTIL_NONE)
+        hipLaunchKernelGGL(argmin_final_kernel, dim3(1), dim3(1024), 0, s, a.part_u, a.part_i, nblk, best);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // mean-only prediction: the batched ApproxPosterior._gpll (approx.py:178-180).
 // One wavefront per candidate; lanes stride over the training points.
 // ---------------------------------------------------------------------------
@@ -490,7 +649,7 @@ struct MeanArgs {
     double* mu;
     long long m, npad;
     int ndim;
-    double mean, log_amp;
+    double mean, amp;
     double sc[APGP_MAX_DIM];
 };
 
@@ -509,7 +668,7 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(MeanArgs a) {
     double acc = 0.0;
     for (long long k = lane; k < a.npad; k += 64) {
         const double* xr = a.xs + k * XS;
-        double s = -a.log_amp, s3 = 0.0;
+        double s = 0.0, s3 = 0.0;
 #pragma unroll
         for (int d = 0; d < DPAD; d += 2) {
             double df0 = tt[d] - xr[d];
@@ -517,7 +676,7 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(MeanArgs a) {
             s = fma(df0, df0, s);
             s3 = fma(df1, df1, s3);
         }
-        acc = fma(apgp_exp(-(s + s3), etab), xr[DPAD], acc);
+        acc = fma(a.amp * apgp_exp(-(s + s3), etab), xr[DPAD], acc);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     bool bad = false;
@@ -533,7 +692,7 @@ extern "C" int apgp_predict_mean(const double* T, int64_t m, const double* xs, i
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
     MeanArgs a;
     a.T = T; a.xs = xs; a.mu = mu; a.m = m; a.npad = apgp_npad(n); a.ndim = kc.ndim;
-    a.mean = mean; a.log_amp = kc.log_amp;
+    a.mean = mean; a.amp = kc.amp;
     for (int d = 0; d < APGP_MAX_DIM; ++d) a.sc[d] = kc.sc[d];
     dim3 grid((unsigned)((m + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;

@@ -43,8 +43,9 @@ UTILITY_KINDS = {"agp": _lib.UTIL_AGP, "bape": _lib.UTIL_BAPE, "jones": _lib.UTI
 
 # Above this condition estimate ((max L_ii / min L_ii)^2) the explicit L^-1
 # contraction is no longer trusted for the predictive variance (SURVEY.md
-# section 7, "Conditioning vs. formulation").
-COND_WARN = 1.0e12
+# section 7, "Conditioning vs. formulation") and the solve-based sweep
+# (apgp_acquire_solve) is used instead.  APGP_VARIANCE=solve|inverse overrides.
+COND_SOLVE = 1.0e10
 
 # APGP_CHOLESKY=rocsolver routes the factorisation through torch.linalg.cholesky_ex
 # (rocSOLVER dpotrf) instead of the in-tree blocked Cholesky -- for A/B checks only.
@@ -511,11 +512,15 @@ class GP(object):
                                                  ctypes.byref(ks), float(self.mean.value),
                                                  mu.data_ptr(), st), "apgp_predict_mean")
                 return (mu.cpu().numpy(),)
-            self._ensure_linv()
+            mode = _os.environ.get("APGP_VARIANCE", "").lower()
+            use_solve = (mode == "solve") or (mode != "inverse" and self.cond_estimate is not None
+                                              and self.cond_estimate > COND_SOLVE and n <= 4096)
+            if not use_solve:
+                self._ensure_linv()
             mu = torch.empty(m, dtype=torch.float64, device=dev) if "mu" in want else None
             var = torch.empty(m, dtype=torch.float64, device=dev) if "var" in want else None
             u = torch.empty(m, dtype=torch.float64, device=dev) if "u" in want else None
-            nblk = (m + 63) // 64
+            nblk = (m + 3) // 4 if use_solve else (m + 63) // 64
             part = torch.empty(2 * nblk, dtype=torch.float64, device=dev)
             best = torch.empty(2, dtype=torch.float64, device=dev)
             lo = hi = None
@@ -537,14 +542,18 @@ class GP(object):
             if ev is not None:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            _lib.check(lib.apgp_acquire(
-                T.data_ptr(), m, int(idx_offset), self._packed.data_ptr(), self._xs.data_ptr(), n,
-                ctypes.byref(ks), float(self.mean.value), kid, lo, hi,
-                mask_d.data_ptr() if mask_d is not None else None, float(zeta), ybest,
-                mu.data_ptr() if mu is not None else None,
-                var.data_ptr() if var is not None else None,
-                u.data_ptr() if u is not None else None,
-                part.data_ptr(), best.data_ptr(), st), "apgp_acquire")
+            common = (ctypes.byref(ks), float(self.mean.value), kid, lo, hi,
+                      mask_d.data_ptr() if mask_d is not None else None, float(zeta), ybest,
+                      mu.data_ptr() if mu is not None else None,
+                      var.data_ptr() if var is not None else None,
+                      u.data_ptr() if u is not None else None,
+                      part.data_ptr(), best.data_ptr(), st)
+            if use_solve:
+                _lib.check(lib.apgp_acquire_solve(T.data_ptr(), m, int(idx_offset), self._L.data_ptr(), n,
+                                                  self._xs.data_ptr(), n, *common), "apgp_acquire_solve")
+            else:
+                _lib.check(lib.apgp_acquire(T.data_ptr(), m, int(idx_offset), self._packed.data_ptr(),
+                                            self._xs.data_ptr(), n, *common), "apgp_acquire")
             if ev is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()

@@ -149,6 +149,20 @@ int apgp_acquire(const double* T, int64_t m, int64_t idx_offset,
                  double* mu, double* var, double* u,
                  void* part, apgp_best_t* best, void* stream);
 
+/* ---- solve-based variant of apgp_acquire for ill-conditioned factors --------
+ * Same semantics and outputs, but sigma^2 = amp - |L^-1 k*|^2 is obtained by a
+ * forward substitution against the factor L itself (what george's cho_solve
+ * does) instead of the packed explicit inverse: use when the condition estimate
+ * from apgp_logdet, (out[2]/out[1])^2, exceeds ~1e10.  n <= 4096.
+ * part: 2 * ceil(m/4) doubles.                                               */
+int apgp_acquire_solve(const double* T, int64_t m, int64_t idx_offset,
+                       const double* L, int64_t ldl, const double* xs, int64_t n,
+                       const apgp_kernel_t* kern /*host*/, double mean, int32_t kind,
+                       const double* lo /*host*/, const double* hi /*host*/,
+                       const uint8_t* mask, double zeta, double ybest,
+                       double* mu, double* var, double* u,
+                       void* part, apgp_best_t* best, void* stream);
+
 /* ---- mean-only prediction (the batched ApproxPosterior._gpll path) --------
  * mu_i = k(t_i,X).alpha + mean for m candidates (approx.py:178-180).         */
 int apgp_predict_mean(const double* T, int64_t m, const double* xs, int64_t n,

@@ -237,6 +237,48 @@ def main():
     cands = np.linspace(-1.2, 2.2, 150).reshape(-1, 1)
     sweep_case("bo1d_n12_amp", th1, y1, gp, cands, [-1], [2], meta)
 
+    # S8: ILL-CONDITIONED -- 2-D Rosenbrock, N=50, fitAmp=True at the optimised hypers
+    # (cond(K) ~ 1e16, SURVEY.md section 7).  Besides the oracle outputs the fixture
+    # carries a 60-digit mpmath truth for mu / var so that the solve-based HIP path is
+    # judged against exact arithmetic, not against the reference's own noise.
+    np.random.seed(57)
+    theta, y = rosen_set(50)
+    gp = gpUtils.defaultGP(theta, y, fitAmp=True)
+    gp.set_parameter_vector(replay["optgp_amp"]["p"])
+    gp.recompute()
+    cands = rng.uniform(-5.0, 5.0, size=(24, 2))
+    sweep_case("rosen2d_n50_amp_opt_illcond", theta, y, gp, cands, [-5, -5], [5, 5], meta)
+    import mpmath as mp
+    mp.mp.dps = 60
+    p = gp.get_parameter_vector()
+    amp = mp.mpf(2) * mp.exp(mp.mpf(float(p[1])))
+    w = [mp.exp(-mp.mpf(float(v))) for v in p[2:]]
+    wn = mp.exp(mp.mpf(-12))
+    X = [[mp.mpf(float(v)) for v in row] for row in theta]
+    def kfun(a, b):
+        return amp * mp.exp(-mp.mpf(1) / 2 * sum(w[d] * (a[d] - b[d]) ** 2 for d in range(2)))
+    n = len(X)
+    K = mp.matrix(n, n)
+    for i in range(n):
+        for j in range(n):
+            K[i, j] = kfun(X[i], X[j]) + (wn if i == j else 0)
+    r = mp.matrix([mp.mpf(float(v)) - mp.mpf(float(p[0])) for v in y])
+    alpha = mp.lu_solve(K, r)
+    mu_t, var_t = [], []
+    for c in cands:
+        cc = [mp.mpf(float(v)) for v in c]
+        ks = mp.matrix([kfun(cc, X[i]) for i in range(n)])
+        sol = mp.lu_solve(K, ks)
+        mu_t.append(float(sum(ks[i] * alpha[i] for i in range(n)) + mp.mpf(float(p[0]))))
+        var_t.append(float(amp - sum(ks[i] * sol[i] for i in range(n))))
+    d = dict(np.load(os.path.join(OUT, "rosen2d_n50_amp_opt_illcond.npz")))
+    d["mu_truth"] = np.array(mu_t)
+    d["var_truth"] = np.array(var_t)
+    np.savez_compressed(os.path.join(OUT, "rosen2d_n50_amp_opt_illcond.npz"), **d)
+    print("ill-conditioned: oracle var rel err vs truth (median, max):",
+          np.median(np.abs(d["var"] - d["var_truth"]) / np.abs(d["var_truth"])),
+          np.max(np.abs(d["var"] - d["var_truth"]) / np.abs(d["var_truth"])))
+
     with open(os.path.join(OUT, "pins.json"), "w") as fh:
         json.dump(pins, fh, indent=1)
     with open(os.path.join(OUT, "meta.json"), "w") as fh:
