@@ -56,7 +56,7 @@ def sharded_acquire(local_acquire, idx_offset, group=None, device=None):
     import torch.distributed as dist
 
     bi, bu = local_acquire(idx_offset)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return combine_best([(bu, bi)])
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) \

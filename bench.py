@@ -108,7 +108,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # torch.distributed.run
+    if launched:
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from approxposterior_amd import gp as agp
@@ -140,7 +141,7 @@ def main():
             lambda off: gp.acquire(y, T, args.utility, bounds=bounds, idx_offset=off), offset)
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,7 +156,7 @@ def main():
         best = step()
     barrier()
     elapsed = time.time() - t0
-    if world > 1:
+    if launched:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -189,7 +190,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, y, args.metric, D, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 
