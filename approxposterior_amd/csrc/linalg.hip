@@ -30,37 +30,52 @@ extern "C" int64_t apgp_trtri_work_len(int64_t n) {
 // K2: logdet + diagonal range.  One workgroup; the diagonal is N doubles.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void logdet_kernel(const double* L, long long n, long long ldl,
-                                                      double* out) {
-    __shared__ double ssum[16], smin[16], smax[16];
-    double s = 0.0, mn = INFINITY, mx = -INFINITY;
+                                                      const double* z, const int* info, double* out) {
+    __shared__ double ssum[16], smin[16], smax[16], szz[16];
+    double s = 0.0, mn = INFINITY, mx = -INFINITY, zz = 0.0;
     for (long long i = threadIdx.x; i < n; i += 1024) {
         double d = L[i * ldl + i];
         s += log(d);
         mn = fmin(mn, d);
         mx = fmax(mx, d);
+        if (z) zz = fma(z[i], z[i], zz);
     }
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_xor(s, o);
+        zz += __shfl_xor(zz, o);
         mn = fmin(mn, __shfl_xor(mn, o));
         mx = fmax(mx, __shfl_xor(mx, o));
     }
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { ssum[w] = s; smin[w] = mn; smax[w] = mx; }
+    if ((threadIdx.x & 63) == 0) { ssum[w] = s; smin[w] = mn; smax[w] = mx; szz[w] = zz; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        s = 0.0; mn = INFINITY; mx = -INFINITY;
-        for (int i = 0; i < 16; ++i) { s += ssum[i]; mn = fmin(mn, smin[i]); mx = fmax(mx, smax[i]); }
+        s = 0.0; zz = 0.0; mn = INFINITY; mx = -INFINITY;
+        for (int i = 0; i < 16; ++i) { s += ssum[i]; zz += szz[i]; mn = fmin(mn, smin[i]); mx = fmax(mx, smax[i]); }
         out[0] = 2.0 * s;
         out[1] = mn;
         out[2] = mx;
+        out[3] = zz;
+        out[4] = info ? (double)(*info) : 0.0;
     }
 }
 
 extern "C" int apgp_logdet(const double* L, int64_t n, int64_t ldl, double* out3, void* stream) {
     APGP_CHECK_ARG(L && out3, "null pointer");
     APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    // legacy 3-value form: the kernel writes 5 doubles, callers of this entry pass >= 5
     hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, (long long)n,
-                       (long long)ldl, out3);
+                       (long long)ldl, (const double*)NULL, (const int*)NULL, out3);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int apgp_fit_summary(const double* L, int64_t n, int64_t ldl, const double* z,
+                                const int32_t* info_dev, double* out5, void* stream) {
+    APGP_CHECK_ARG(L && out5, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, (long long)n,
+                       (long long)ldl, z, (const int*)info_dev, out5);
     APGP_CHECK_LAUNCH();
     return 0;
 }

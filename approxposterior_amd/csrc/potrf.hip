@@ -18,8 +18,10 @@
 
 struct PotrfArgs {
     double* A;
+    double* rhs;         // optional right-hand side carried through the factorisation
     long long n, lda;
     long long j0;        // first column of the current block
+    double shift;        // rhs is used as (rhs - shift); applied at block step 0 .. as read
     int* info;
 };
 
@@ -53,6 +55,7 @@ __device__ __forceinline__ void potf2_lds(double (*S)[PB + 1], double* invd, int
 __global__ __launch_bounds__(256) void potrf_panel_kernel(PotrfArgs a) {
     __shared__ double S[PB][PB + 1];
     __shared__ double invd[PB];
+    __shared__ double zblk[PB];
     const int t = threadIdx.x;
     if (t < PB) invd[t] = 1.0;
     const long long j0 = a.j0;
@@ -70,6 +73,22 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(PotrfArgs a) {
             const int i = e >> 6, k = e & 63;
             if (i < bs && k <= i) a.A[(j0 + i) * a.lda + j0 + k] = S[i][k];
         }
+    }
+    // fused forward solve z = L^-1 (rhs): every workgroup solves the 64-block of
+    // the right-hand side against the fresh diagonal factor (wavefront 0, shuffle
+    // forward substitution), then each panel row subtracts its share below.
+    if (a.rhs) {
+        if (t < 64) {
+            double ri = (t < bs) ? a.rhs[j0 + t] : 0.0;
+            for (int k = 0; k < bs; ++k) {
+                const double zk = __shfl(ri, k) * invd[k];
+                if (t == k) ri = zk;
+                else if (t > k) ri = fma(-S[t][k], zk, ri);
+            }
+            zblk[t] = ri;
+            if (blockIdx.x == 0 && t < bs) a.rhs[j0 + t] = ri;
+        }
+        __syncthreads();
     }
     // rows of the panel below the diagonal block: x L_jj^T = a  (row-wise forward substitution)
     const long long row = j0 + PB + (long long)blockIdx.x * 256 + t;
@@ -95,6 +114,15 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(PotrfArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < PB; ++k) ap[k] = x[k];
+        if (a.rhs) {
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < PB; k += 2) {
+                d0 = fma(x[k], zblk[k], d0);
+                d1 = fma(x[k + 1], zblk[k + 1], d1);
+            }
+            a.rhs[row] -= d0 + d1;
+        }
     }
 }
 
@@ -149,12 +177,19 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(PotrfArgs a) {
             }
 }
 
+__global__ __launch_bounds__(256) void potrf_rhs_init_kernel(const double* y, double shift, double* rhs, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rhs[i] = y[i] - shift;
+}
+
 __global__ void potrf_finish_kernel(int* info) {
     if (*(unsigned int*)info == 0xffffffffu) *info = 0;
 }
 
-extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, int32_t* info_dev, void* stream) {
+extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, double shift, double* z,
+                          int32_t* info_dev, void* stream) {
     APGP_CHECK_ARG(A && info_dev, "null pointer");
+    APGP_CHECK_ARG((y == NULL) == (z == NULL), "y and z must be given together");
     APGP_CHECK_ARG(n >= 1 && lda >= n, "n >= 1 and lda >= n required");
     hipStream_t s = (hipStream_t)stream;
     // info = UINT_MAX means "no failure yet"; normalised to 0 by the caller-visible finish kernel
@@ -163,7 +198,8 @@ extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, int32_t* info_dev, 
         return -2;
     }
     PotrfArgs a;
-    a.A = A; a.n = n; a.lda = lda; a.info = info_dev;
+    a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = shift; a.info = info_dev;
+    if (z) hipLaunchKernelGGL(potrf_rhs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, shift, z, (long long)n);
     const long long nb = (n + PB - 1) / PB;
     for (long long jb = 0; jb < nb; ++jb) {
         a.j0 = jb * PB;

@@ -237,6 +237,8 @@ class GP(object):
         self._L = None            # (N,N) lower Cholesky factor (device)
         self._alpha_y = None      # host copy of the y alpha/z were computed for
         self._alpha_mean = None
+        self._y_d = None
+        self._ztz_host = None
         self._z = None
         self._alpha = None
         self._packed = None       # packed L^-1 tiles
@@ -326,24 +328,38 @@ class GP(object):
             raise ValueError("Dimension mismatch")
         return np.ascontiguousarray(y)
 
-    # -- compute / recompute: K1 gram + rocSOLVER potrf + K2 logdet ---------------
+    # -- compute / recompute: K1 gram + blocked Cholesky (+ fused forward solve) + K2 ------
     def compute(self, x, yerr=0.0, **kwargs):
-        torch, dev, lib = self._rt()
         x = self.parse_samples(x)
         if x.shape[1] > _lib.MAX_DIM:
             raise ValueError("at most %d dimensions are supported" % _lib.MAX_DIM)
+        same_x = self._x is not None and self._x.shape == x.shape and np.array_equal(self._x, x)
         self._x = x
         self._yerr2 = float(yerr) ** 2
+        self._factor(None, upload_x=not same_x)
+
+    def _factor(self, y, upload_x=False):
+        """Gram + Cholesky (+ z = L^-1 (y - mean) carried through the factorisation)
+        + log-determinant / diagonal range / z.z / info, fetched with ONE 40-byte
+        device-to-host copy.  This is one gpUtils._nll evaluation."""
+        torch, dev, lib = self._rt()
+        x = self._x
+        n = len(x)
+        yv = None if y is None else self._check_dimensions(y)
+        keep_x = None if upload_x else getattr(self, "_x_d", None)
+        keep_y = self._y_d if (yv is not None and self._alpha_y is not None
+                               and np.array_equal(self._alpha_y, yv)) else None
         self._reset_device_state()
         self._computed = False
-        n = len(x)
         ks = self._kernel_struct()
         with torch.cuda.device(dev):
             st = self._stream(torch)
-            self._x_d = torch.from_numpy(x).to(dev)
+            self._x_d = keep_x if keep_x is not None else torch.from_numpy(x).to(dev)
             K = torch.empty((n, n), dtype=torch.float64, device=dev)
             _lib.check(lib.apgp_gram(self._x_d.data_ptr(), n, ctypes.byref(ks), K.data_ptr(), n, st),
                        "apgp_gram")
+            out5 = torch.empty(5, dtype=torch.float64, device=dev)
+            z = None
             if _USE_ROCSOLVER:
                 # rocSOLVER potrf works column-major: asking for the UPPER factor makes
                 # its memory image the row-major LOWER factor the kernels stream.
@@ -351,18 +367,25 @@ class GP(object):
                 L = U.mT
                 if not L.is_contiguous():
                     L = L.contiguous()
+                info = info.to(torch.int32).reshape(1)
             else:
                 # own blocked Cholesky (csrc/potrf.hip), in place on the Gram matrix
                 info = torch.empty(1, dtype=torch.int32, device=dev)
-                _lib.check(lib.apgp_potrf(K.data_ptr(), n, n, info.data_ptr(), st), "apgp_potrf")
+                if yv is not None:
+                    y_d = keep_y if keep_y is not None else torch.from_numpy(yv).to(dev)
+                    z = torch.empty(n, dtype=torch.float64, device=dev)
+                    _lib.check(lib.apgp_potrf(K.data_ptr(), n, n, y_d.data_ptr(), float(self.mean.value),
+                                              z.data_ptr(), info.data_ptr(), st), "apgp_potrf")
+                else:
+                    _lib.check(lib.apgp_potrf(K.data_ptr(), n, n, None, 0.0, None, info.data_ptr(), st),
+                               "apgp_potrf")
                 L = K
-            out3 = torch.empty(3, dtype=torch.float64, device=dev)
-            _lib.check(lib.apgp_logdet(L.data_ptr(), n, n, out3.data_ptr(), st), "apgp_logdet")
-            info = int(info.item())
-            if info != 0:
-                # same failure mode as scipy.linalg.cholesky inside george
-                raise LinAlgError("%d-th leading minor of the array is not positive definite" % info)
-            o = out3.cpu().numpy()
+            _lib.check(lib.apgp_fit_summary(L.data_ptr(), n, n, z.data_ptr() if z is not None else None,
+                                            info.data_ptr(), out5.data_ptr(), st), "apgp_fit_summary")
+            o = out5.cpu().numpy()          # the only synchronisation of the evaluation
+        if int(o[4]) != 0:
+            # same failure mode as scipy.linalg.cholesky inside george
+            raise LinAlgError("%d-th leading minor of the array is not positive definite" % int(o[4]))
         if not np.isfinite(o[0]):
             raise LinAlgError("non-finite log-determinant")
         self._L = L
@@ -371,13 +394,19 @@ class GP(object):
         self._const = -0.5 * (n * np.log(2.0 * np.pi) + self.log_determinant)
         self._computed = True
         self.kernel.dirty = False
+        if z is not None:
+            self._z = z
+            self._ztz_host = float(o[3])
+            self._y_d = y_d
+            self._alpha_y = np.array(yv, copy=True)
+            self._alpha_mean = self.mean.value
 
     def recompute(self, quiet=False, **kwargs):
         if self.kernel.dirty or not self._computed:
             if self._x is None:
                 raise RuntimeError("You need to compute the model first")
             try:
-                self.compute(self._x, np.sqrt(self._yerr2), **kwargs)
+                self._factor(None)
             except (ValueError, LinAlgError):
                 if quiet:
                     return False
@@ -386,7 +415,7 @@ class GP(object):
 
     # -- K3: z = L^-1 (y - mean), alpha = L^-T z -----------------------------------
     def _solve(self, y, need_alpha):
-        """Ensures z (and alpha) for this y; returns device sum-of-squares tensor."""
+        """Ensures z (and alpha) for this y; returns z.z as a float."""
         torch, dev, lib = self._rt()
         y = self._check_dimensions(y)
         n = len(y)
@@ -395,12 +424,13 @@ class GP(object):
         with torch.cuda.device(dev):
             st = self._stream(torch)
             if not same or self._z is None:
-                y_d = torch.from_numpy(y).to(dev)
+                self._y_d = torch.from_numpy(y).to(dev)
                 self._z = torch.empty(n, dtype=torch.float64, device=dev)
-                self._ztz = torch.empty(1, dtype=torch.float64, device=dev)
-                _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, y_d.data_ptr(),
+                ztz = torch.empty(1, dtype=torch.float64, device=dev)
+                _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, self._y_d.data_ptr(),
                                          float(self.mean.value), 0, self._z.data_ptr(),
-                                         self._ztz.data_ptr(), st), "apgp_trsv(forward)")
+                                         ztz.data_ptr(), st), "apgp_trsv(forward)")
+                self._ztz_host = float(ztz.item())
                 self._alpha = None
                 self._xs = None
                 self._alpha_y = np.array(y, copy=True)
@@ -410,15 +440,20 @@ class GP(object):
                 _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, self._z.data_ptr(), 0.0, 1,
                                          self._alpha.data_ptr(), None, st), "apgp_trsv(backward)")
                 self._xs = None
-        return self._ztz
+        return self._ztz_host
 
     def log_likelihood(self, y, quiet=False):
-        """george GP.log_likelihood (gpUtils.py:78,247): never raises when quiet."""
+        """george GP.log_likelihood (gpUtils.py:78,247): never raises when quiet.
+        When the model is dirty (the gpUtils._nll pattern: set_parameter_vector then
+        log_likelihood) the refactorisation carries y along, so the whole evaluation
+        is gram + potrf + one reduction + one 40-byte copy."""
         try:
-            if not self.recompute(quiet=quiet):
-                return -np.inf
+            if self.kernel.dirty or not self._computed:
+                if self._x is None:
+                    raise RuntimeError("You need to compute the model first")
+                self._factor(y)
             ztz = self._solve(y, need_alpha=False)
-            ll = self._const - 0.5 * float(ztz.item())
+            ll = self._const - 0.5 * ztz
         except (ValueError, LinAlgError):
             if quiet:
                 return -np.inf

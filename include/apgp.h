@@ -90,17 +90,26 @@ int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
  * Replaces scipy.linalg.cholesky inside george BasicSolver.compute (every
  * gpUtils._nll evaluation, gpUtils.py:74-78; GP.compute, gpUtils.py:178,
  * approx.py:717).  Only the lower triangle of A is read and written.
+ * Optionally carries a right-hand side through the factorisation: with
+ * y, z != NULL, z = L^-1 (y - shift) comes out of the same launches (what
+ * GP.log_likelihood needs right after a refactorisation: r^T K^-1 r = z.z), so
+ * an _nll evaluation needs no separate triangular solve.
  * *info_dev (device int32): 0 = OK, k > 0 = leading minor of order k is not
  * positive definite (LAPACK dpotrf convention; george/SciPy raise LinAlgError). */
-int apgp_potrf(double* A, int64_t n, int64_t lda, int32_t* info_dev, void* stream);
+int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, double shift, double* z,
+               int32_t* info_dev, void* stream);
 
 /* ---- K2: log-determinant and diagonal range of the Cholesky factor -------
  * Replaces BasicSolver.compute's ``2*sum(log(diag(U)))`` (george; feeds
  * GP._const used by gpUtils._nll, gpUtils.py:78).  L is the lower factor
- * (row-major; the Cholesky itself is rocSOLVER dpotrf driven by the host).
- * out[0] = log det K = 2*sum log L_ii, out[1] = min L_ii, out[2] = max L_ii
- * (so (out[2]/out[1])^2 is a condition estimate).                           */
-int apgp_logdet(const double* L, int64_t n, int64_t ldl, double* out3, void* stream);
+ * (row-major).  out[0] = log det K = 2*sum log L_ii, out[1] = min L_ii,
+ * out[2] = max L_ii (so (out[2]/out[1])^2 is a condition estimate); the buffer
+ * must hold 5 doubles (out[3], out[4] are written as 0).
+ * apgp_fit_summary additionally returns out[3] = z.z (if z != NULL) and
+ * out[4] = *info_dev, so one 40-byte copy fetches everything an _nll needs.   */
+int apgp_logdet(const double* L, int64_t n, int64_t ldl, double* out5, void* stream);
+int apgp_fit_summary(const double* L, int64_t n, int64_t ldl, const double* z,
+                     const int32_t* info_dev, double* out5, void* stream);
 
 /* ---- K3: triangular solves for z = L^-1 (b - shift), alpha = L^-T z --------
  * Replaces BasicSolver.apply_inverse / dot_solve on a vector (scipy cho_solve;

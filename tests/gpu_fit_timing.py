@@ -33,7 +33,7 @@ for N, D in ((50, 2), (512, 8), (1152, 8), (4096, 8)):
     t_chol = timeit(lambda: torch.linalg.cholesky_ex(K, upper=True))
     info = torch.empty(1, dtype=torch.int32, device='cuda'); K2 = K.clone()
     def own():
-        K2.copy_(K); lib.apgp_potrf(K2.data_ptr(), N, N, info.data_ptr(), st)
+        K2.copy_(K); lib.apgp_potrf(K2.data_ptr(), N, N, None, 0.0, None, info.data_ptr(), st)
     t_copy = timeit(lambda: K2.copy_(K))
     t_own = timeit(own) - t_copy
     yd = torch.from_numpy(y).cuda(); z = torch.empty_like(yd); s = torch.empty(1, dtype=torch.float64, device="cuda")
