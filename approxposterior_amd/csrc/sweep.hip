@@ -339,7 +339,9 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
             SW_TICK(4);
             buf ^= 1;
         };
-        const int ndiag0 = CPB * ib;   // first chunk of the diagonal block
+        // first chunk that needs the predicated path: the diagonal block, or every
+        // chunk when the row block has padded rows (N not a multiple of 512)
+        const int ndiag0 = (sb_lim - RS * ib < RS) ? 0 : CPB * ib;
         for (; kc < nkc && kc < ndiag0; ++kc) do_tile(std::false_type{});
         for (; kc < nkc; ++kc) do_tile(std::true_type{});
         // row block finished: fold ||V||^2 into the per-candidate sum
