@@ -48,6 +48,7 @@ SIGNATURES = {
     "apgp_trtri_work_len": (_I64, [_I64]),
     "apgp_grad_work_len": (_I64, [_I64]),
     "apgp_gram": (ctypes.c_int, [_P, _I64, _KP, _P, _I64, _P]),
+    "apgp_kernel_cross": (ctypes.c_int, [_P, _I64, _P, _I64, _KP, _P, _I64, _P]),
     "apgp_potrf": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, _P, _P, _P]),
     "apgp_logdet": (ctypes.c_int, [_P, _I64, _I64, _P, _P]),
     "apgp_fit_summary": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),

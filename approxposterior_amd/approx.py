@@ -204,12 +204,17 @@ class ApproxPosterior(object):
                     if cache:
                         self.gpPar.append(currentHype)
                     # same kernel / mean / white-noise objects, new training set
+                    oldGP = self.gp
                     self.gp = george.GP(kernel=self.gp.kernel, fit_mean=True,
                                         mean=self.gp.mean,
                                         white_noise=self.gp.white_noise,
                                         fit_white_noise=False)
                     self.gp.set_parameter_vector(currentHype)
-                    self.gp.compute(self.theta)
+                    if hasattr(self.gp, "_try_extend"):
+                        # same hyper-parameters, one more row: O(N^2) factor extension
+                        self.gp.compute(self.theta, previous=oldGP)
+                    else:
+                        self.gp.compute(self.theta)
                     if ii % optGPEveryN == 0:
                         self.optGP(seed=seed, method=gpMethod, options=gpOptions,
                                    p0=gpP0, nGPRestarts=nGPRestarts,

@@ -90,3 +90,49 @@ extern "C" int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern, 
     APGP_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------
+// Cross kernel matrix  C_ij = amp * exp(-|xs1_i - xs2_j|^2)  (no diagonal term):
+// george ``kernel.get_value(x1, x2)``.  Used by the incremental factor update
+// (new training rows against the old ones).  One thread per output element.
+// ---------------------------------------------------------------------------
+struct CrossArgs {
+    const double* X1;
+    const double* X2;
+    double* C;
+    long long m, n, ldc;
+    KernConst kc;
+};
+
+__global__ __launch_bounds__(256) void kernel_cross_kernel(CrossArgs a) {
+    __shared__ double etab[APGP_EXP_TAB_N];
+    apgp_exp_tab_load(etab);
+    __syncthreads();
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.m * a.n) return;
+    const long long i = e / a.n, j = e % a.n;
+    double s = 0.0, s3 = 0.0;
+    for (int d = 0; d < a.kc.dpad; d += 2) {
+        double df0 = 0.0, df1 = 0.0;
+        if (d < a.kc.ndim) df0 = a.X1[i * a.kc.ndim + d] * a.kc.sc[d] - a.X2[j * a.kc.ndim + d] * a.kc.sc[d];
+        if (d + 1 < a.kc.ndim)
+            df1 = a.X1[i * a.kc.ndim + d + 1] * a.kc.sc[d + 1] - a.X2[j * a.kc.ndim + d + 1] * a.kc.sc[d + 1];
+        s = fma(df0, df0, s);
+        s3 = fma(df1, df1, s3);
+    }
+    a.C[i * a.ldc + j] = a.kc.amp * apgp_exp(-(s + s3), etab);
+}
+
+extern "C" int apgp_kernel_cross(const double* X1, int64_t m, const double* X2, int64_t n,
+                                 const apgp_kernel_t* kern, double* C, int64_t ldc, void* stream) {
+    APGP_CHECK_ARG(X1 && X2 && C && kern, "null pointer");
+    APGP_CHECK_ARG(m >= 1 && n >= 1 && ldc >= n, "m >= 1, n >= 1 and ldc >= n required");
+    CrossArgs a;
+    APGP_CHECK_ARG(apgp_make_kernconst(kern, &a.kc) == 0, "kernel parameters");
+    a.X1 = X1; a.X2 = X2; a.C = C; a.m = m; a.n = n; a.ldc = ldc;
+    hipLaunchKernelGGL(kernel_cross_kernel, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}

@@ -329,14 +329,69 @@ class GP(object):
         return np.ascontiguousarray(y)
 
     # -- compute / recompute: K1 gram + blocked Cholesky (+ fused forward solve) + K2 ------
-    def compute(self, x, yerr=0.0, **kwargs):
+    def compute(self, x, yerr=0.0, previous=None, **kwargs):
+        """george GP.compute.  ``previous`` (extension): a GP factorised with the
+        same hyper-parameters on a training set that is a PREFIX of ``x`` -- what
+        ApproxPosterior.findNextPoint has at hand when it appends a design point
+        (approx.py:693-717).  The factor is then extended row by row in O(N^2) per
+        new point instead of refactorised in O(N^3)."""
         x = self.parse_samples(x)
         if x.shape[1] > _lib.MAX_DIM:
             raise ValueError("at most %d dimensions are supported" % _lib.MAX_DIM)
         same_x = self._x is not None and self._x.shape == x.shape and np.array_equal(self._x, x)
         self._x = x
         self._yerr2 = float(yerr) ** 2
+        if previous is not None and self._try_extend(previous):
+            return
         self._factor(None, upload_x=not same_x)
+
+    def _factor_key(self):
+        return (tuple(self.kernel.get_parameter_vector().tolist()), float(self.white_noise.value),
+                float(self._yerr2))
+
+    def _try_extend(self, prev):
+        """Extend ``prev``'s Cholesky factor by the rows of self._x it does not cover:
+        l = L^-1 k(x_new, X_old), d = sqrt(k(x_new,x_new) + diag_add - l.l)."""
+        if _USE_ROCSOLVER or getattr(prev, "_L", None) is None or getattr(prev, "_x", None) is None:
+            return False
+        if getattr(prev, "_factored_key", None) != self._factor_key():
+            return False
+        n0, n1 = len(prev._x), len(self._x)
+        if not (0 < n0 < n1 and n1 - n0 <= 64 and prev._x.shape[1] == self._x.shape[1]
+                and np.array_equal(prev._x, self._x[:n0])):
+            return False
+        torch, dev, lib = self._rt()
+        ks = self._kernel_struct()
+        self._reset_device_state()
+        self._computed = False
+        with torch.cuda.device(dev):
+            st = self._stream(torch)
+            self._x_d = torch.from_numpy(self._x).to(dev)
+            L = torch.zeros((n1, n1), dtype=torch.float64, device=dev)
+            L[:n0, :n0].copy_(prev._L[:n0, :n0])
+            row = torch.empty(n1, dtype=torch.float64, device=dev)
+            ss = torch.empty(1, dtype=torch.float64, device=dev)
+            for j in range(n0, n1):
+                _lib.check(lib.apgp_kernel_cross(self._x_d[j:].data_ptr(), 1, self._x_d.data_ptr(), j,
+                                                 ctypes.byref(ks), row.data_ptr(), n1, st), "apgp_kernel_cross")
+                _lib.check(lib.apgp_trsv(L.data_ptr(), j, n1, row.data_ptr(), 0.0, 0, L[j].data_ptr(),
+                                         ss.data_ptr(), st), "apgp_trsv(append)")
+                d2 = ks.amp + ks.diag_add - float(ss.item())
+                if not (d2 > 0.0 and np.isfinite(d2)):
+                    self._reset_device_state()
+                    raise LinAlgError("%d-th leading minor of the array is not positive definite" % (j + 1))
+                L[j, j] = float(np.sqrt(d2))
+            out5 = torch.empty(5, dtype=torch.float64, device=dev)
+            _lib.check(lib.apgp_logdet(L.data_ptr(), n1, n1, out5.data_ptr(), st), "apgp_logdet")
+            o = out5.cpu().numpy()
+        self._L = L
+        self.log_determinant = float(o[0])
+        self.cond_estimate = float((o[2] / o[1]) ** 2)
+        self._const = -0.5 * (n1 * np.log(2.0 * np.pi) + self.log_determinant)
+        self._computed = True
+        self.kernel.dirty = False
+        self._factored_key = self._factor_key()
+        return True
 
     def _factor(self, y, upload_x=False):
         """Gram + Cholesky (+ z = L^-1 (y - mean) carried through the factorisation)
@@ -394,6 +449,7 @@ class GP(object):
         self._const = -0.5 * (n * np.log(2.0 * np.pi) + self.log_determinant)
         self._computed = True
         self.kernel.dirty = False
+        self._factored_key = self._factor_key()
         if z is not None:
             self._z = z
             self._ztz_host = float(o[3])

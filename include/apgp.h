@@ -86,6 +86,13 @@ int64_t apgp_trtri_work_len(int64_t n);
 int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
               double* K, int64_t ldk, void* stream);
 
+/* ---- cross kernel matrix ------------------------------------------------------
+ * C (m x n, ld ldc) = k(X1_i, X2_j) without the diagonal term: george
+ * ``kernel.get_value(x1, x2)``.  Feeds the incremental factor update when
+ * ApproxPosterior.findNextPoint appends a design point (approx.py:693-717).     */
+int apgp_kernel_cross(const double* X1, int64_t m, const double* X2, int64_t n,
+                      const apgp_kernel_t* kern /*host*/, double* C, int64_t ldc, void* stream);
+
 /* ---- Cholesky factorisation (lower, row-major, in place) -------------------
  * Replaces scipy.linalg.cholesky inside george BasicSolver.compute (every
  * gpUtils._nll evaluation, gpUtils.py:74-78; GP.compute, gpUtils.py:178,

@@ -348,3 +348,43 @@ def test_illconditioned_uses_solve_path(golden_dir, lib_loaded):
     bi, bu = gp.acquire(g["y"], g["cands"], "bape", bounds=bounds)
     u_true = -((2 * mt + vt) + (vt + np.log(-np.expm1(-vt))))
     assert u_true[bi] <= u_true.min() + 0.3 * abs(u_true.min())
+
+
+def test_incremental_factor_extension(lib_loaded):
+    """Appending design points (approx.py:693-717): the O(N^2) factor extension
+    (compute(x, previous=old_gp)) must agree with a full refactorisation, fall back
+    to it when the hyper-parameters differ, and feed the same predictions."""
+    go, agp = _mods()
+    X, y = _synthetic(700, 8)
+    def make():
+        return agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 8.0), ndim=8), fit_mean=True,
+                      mean=np.median(y), white_noise=-12, fit_white_noise=False)
+    old = make(); old.compute(X[:690])
+    ext = make(); ext.compute(X, previous=old)
+    full = make(); full.compute(X)
+    assert ext._L.shape == (700, 700)
+    assert np.isclose(ext.log_determinant, full.log_determinant, rtol=1e-12)
+    assert np.isclose(ext.log_likelihood(y), full.log_likelihood(y), rtol=1e-11)
+    Le, Lf = np.tril(ext._L.cpu().numpy()), np.tril(full._L.cpu().numpy())
+    assert np.abs(Le - Lf).max() <= 1e-11 * np.abs(Lf).max()
+    cands = np.random.RandomState(4).uniform(-5, 5, size=(300, 8))
+    me, ve = ext.predict(y, cands, return_var=True)
+    mf, vf = full.predict(y, cands, return_var=True)
+    assert np.allclose(me, mf, rtol=1e-10, atol=1e-10 * np.abs(mf).max()) and np.allclose(ve, vf, rtol=1e-9, atol=1e-12)
+    # different hyper-parameters -> silently refactorises from scratch
+    other = agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 7.0), ndim=8), fit_mean=True,
+                   mean=np.median(y), white_noise=-12, fit_white_noise=False)
+    other.compute(X, previous=old)
+    ref = agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 7.0), ndim=8), fit_mean=True,
+                 mean=np.median(y), white_noise=-12, fit_white_noise=False)
+    ref.compute(X)
+    assert np.isclose(other.log_determinant, ref.log_determinant, rtol=1e-13)
+    # a duplicated point makes the extension fail exactly like a factorisation would
+    dup = make()
+    with pytest.raises(np.linalg.LinAlgError):
+        bad = agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 8.0), ndim=8), fit_mean=True,
+                     mean=0.0, white_noise=-800.0, fit_white_noise=False)
+        bad.compute(X[:50])
+        dup2 = agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 8.0), ndim=8), fit_mean=True,
+                      mean=0.0, white_noise=-800.0, fit_white_noise=False)
+        dup2.compute(np.vstack([X[:50], X[:1]]), previous=bad)
