@@ -43,6 +43,20 @@ def synthetic_c3(n_train, ndim):
     return X, y
 
 
+def profiled_traffic(n, d, m):
+    """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes
+    (profiles/r01b_pmc_sweep.json: FETCH_SIZE x2 for the gfx950 wide-stream
+    correction + WRITE_SIZE, per MI355X_MICROARCH.md), only for the exact workload
+    that was profiled; None otherwise (PMC counters are not collected inline)."""
+    path = os.path.join(ROOT, "profiles", "r01b_pmc_sweep.json")
+    if (n, d, m) != (4096, 8, 1000000) or not os.path.exists(path):
+        return None
+    try:
+        return float(json.load(open(path))["derived"]["hbm_traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def f_var(n, d):
     """Algorithmic flops per candidate, SURVEY.md section 8(d)."""
     return float(n) * n + float(n) * (3 * d + 4)
@@ -181,7 +195,8 @@ def main():
                        "sharding": "candidates split by rank, one 16 B/rank all-gather",
                        "fit_ms_excluded": fit_ms},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
+                         "traffic": profiled_traffic(N, D, M),
                          "kernel": "sweep_kernel<%d>" % (2 if D <= 2 else 4 if D <= 4 else 8 if D <= 8 else 16),
                          "kernel_ms": k_avg_ms,
                          "algorithmic_flops_per_candidate": f_var(N, D)},
