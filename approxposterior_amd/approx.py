@@ -238,19 +238,37 @@ class ApproxPosterior(object):
     # ---------------------------------------------------------------- runMCMC
     def runMCMC(self, samplerKwargs=None, mcmcKwargs=None, runName="apRun",
                 cache=True, estBurnin=True, thinChains=True, verbose=False,
-                args=None, batched=True, **kwargs):
+                args=None, batched=True, onDevice=False, **kwargs):
         """Sample the GP surrogate posterior with the stretch-move ensemble
         sampler and estimate burn-in / thinning (approx.py:757-859).  Returns
         ``(sampler, iburn, ithin)``.
 
         ``batched=True`` (default) evaluates each half-ensemble with ONE
         mean-only GP launch (``_gpllBatch``); ``batched=False`` calls the scalar
-        ``_gpll`` once per walker exactly as emcee does for the reference.
+        ``_gpll`` once per walker exactly as emcee does for the reference;
+        ``onDevice=True`` runs the entire chain as one persistent kernel
+        (``GP.sample_ensemble``) -- only valid when ``lnprior`` is the box prior
+        ``self.bounds`` (constant inside, -inf outside).
         With ``cache=True`` the finished chain is written to ``<runName>.npz``
         (keys chain, log_prob, blobs) where the reference writes ``<runName>.h5``.
         """
         samplerKwargs, mcmcKwargs = mcmcUtils.validateMCMCKwargs(self, samplerKwargs,
                                                                  mcmcKwargs, verbose)
+        if onDevice:
+            # the whole loop as one persistent kernel; valid when lnprior is the box
+            # prior self.bounds (constant inside, -inf outside), which the caller asserts
+            res = self.gp.sample_ensemble(self.y, mcmcKwargs["initial_state"],
+                                          mcmcKwargs["iterations"], self.bounds,
+                                          seed=np.random.randint(0, 2 ** 31 - 1))
+            self.sampler = emcee.DeviceChain(res)
+            if cache:
+                bname = str(runName) + ".npz"
+                self.backends.append(bname)
+                np.savez(bname, chain=self.sampler.get_chain(), log_prob=self.sampler.get_log_prob(),
+                         blobs=np.array([]))
+            iburn, ithin = mcmcUtils.estimateBurnin(self.sampler, estBurnin=estBurnin,
+                                                    thinChains=thinChains, verbose=verbose)
+            return self.sampler, iburn, ithin
         skw = dict(samplerKwargs)
         if batched:
             skw["log_prob_fn"] = lambda thetas, *a, **k: self._gpllBatch(thetas)

@@ -1,0 +1,216 @@
+// On-device affine-invariant ensemble sampler over the GP-mean surrogate: the
+// whole MCMC loop of ApproxPosterior.runMCMC (approx.py:839-846) -- emcee's
+// stretch move (Goodman & Weare 2010; red/blue split, a = 2) calling
+// ApproxPosterior._gpll (approx.py:148-189: log-probability = GP predictive
+// mean, -inf outside the prior) once per walker per half-step -- as ONE
+// persistent kernel.  The chain is sequential (every half-step depends on the
+// previous one) and a half-step is only W/2 mean-only predictions, so on a GPU
+// the reference's structure is pure launch/sync latency (~0.1 ms per half-step
+// from the host, 4e4 half-steps for the README example); here proposal, RNG
+// (Philox4x32-10), prior gate, GP mean and accept test all stay on the device.
+// One workgroup = one independent ensemble (grid.x ensembles = replicas, the
+// only way this path shards); a wavefront evaluates one
+// walker's GP mean with its lanes striding the training points.
+// Only a box prior can be evaluated on the device (arbitrary Python priors
+// cannot): the caller asserts lnprior == const inside [lo, hi], -inf outside.
+#include "apgp_common.h"
+
+struct EnsArgs {
+    const double* xs;      // packed training stream: Npad x (DPAD+2): scaled x | alpha | 0
+    double* coords;        // E x W x D  (in: initial state, out: final state)
+    double* logp;          // E x W      (out: final log-probability)
+    double* chain;         // iterations x E x W x D or NULL
+    double* logp_chain;    // iterations x E x W or NULL
+    long long* naccept;    // E x W
+    long long n, iterations;
+    int ndim, nwalkers;
+    unsigned long long seed;
+    double mean, amp, a_stretch;
+    double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM];
+};
+
+__device__ __forceinline__ void philox4x32(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0;
+        const unsigned int n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
+        const unsigned int n3 = (unsigned int)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ double u01(unsigned int a, unsigned int b) {
+    // 53-bit uniform in (0, 1)
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+#define ENS_MAXW 256
+
+template <int DPAD>
+__global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
+    constexpr int XS = DPAD + 2;
+    __shared__ double etab[APGP_EXP_TAB_N];
+    __shared__ double cs[ENS_MAXW][DPAD];      // scaled walker coordinates
+    __shared__ double lp[ENS_MAXW];
+    __shared__ double qs[ENS_MAXW / 2][DPAD];  // scaled proposals of the active half
+    __shared__ double lpq[ENS_MAXW / 2];
+    __shared__ double fac[ENS_MAXW / 2];       // (D-1) log z
+    __shared__ double uacc[ENS_MAXW / 2];
+    __shared__ int qok[ENS_MAXW / 2];
+    __shared__ int nacc[ENS_MAXW];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int W = a.nwalkers, H = W / 2, D = a.ndim;
+    const long long ens = blockIdx.x;
+    apgp_exp_tab_load(etab);
+    double* gc = a.coords + ens * W * D;
+    for (int e = t; e < W * DPAD; e += 1024) {
+        const int w = e / DPAD, d = e % DPAD;
+        cs[w][d] = d < D ? gc[w * D + d] * a.sc[d] : 0.0;
+    }
+    if (t < W) nacc[t] = 0;
+    __syncthreads();
+
+    // GP mean of the point whose scaled coordinates are p[0..DPAD): one wavefront
+    auto gp_mean = [&](const double* p) {
+        double tt[DPAD];
+#pragma unroll
+        for (int d = 0; d < DPAD; ++d) tt[d] = p[d];
+        double acc = 0.0;
+        for (long long k = lane; k < a.n; k += 64) {
+            const double* xr = a.xs + k * XS;
+            double s = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DPAD; d += 2) {
+                const double df0 = tt[d] - xr[d], df1 = tt[d + 1] - xr[d + 1];
+                s = fma(df0, df0, s);
+                s3 = fma(df1, df1, s3);
+            }
+            acc = fma(a.amp * apgp_exp(-(s + s3), etab), xr[DPAD], acc);
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        return acc + a.mean;
+    };
+
+    for (int w = wv; w < W; w += 16) {
+        double m = gp_mean(cs[w]);
+        // walkers that start outside the prior have zero probability (as _gpll returns -inf)
+        for (int d = 0; d < D; ++d) {
+            const double x = cs[w][d] / a.sc[d];
+            if (!(x >= a.lo[d] && x <= a.hi[d])) m = -INFINITY;
+        }
+        if (lane == 0) lp[w] = m;
+    }
+    __syncthreads();
+
+    const unsigned int k0 = (unsigned int)a.seed, k1 = (unsigned int)(a.seed >> 32) ^ (unsigned int)(ens * 0x9E3779B9u);
+    for (long long it = 0; it < a.iterations; ++it) {
+        // random cyclic offset of the red/blue partition for this iteration
+        unsigned int cr[4] = {(unsigned int)it, (unsigned int)(it >> 32), 0xFFFFFFFFu, 0x5u};
+        philox4x32(cr, k0, k1);
+        const int rot = (int)(cr[0] % (unsigned int)W);
+        for (int split = 0; split < 2; ++split) {
+            // walker index of slot i of the active half S and of the complement C
+            auto s_idx = [&](int i) { int v = i + split * H + rot; return v >= W ? v - W : v; };
+            auto c_idx = [&](int i) { int v = i + (1 - split) * H + rot; return v >= W ? v - W : v; };
+            if (t < H) {
+                unsigned int c1[4] = {(unsigned int)it, (unsigned int)(it >> 32), (unsigned int)(split * ENS_MAXW + t), 0x1u};
+                philox4x32(c1, k0, k1);
+                const double u = u01(c1[0], c1[1]);
+                const double z = ((a.a_stretch - 1.0) * u + 1.0);
+                const double zz = z * z / a.a_stretch;
+                const int j = c_idx((int)(c1[2] % (unsigned int)H));
+                const int s = s_idx(t);
+                bool ok = true;
+#pragma unroll
+                for (int d = 0; d < DPAD; ++d) {
+                    const double q = cs[j][d] - (cs[j][d] - cs[s][d]) * zz;
+                    qs[t][d] = q;
+                    if (d < D) {
+                        // prior gate in unscaled coordinates
+                        const double x = q / a.sc[d];
+                        if (!(x >= a.lo[d] && x <= a.hi[d])) ok = false;
+                    }
+                }
+                qok[t] = ok ? 1 : 0;
+                fac[t] = (D - 1.0) * log(zz);
+                unsigned int c2[4] = {(unsigned int)it, (unsigned int)(it >> 32), (unsigned int)(split * ENS_MAXW + t), 0x2u};
+                philox4x32(c2, k0, k1);
+                uacc[t] = u01(c2[0], c2[1]);
+            }
+            __syncthreads();
+            for (int i = wv; i < H; i += 16) {
+                double m = -INFINITY;
+                if (qok[i]) m = gp_mean(qs[i]);         // wave-uniform branch
+                if (lane == 0) lpq[i] = m;
+            }
+            __syncthreads();
+            if (t < H) {
+                const int s = s_idx(t);
+                const double diff = fac[t] + lpq[t] - lp[s];
+                if (qok[t] && lpq[t] == lpq[t] && log(uacc[t]) < diff) {
+#pragma unroll
+                    for (int d = 0; d < DPAD; ++d) cs[s][d] = qs[t][d];
+                    lp[s] = lpq[t];
+                    nacc[s] += 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (a.chain) {
+            double* out = a.chain + ((it * gridDim.x + ens) * W) * D;
+            for (int e = t; e < W * D; e += 1024) {
+                const int w = e / D, d = e % D;
+                out[e] = cs[w][d] / a.sc[d];
+            }
+        }
+        if (a.logp_chain && t < W) a.logp_chain[(it * gridDim.x + ens) * W + t] = lp[t];
+    }
+    for (int e = t; e < W * D; e += 1024) {
+        const int w = e / D, d = e % D;
+        gc[e] = cs[w][d] / a.sc[d];
+    }
+    if (t < W) {
+        a.logp[ens * W + t] = lp[t];
+        a.naccept[ens * W + t] = nacc[t];
+    }
+}
+
+extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kernel_t* kern, double mean,
+                                    const double* lo, const double* hi, int32_t nwalkers,
+                                    int32_t nensembles, int64_t iterations, double a_stretch,
+                                    uint64_t seed, double* coords, double* logp, double* chain,
+                                    double* logp_chain, int64_t* naccept, void* stream) {
+    APGP_CHECK_ARG(xs && kern && lo && hi && coords && logp && naccept, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && iterations >= 0 && nensembles >= 1, "n, iterations, nensembles");
+    KernConst kc;
+    APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
+    APGP_CHECK_ARG(nwalkers >= 2 && nwalkers % 2 == 0 && nwalkers <= ENS_MAXW, "nwalkers must be even and <= 256");
+    APGP_CHECK_ARG(nwalkers >= 2 * kc.ndim, "nwalkers must be at least twice the dimension");
+    APGP_CHECK_ARG(a_stretch > 1.0, "stretch scale a must be > 1");
+    for (int d = 0; d < kc.ndim; ++d) APGP_CHECK_ARG(kc.sc[d] > 0.0, "inverse metric must be positive");
+    EnsArgs a;
+    a.xs = xs; a.coords = coords; a.logp = logp; a.chain = chain; a.logp_chain = logp_chain;
+    a.naccept = (long long*)naccept; a.n = apgp_npad(n); a.iterations = iterations;
+    a.ndim = kc.ndim; a.nwalkers = nwalkers; a.seed = seed; a.mean = mean; a.amp = kc.amp;
+    a.a_stretch = a_stretch;
+    for (int d = 0; d < APGP_MAX_DIM; ++d) {
+        a.sc[d] = d < kc.ndim ? kc.sc[d] : 1.0;
+        a.lo[d] = d < kc.ndim ? lo[d] : 0.0;
+        a.hi[d] = d < kc.ndim ? hi[d] : 0.0;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)nensembles), block(1024);
+    switch (kc.dpad) {
+        case 2: hipLaunchKernelGGL(ensemble_kernel<2>, grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL(ensemble_kernel<4>, grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL(ensemble_kernel<8>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(ensemble_kernel<16>, grid, block, 0, s, a); break;
+    }
+    APGP_CHECK_LAUNCH();
+    return 0;
+}

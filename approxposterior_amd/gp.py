@@ -663,6 +663,56 @@ class GP(object):
                     out.append(u.cpu().numpy())
         return tuple(out)
 
+    # -- on-device ensemble MCMC over the GP mean ------------------------------------
+    def sample_ensemble(self, y, initial_state, iterations, bounds, a=2.0, seed=0, store=True):
+        """Run the stretch-move ensemble sampler entirely on the device with
+        log-probability = GP mean (what ApproxPosterior._gpll returns) and the box
+        prior ``bounds``.  ``initial_state`` is (W, D) for one ensemble or (E, W, D)
+        for E independent ensembles (one workgroup each).  Returns a dict with
+        ``chain`` (iterations, E*W, D), ``log_prob`` (iterations, E*W), ``coords``,
+        ``final_log_prob`` and ``naccept``."""
+        self.recompute()
+        torch, dev, lib = self._rt()
+        y = self._check_dimensions(y)
+        p0 = np.ascontiguousarray(np.asarray(initial_state, dtype=np.float64))
+        D = self.kernel.ndim
+        if p0.ndim == 1:
+            p0 = p0.reshape(-1, D)
+        if p0.ndim == 2:
+            p0 = p0[None]
+        if p0.ndim != 3 or p0.shape[2] != D:
+            raise ValueError("initial_state must be (W, D) or (E, W, D)")
+        if not np.all(np.isfinite(p0)):
+            raise ValueError("At least one parameter value was NaN or infinite")
+        E, W, _ = p0.shape
+        b = np.asarray(bounds, dtype=np.float64).reshape(-1, 2)
+        if len(b) != D:
+            raise ValueError("bounds must have one (lo, hi) pair per dimension")
+        lo = (ctypes.c_double * _lib.MAX_DIM)(*b[:, 0])
+        hi = (ctypes.c_double * _lib.MAX_DIM)(*b[:, 1])
+        n = len(self._x)
+        ks = self._kernel_struct()
+        iterations = int(iterations)
+        with torch.cuda.device(dev):
+            st = self._stream(torch)
+            self._ensure_xs(y)
+            coords = torch.from_numpy(p0).to(dev)
+            logp = torch.empty((E, W), dtype=torch.float64, device=dev)
+            nacc = torch.empty((E, W), dtype=torch.int64, device=dev)
+            chain = torch.empty((iterations, E, W, D), dtype=torch.float64, device=dev) if store else None
+            lchain = torch.empty((iterations, E, W), dtype=torch.float64, device=dev) if store else None
+            _lib.check(lib.apgp_ensemble_sample(
+                self._xs.data_ptr(), n, ctypes.byref(ks), float(self.mean.value), lo, hi, W, E,
+                iterations, float(a), int(seed) & 0xFFFFFFFFFFFFFFFF, coords.data_ptr(), logp.data_ptr(),
+                chain.data_ptr() if store else None, lchain.data_ptr() if store else None,
+                nacc.data_ptr(), st), "apgp_ensemble_sample")
+            out = {"coords": coords.cpu().numpy().reshape(E * W, D),
+                   "final_log_prob": logp.cpu().numpy().reshape(E * W),
+                   "naccept": nacc.cpu().numpy().reshape(E * W),
+                   "chain": chain.cpu().numpy().reshape(iterations, E * W, D) if store else None,
+                   "log_prob": lchain.cpu().numpy().reshape(iterations, E * W) if store else None}
+        return out
+
     # -- K4: gradient of the log-likelihood ------------------------------------------
     def grad_log_likelihood(self, y, quiet=False):
         """george GP.grad_log_likelihood (gpUtils.py:110): zeros on failure when quiet."""

@@ -244,3 +244,33 @@ class EnsembleSampler(object):
 
     def get_autocorr_time(self, discard=0, thin=1, **kwargs):
         return thin * integrated_time(self.get_chain(discard=discard, thin=thin), **kwargs)
+
+
+class DeviceChain(EnsembleSampler):
+    """Result of an on-device run (``GP.sample_ensemble``) behind the same accessors
+    as :class:`EnsembleSampler` (``get_chain``, ``get_log_prob``,
+    ``get_autocorr_time``, ``acceptance_fraction``), so burn-in estimation and the
+    reference-style post-processing work unchanged."""
+
+    def __init__(self, result):
+        chain = result["chain"]
+        self.nwalkers = chain.shape[1]
+        self.ndim = chain.shape[2]
+        self.log_prob_fn = None
+        self.args, self.kwargs = (), {}
+        self.vectorize = True
+        self.a = 2.0
+        self.blobs_dtype = None
+        self.backend = None
+        self._random = None
+        self.iteration = chain.shape[0]
+        self._chain = chain
+        self._log_prob = result["log_prob"]
+        self._blobs = []
+        self._naccepted = np.asarray(result["naccept"], dtype=float)
+        self._coords = result["coords"]
+        self._lp = result["final_log_prob"]
+        self._bl = None
+
+    def sample(self, *args, **kwargs):
+        raise NotImplementedError("a finished on-device chain cannot be advanced from the host")

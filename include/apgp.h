@@ -185,6 +185,23 @@ int apgp_predict_mean(const double* T, int64_t m, const double* xs, int64_t n,
                       const apgp_kernel_t* kern /*host*/, double mean,
                       double* mu, void* stream);
 
+/* ---- on-device ensemble MCMC over the GP-mean surrogate ---------------------
+ * The whole loop of ApproxPosterior.runMCMC (approx.py:839-846): emcee's stretch
+ * move (a = a_stretch, red/blue halves with a random cyclic offset per iteration)
+ * with log-probability = GP predictive mean (ApproxPosterior._gpll,
+ * approx.py:148-189) and a box prior [lo, hi] (host arrays, required: -inf
+ * outside), as one persistent kernel; nensembles independent ensembles run as
+ * one workgroup each (replicas).  coords: nensembles x nwalkers x ndim, in =
+ * initial state, out = final state; logp / naccept: nensembles x nwalkers;
+ * chain (iterations x nensembles x nwalkers x ndim) and logp_chain may be NULL.
+ * nwalkers even, >= 2 ndim, <= 256.  RNG: Philox4x32-10 keyed by seed.         */
+int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kernel_t* kern /*host*/, double mean,
+                         const double* lo /*host*/, const double* hi /*host*/,
+                         int32_t nwalkers, int32_t nensembles, int64_t iterations,
+                         double a_stretch, uint64_t seed,
+                         double* coords, double* logp, double* chain, double* logp_chain,
+                         int64_t* naccept, void* stream);
+
 /* ---- K4: gradient of the log-likelihood wrt kernel hyper-parameters -------
  * Replaces george GP.grad_log_likelihood (gpUtils._grad_nll, gpUtils.py:110):
  *   g_k = 0.5 * sum_ij (alpha alpha^T - K^-1)_ij dK_ij/dtheta_k.

@@ -105,3 +105,51 @@ def test_sweep_point_search_vs_nelder_mead():
             a = float(np.ravel(a)[0]); b = float(np.ravel(b)[0])
             assert (np.isnan(b) and np.isnan(blob[i])) or b == blob[i]
             assert a == lp[i] or np.isclose(a, lp[i], rtol=1e-12)
+
+
+def test_device_ensemble_sampler_matches_host_sampler():
+    """The persistent-kernel sampler (GP.sample_ensemble / runMCMC(onDevice=True)):
+    (1) every stored log-probability IS the GP mean at the stored coordinates
+    (deterministic check of the in-kernel surrogate), (2) the chain never leaves
+    the box prior, (3) its posterior moments and acceptance rate agree with the
+    host stretch-move sampler driving the same GP within Monte-Carlo error,
+    (4) independent ensembles (replicas) are statistically consistent."""
+    from approxposterior_amd import mcmcUtils
+    np.random.seed(57)
+    ap = _rosen_ap(80)
+    with np.errstate(all="ignore"):
+        ap.optGP(seed=57, nGPRestarts=2)
+    W, iters = 40, 6000
+    p0 = np.array(ap.priorSample(W))
+    res = ap.gp.sample_ensemble(ap.y, p0, iters, ap.bounds, seed=11)
+    chain, lpc = res["chain"], res["log_prob"]
+    assert chain.shape == (iters, W, 2) and lpc.shape == (iters, W)
+    assert np.all(np.abs(chain) <= 5.0)
+    idx = np.random.RandomState(0).randint(0, iters, size=60)
+    for i in idx[:6]:
+        mu = ap.gp.predict(ap.y, chain[i], return_cov=False, return_var=False)
+        assert np.allclose(mu, lpc[i], rtol=1e-9, atol=1e-9)
+    # host sampler on the same surrogate
+    with np.errstate(all="ignore"):
+        sampler, iburn, ithin = ap.runMCMC(samplerKwargs={"nwalkers": W},
+                                           mcmcKwargs={"iterations": iters, "initial_state": p0},
+                                           cache=False, estBurnin=True, thinChains=True)
+        dsamp, dburn, dthin = ap.runMCMC(samplerKwargs={"nwalkers": W},
+                                         mcmcKwargs={"iterations": iters, "initial_state": p0},
+                                         cache=False, estBurnin=True, thinChains=True, onDevice=True)
+    h = sampler.get_chain(discard=max(iburn, 500), flat=True)
+    d = dsamp.get_chain(discard=max(dburn, 500), flat=True)
+    tau = max(np.max(sampler.get_autocorr_time(tol=0)), np.max(dsamp.get_autocorr_time(tol=0)))
+    neff = min(len(h), len(d)) / (2.0 * tau)
+    se = np.sqrt(h.var(axis=0) / neff + d.var(axis=0) / neff)
+    assert np.all(np.abs(h.mean(axis=0) - d.mean(axis=0)) < 5 * se), (h.mean(axis=0), d.mean(axis=0), se)
+    assert np.allclose(h.std(axis=0), d.std(axis=0), rtol=0.15)
+    assert abs(sampler.acceptance_fraction.mean() - dsamp.acceptance_fraction.mean()) < 0.08
+    assert 0.5 * iburn <= dburn <= 2.0 * iburn + 20
+    # replicas: 4 independent ensembles in one launch
+    p4 = np.array(ap.priorSample(4 * W)).reshape(4, W, 2)
+    r4 = ap.gp.sample_ensemble(ap.y, p4, 3000, ap.bounds, seed=5)
+    c4 = r4["chain"][500:].reshape(-1, 4, W, 2)
+    m4 = c4.mean(axis=(0, 2))
+    assert m4.shape == (4, 2) and np.all(np.abs(m4 - d.mean(axis=0)) < 8 * se + 0.15)
+    assert not np.allclose(c4[:, 0], c4[:, 1])
