@@ -51,9 +51,13 @@ __device__ __forceinline__ double u01(unsigned int a, unsigned int b) {
 
 #define ENS_MAXW 256
 
-template <int DPAD>
+// XLDS: the packed training stream (Npad x (DPAD+2) doubles) is staged into LDS once
+// (it is re-read by every walker of every half-step); falls back to L2 when it does
+// not fit beside the sampler state.
+template <int DPAD, bool XLDS>
 __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
     constexpr int XS = DPAD + 2;
+    extern __shared__ __attribute__((aligned(16))) double xsl[];
     __shared__ double etab[APGP_EXP_TAB_N];
     __shared__ double cs[ENS_MAXW][DPAD];      // scaled walker coordinates
     __shared__ double lp[ENS_MAXW];
@@ -73,6 +77,9 @@ __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
         cs[w][d] = d < D ? gc[w * D + d] * a.sc[d] : 0.0;
     }
     if (t < W) nacc[t] = 0;
+    if (XLDS) {
+        for (long long e = t; e < a.n * XS; e += 1024) xsl[e] = a.xs[e];
+    }
     __syncthreads();
 
     // GP mean of the point whose scaled coordinates are p[0..DPAD): one wavefront
@@ -81,8 +88,9 @@ __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
 #pragma unroll
         for (int d = 0; d < DPAD; ++d) tt[d] = p[d];
         double acc = 0.0;
-        for (long long k = lane; k < a.n; k += 64) {
-            const double* xr = a.xs + k * XS;
+        const int nn = (int)a.n;
+        for (int k = lane; k < nn; k += 64) {
+            const double* xr = (XLDS ? (const double*)xsl : a.xs) + k * XS;
             double s = 0.0, s3 = 0.0;
 #pragma unroll
             for (int d = 0; d < DPAD; d += 2) {
@@ -99,10 +107,8 @@ __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
     for (int w = wv; w < W; w += 16) {
         double m = gp_mean(cs[w]);
         // walkers that start outside the prior have zero probability (as _gpll returns -inf)
-        for (int d = 0; d < D; ++d) {
-            const double x = cs[w][d] / a.sc[d];
-            if (!(x >= a.lo[d] && x <= a.hi[d])) m = -INFINITY;
-        }
+        for (int d = 0; d < D; ++d)
+            if (!(cs[w][d] >= a.lo[d] && cs[w][d] <= a.hi[d])) m = -INFINITY;
         if (lane == 0) lp[w] = m;
     }
     __syncthreads();
@@ -130,11 +136,8 @@ __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
                 for (int d = 0; d < DPAD; ++d) {
                     const double q = cs[j][d] - (cs[j][d] - cs[s][d]) * zz;
                     qs[t][d] = q;
-                    if (d < D) {
-                        // prior gate in unscaled coordinates
-                        const double x = q / a.sc[d];
-                        if (!(x >= a.lo[d] && x <= a.hi[d])) ok = false;
-                    }
+                    // prior gate in scaled coordinates (lo/hi were scaled on the host)
+                    if (d < D && !(q >= a.lo[d] && q <= a.hi[d])) ok = false;
                 }
                 qok[t] = ok ? 1 : 0;
                 fac[t] = (D - 1.0) * log(zz);
@@ -200,17 +203,30 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
     a.a_stretch = a_stretch;
     for (int d = 0; d < APGP_MAX_DIM; ++d) {
         a.sc[d] = d < kc.ndim ? kc.sc[d] : 1.0;
-        a.lo[d] = d < kc.ndim ? lo[d] : 0.0;
-        a.hi[d] = d < kc.ndim ? hi[d] : 0.0;
+        a.lo[d] = d < kc.ndim ? lo[d] * kc.sc[d] : 0.0;     // bounds in scaled coordinates
+        a.hi[d] = d < kc.ndim ? hi[d] * kc.sc[d] : 0.0;
     }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)nensembles), block(1024);
+    const size_t xbytes = (size_t)a.n * (kc.dpad + 2) * sizeof(double);
+    const bool xlds = xbytes <= 96 * 1024;
+#define APGP_LAUNCH_ENS(DP)                                                                            \
+    do {                                                                                               \
+        if (xlds) {                                                                                    \
+            (void)hipFuncSetAttribute((const void*)ensemble_kernel<DP, true>,                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);          \
+            hipLaunchKernelGGL((ensemble_kernel<DP, true>), grid, block, xbytes, s, a);                \
+        } else {                                                                                       \
+            hipLaunchKernelGGL((ensemble_kernel<DP, false>), grid, block, 0, s, a);                    \
+        }                                                                                              \
+    } while (0)
     switch (kc.dpad) {
-        case 2: hipLaunchKernelGGL(ensemble_kernel<2>, grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL(ensemble_kernel<4>, grid, block, 0, s, a); break;
-        case 8: hipLaunchKernelGGL(ensemble_kernel<8>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(ensemble_kernel<16>, grid, block, 0, s, a); break;
+        case 2: APGP_LAUNCH_ENS(2); break;
+        case 4: APGP_LAUNCH_ENS(4); break;
+        case 8: APGP_LAUNCH_ENS(8); break;
+        default: APGP_LAUNCH_ENS(16); break;
     }
+#undef APGP_LAUNCH_ENS
     APGP_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Times the BASELINE.json configurations end to end on one MI355X (developer
+script; prints a small table used in DESIGN.md / BASELINE results)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from scipy.optimize import rosen
+from approxposterior_amd import approx, gpUtils, likelihood as lh, gp as agp
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def c1():
+    """README example (examples/inference/example.py:16-52): m0=50, m=20, nmax=2, 20 walkers x 2e4."""
+    np.random.seed(57)
+    theta = lh.rosenbrockSample(50)
+    y = np.array([lh.rosenbrockLnlike(t) + lh.rosenbrockLnprior(t) for t in theta])
+    gp = gpUtils.defaultGP(theta, y, white_noise=-12)
+    ap = approx.ApproxPosterior(theta=theta, y=y, gp=gp, lnprior=lh.rosenbrockLnprior,
+                                lnlike=lh.rosenbrockLnlike, priorSample=lh.rosenbrockSample,
+                                bounds=[(-5, 5), (-5, 5)], algorithm="bape")
+    t0 = time.time()
+    with np.errstate(all="ignore"):
+        ap.run(m=20, nmax=2, estBurnin=True, nGPRestarts=3, mcmcKwargs={"iterations": int(2.0e4)},
+               cache=False, samplerKwargs={"nwalkers": 20}, verbose=False, thinChains=False,
+               onlyLastMCMC=True, timing=True)
+    sync(); total = time.time() - t0
+    samples = ap.sampler.get_chain(discard=ap.iburns[-1], flat=True, thin=ap.ithins[-1])
+    print("C1 README example: total %.1f s (training %s s, mcmc %s s); posterior mean %s, N_train %d"
+          % (total, np.round(ap.trainingTime, 1), np.round(ap.mcmcTime, 1), np.round(samples.mean(axis=0), 3), len(ap.y)))
+    t0 = time.time()
+    with np.errstate(all="ignore"):
+        s2, ib, it_ = ap.runMCMC(samplerKwargs={"nwalkers": 20}, mcmcKwargs={"iterations": int(2.0e4)},
+                                 cache=False, onDevice=True)
+    sync()
+    print("   same MCMC (20 walkers x 2e4) on device: %.2f s; posterior mean %s"
+          % (time.time() - t0, np.round(s2.get_chain(discard=ib, flat=True).mean(axis=0), 3)))
+
+
+def c5_pieces():
+    """C5 shape: D=8, N=512..1152, 64 walkers x 2e4 iterations; per-point sweep."""
+    rs = np.random.RandomState(0)
+    for N in (512, 1152):
+        X = rs.uniform(-5, 5, size=(N, 8))
+        y = np.array([-rosen(x) / 100.0 for x in X])
+        gp = agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 8.0), ndim=8), fit_mean=True,
+                    mean=np.median(y), white_noise=-12, fit_white_noise=False)
+        gp.compute(X)
+        ap = approx.ApproxPosterior(theta=X, y=y, gp=gp, lnprior=lh.rosenbrockLnprior,
+                                    lnlike=lh.rosenbrockLnlike,
+                                    priorSample=lambda n: np.random.uniform(-5, 5, size=(n, 8)),
+                                    bounds=[(-5, 5)] * 8, algorithm="bape")
+        p0 = ap.priorSample(64)
+        for dev in (False, True):
+            sync(); t0 = time.time()
+            with np.errstate(all="ignore"):
+                ap.runMCMC(samplerKwargs={"nwalkers": 64}, mcmcKwargs={"iterations": 20000, "initial_state": p0},
+                           cache=False, estBurnin=False, thinChains=False, onDevice=dev)
+            sync()
+            print("C5 MCMC N=%d: 64 walkers x 2e4 iterations, %s: %.2f s" % (N, "on device" if dev else "host loop + batched GP mean", time.time() - t0))
+        sync(); t0 = time.time()
+        th = ap.findNextPoint(computeLnLike=False, nCandidates=1000000, verbose=False)
+        sync()
+        print("C5 point search N=%d: 1e6-candidate fused sweep incl. prior draws + H2D: %.3f s" % (N, time.time() - t0))
+        t0 = time.time()
+        with np.errstate(all="ignore"):
+            th = ap.findNextPoint(computeLnLike=False, verbose=False)
+        print("C5 point search N=%d: reference-style 5-restart Nelder-Mead: %.3f s" % (N, time.time() - t0))
+        t0 = time.time()
+        with np.errstate(all="ignore"):
+            ap.optGP(nGPRestarts=1)
+        print("C5 optGP N=%d: one Powell restart: %.2f s" % (N, time.time() - t0))
+
+
+if __name__ == "__main__":
+    c1()
+    c5_pieces()
