@@ -44,6 +44,7 @@ SIGNATURES = {
     "apgp_last_error": (ctypes.c_char_p, []),
     "apgp_npad": (_I64, [_I64]),
     "apgp_packed_linv_len": (_I64, [_I64]),
+    "apgp_acquire_work_len": (_I64, [_I64, _I64]),
     "apgp_packed_train_len": (_I64, [_I64, _I32]),
     "apgp_trtri_work_len": (_I64, [_I64]),
     "apgp_grad_work_len": (_I64, [_I64]),

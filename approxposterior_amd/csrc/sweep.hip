@@ -11,13 +11,20 @@
 //   * the packed factor W = L^-1 is streamed tile by tile (512 rows x 16 k,
 //     64 KiB, A-fragment order) L2/MALL -> registers -> LDS, double buffered,
 //     shared by the four wavefronts (one barrier per tile).
-//   * K* is NEVER materialised: each lane generates the k*(t_m, x_k) value it
-//     must feed as the MFMA B operand (lane -> candidate lane&15, k lane>>4)
-//     on the VALU (D sub + D fma + table-driven exp).
+//   * each lane generates the k*(t_m, x_k) value it must feed as the MFMA B
+//     operand (lane -> candidate lane&15, k lane>>4) on the VALU (D sub + D fma
+//     + table-driven exp) the FIRST time chunk k is visited (the diagonal row
+//     block); later row blocks need the same operands again, and because the
+//     fp64 VALU shares the DP pipe with the matrix cores, regenerating them
+//     costs ~12 % of a tile.  They are parked in a per-workgroup-slot scratch
+//     stream instead (32 B per lane per chunk, written once, read back one tile
+//     ahead, <0.5 TB/s chip-wide) -- K* is still never materialised as a matrix
+//     the host sees.  The grid is persistent (one workgroup per CU, candidate
+//     blocks dealt round-robin) so the scratch is SW_GRID slots, not M/64.
 //   * V = W K*^T is accumulated 512 rows x 16 candidates per wavefront in 128
 //     v_mfma_f64_4x4x4_4b_f64 accumulators (AGPRs); at the end of a row block
 //     the squares are folded into a per-candidate sum; V is never stored.
-//   * mu is a VALU by-product of the last row block (which visits every k).
+//   * mu is a VALU by-product of the generating tiles (every k exactly once).
 #include "apgp_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -28,6 +35,9 @@
 #define SW_TILE (SW_ROWS * SW_KC)    // doubles per tile (64 KiB)
 #define SW_CAND 64                   // candidates per workgroup (16 per wavefront)
 #define SW_THREADS 256
+#define SW_GRID 256                  // persistent workgroups = K* scratch slots (one per CU)
+#define SW_BCH (SW_THREADS * 4)      // doubles of parked B operands per chunk per slot
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct SweepArgs {
     const double* T;
@@ -39,8 +49,10 @@ struct SweepArgs {
     double* u;
     double* part_u;
     long long* part_i;
+    double* kcache;            // parked B operands: SW_GRID slots x ncache chunks x SW_BCH
+    unsigned linv_bytes, xs_bytes, kslot_bytes;   // buffer-descriptor extents
     long long m, idx_offset;
-    int ndim, nrb, kind, has_box, n;
+    int ndim, nrb, kind, has_box, n, ncache;
     double mean, amp, zeta, ybest;
     double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM];
     unsigned long long* dbg;   // phase cycle counters (APGP_SWEEP_TIMING=1 builds only)
@@ -94,133 +106,217 @@ __device__ __forceinline__ void best_merge(double& bu, long long& bi, double u, 
 // 128 MFMAs; one wavefront per SIMD, everything latency-critical is prefetched.
 template <int DPAD, bool TIMING = false>
 __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
-    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq = 0;
-#define SW_TICK(i) do { if (TIMING) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); tph[i] += n_ - tq; tq = n_; } } while (0)
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tq = 0, ntiles[2] = {0, 0};
+#define SW_TICK(i) do { if (TIMING) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); tph[(gen ? 3 : 0) + i] += n_ - tq; tq = n_; } } while (0)
     constexpr int XS = DPAD + 2;
     constexpr int RS = SW_ROWS / 16;           // 16-row sub-blocks per tile (32)
+    constexpr int NP = RS / 2;                 // sub-block pairs per tile (16)
     constexpr int NKK = SW_KC / 4;             // k-steps per tile (4)
-    static_assert(NKK == 4 && (RS % 2) == 0, "tile layout");
+    constexpr int HT = SW_TILE / 2;            // doubles per half tile (32 KiB)
+    static_assert(NKK == 4 && NP == 16, "tile layout");
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Abuf = smem;                       // 2 x SW_TILE
-    double* Xbuf = smem + 2 * SW_TILE;         // 2 x SW_KC x XS
+    double* Aring = smem;                      // 3 half tiles
+    double* Xbuf = smem + 3 * HT;              // 2 x SW_KC x XS
     double* Etab = Xbuf + 2 * SW_KC * XS;      // exp table
+    double* red_u = Etab + APGP_EXP_TAB_N;     // workgroup arg-min exchange (4 + 4 slots)
+    long long* red_i = (long long*)(red_u + 4);
+    double* Tc = red_u + 8;                    // scaled candidate coordinates [DPAD/2][256] x 16 B
+    // long-lived, rarely-touched per-lane values live in LDS, not in VGPRs: anything
+    // hipcc spills to scratch instead shares vmcnt with the factor stream and makes
+    // every wait on that stream a full drain
+    double* Qp = Tc + DPAD * SW_THREADS;       // ||V||^2 partial sums, one per B rotation
+    double* Mp = Qp + 4 * SW_THREADS;          // mu partial sums
+    int* Fl = (int*)(Mp + SW_THREADS);         // bit 0: admissible, bit 1: NaN coordinate
+    double* Cst = (double*)(Fl + SW_THREADS);  // sc | lo | hi (3 x APGP_MAX_DIM)
+
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cl = lane & 15, kq = lane >> 4;
     apgp_exp_tab_load(Etab);
+    if (t == 0) {
+#pragma unroll
+        for (int d = 0; d < APGP_MAX_DIM; ++d) {
+            Cst[d] = a.sc[d];
+            Cst[APGP_MAX_DIM + d] = a.lo[d];
+            Cst[2 * APGP_MAX_DIM + d] = a.hi[d];
+        }
+    }
 
-    // ---- candidate of this lane -------------------------------------------
-    double tt[DPAD];
-    const long long crow = (long long)blockIdx.x * SW_CAND + w * 16 + cl;
-    bool adm = crow < a.m;
-    bool has_nan = false;
+    constexpr int CPB = SW_ROWS / SW_KC;       // k-chunks per row-block width (32)
+    const int kc_lim = (a.n + SW_KC - 1) / SW_KC;     // chunks that hold real columns
+
+    // ---- the packed factor streams L2/MALL -> registers -> LDS ---------------------
+    // A half tile (256 rows x 16 k, 32 KiB) is eight 16-byte "pieces" per thread;
+    // piece q holds exactly the sub-block pair q of that half.  The stream is
+    // software-pipelined at the granularity of one piece per sub-block pair:
+    // at pair g a thread parks (ds_write_b128) the piece it requested 8 pairs
+    // (~4400 cycles) earlier and re-uses the register for the piece that will
+    // be consumed 17 pairs later.  The half tiles live in a ring of three LDS
+    // slots; a piece is written >= 8 pairs before it is read and >= 15 pairs
+    // after the previous occupant's last read, so ONE barrier every 8 pairs
+    // (placed in the middle of the MFMA stream, where no LDS read waits on it)
+    // covers both hazards and there is no pipeline restart at tile boundaries.
+    // (global_load_lds was measured at ~55 issue cycles per KiB on the issuing
+    // wavefront; with one wavefront per SIMD nothing hides that.)
+    constexpr int HALF16 = HT / 2;                   // 16-byte pieces per half tile (2048)
+    constexpr int NST = HALF16 / SW_THREADS;         // pieces per thread per half (8)
+    constexpr int XCHUNK16 = SW_KC * XS / 2;         // 16-byte pieces of the x chunk
+    static_assert(NST == 8 && XCHUNK16 <= SW_THREADS, "staging layout");
+    f64x2 R[NST];
+    f64x2 xpend;
+    f64x2 bpend[2];
+    // All streams go through buffer descriptors (scalar base + scalar offset + one
+    // 32-bit lane offset): no 64-bit per-lane addresses, VGPRs are the scarce resource.
+    const unsigned toff = (unsigned)t * 16u;         // lane part of every 16-byte piece address
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.linv, 0, (int)a.linv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.xs, 0, (int)a.xs_bytes, 0x00020000);
+    // parked B operands of this workgroup slot: chunk c -> [2][SW_THREADS] x 16 B
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.kcache + (long long)blockIdx.x * a.ncache * SW_BCH), 0, (int)a.kslot_bytes, 0x00020000);
+    auto gpiece = [&](long long tile, int half, int q) {
+        const unsigned soff = (unsigned)tile * (unsigned)(SW_TILE * 8) + (unsigned)(half * HT * 8 + q * SW_THREADS * 16);
+        return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_w, toff, soff, 0));
+    };
+    auto lpiece = [&](int slot, int q) {
+        return (f64x2*)(Aring + slot * HT) + q * SW_THREADS + t;
+    };
+    // NOTE: every load below is UNCONDITIONAL (indices are clamped instead): a load
+    // under an `if` makes hipcc merge "loaded or old" values and drain vmcnt(0) at
+    // the join, exposing the full memory latency (cdna guide, .s-level trap (c)).
+    const unsigned xoff = t < XCHUNK16 ? toff : 0u;
+    auto x_load = [&](int kc) {
+        xpend = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(
+            rs_x, xoff, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0));
+    };
+    auto x_store = [&](int xb) {
+        if (t < XCHUNK16) *((f64x2*)(Xbuf + xb * SW_KC * XS) + t) = xpend;
+    };
+    const int cmax = a.ncache > 0 ? a.ncache - 1 : 0;
+    const bool park = a.ncache > 0;
+    auto b_load = [&](int c) {
+        const unsigned soff = (unsigned)(c < cmax ? c : cmax) * (unsigned)(SW_BCH * 8);
+        bpend[0] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, toff, soff, 0));
+        bpend[1] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, toff, soff + SW_THREADS * 16, 0));
+    };
+
+    // tile sequence: row block ib, chunks kc = 0 .. min((ib+1)*CPB, kc_lim) - 1, then
+    // the next row block, then tile (0,0) again for the next candidate block;
+    // packed tile index = CPB*ib*(ib+1)/2 + kc
+    auto tile_index = [&](int ib, int kc) { return (long long)CPB * ib * (ib + 1) / 2 + kc; };
+    auto nkc_of = [&](int ib) { const int v = CPB * (ib + 1); return v < kc_lim ? v : kc_lim; };
+    auto successor = [&](int& ib, int& kc) {
+        ++kc;
+        if (kc >= nkc_of(ib)) { ++ib; kc = 0; }
+        if (ib >= a.nrb) { ib = 0; kc = 0; }
+    };
+    // A fragments of one sub-block pair: per 16-row sub-block two ds_read_b128 fetch
+    // the four k-steps of the lane's row (half-tile layout [s][kp][lane][q]).
+    f64x2 av[2][2][2];
+    auto load_a = [&](f64x2 (&dst)[2][2], int slot, int q) {
+        const f64x2* A2 = (const f64x2*)(Aring + slot * HT) + lane;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) dst[h][kp] = A2[((q * 2 + h) * 2 + kp) * 64];
+    };
+    // rotate a per-lane double by 4*r lanes inside each row of 16 lanes (DPP row_ror)
+    auto rot16 = [&](double v, int r) {
+        if (r == 0) return v;
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        int rl, rh;
+        if (r == 1) { rl = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xf, false); }
+        else if (r == 2) { rl = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false); }
+        else { rl = __builtin_amdgcn_update_dpp(0, lo, 0x12c, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x12c, 0xf, 0xf, false); }
+        return __hiloint2double(rh, rl);
+    };
+
+    // ---- pipeline prologue: tile (0,0) ------------------------------------------
     {
-        const bool inb = adm;
+        int ib1 = 0, kc1 = 0;
+        successor(ib1, kc1);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) R[q] = gpiece(0, 0, q);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) *lpiece(0, q) = R[q];
+        *lpiece(1, 0) = gpiece(0, 1, 0);
+#pragma unroll
+        for (int q = 1; q < NST; ++q) R[q] = gpiece(0, 1, q);
+        R[0] = gpiece(tile_index(ib1, kc1), 0, 0);
+        x_load(0); x_store(0);
+        bpend[0] = R[0]; bpend[1] = R[0];
+        __syncthreads();
+        load_a(av[0], 0, 0);
+    }
+    int h0 = 0;          // ring slot of the current tile's first half
+    int xb = 0;          // x-chunk buffer of the current tile
+
+    const long long nblk = (a.m + SW_CAND - 1) / SW_CAND;
+    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    // ---- candidate of this lane (scaled coordinates parked in LDS: only the
+    //      generating tiles need them, and VGPRs are the scarce resource) --------
+    {
+        const long long crow = blk * SW_CAND + w * 16 + cl;
+        const bool inb = crow < a.m;
+        bool adm = inb, has_nan = false;
 #pragma unroll
         for (int d = 0; d < DPAD; ++d) {
             double v = 0.0;
             if (inb && d < a.ndim) {
                 v = a.T[crow * a.ndim + d];
-                if (a.has_box && !(v >= a.lo[d] && v <= a.hi[d])) adm = false;
+                if (a.has_box && !(v >= Cst[APGP_MAX_DIM + d] && v <= Cst[2 * APGP_MAX_DIM + d])) adm = false;
                 if (v != v) has_nan = true;
             }
-            tt[d] = v * a.sc[d];
+            Tc[((d >> 1) * SW_THREADS + t) * 2 + (d & 1)] = v * Cst[d];
         }
         if (inb && a.mask && a.mask[crow] == 0) adm = false;
+        Fl[t] = (adm ? 1 : 0) | (has_nan ? 2 : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Qp[r * SW_THREADS + t] = 0.0;
+        Mp[t] = 0.0;
     }
 
-    double qpart = 0.0, mupart = 0.0;
-    // lane index of the A element this lane feeds for rotation r
-    int rot[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rot[r] = (lane & ~12) | ((((lane >> 2) + r) & 3) << 2);
-
-    constexpr int CPB = SW_ROWS / SW_KC;       // k-chunks per row-block width (32)
-    const int kc_lim = (a.n + SW_KC - 1) / SW_KC;     // chunks that hold real columns
-    const int sb_lim = (a.n + 15) / 16;               // sub-blocks (global) that hold real rows
-
-    // Tile staging through registers (global_load_dwordx4 early, ds_write_b128
-    // late): an LDS-DMA (global_load_lds) costs ~55 issue cycles per KiB on the
-    // issuing wavefront, and with one wavefront per SIMD nothing hides that.
-    // The 64 KiB tile moves in two halves of 8 x 16 B per thread.
-    constexpr int HALF16 = SW_TILE / 2 / 2;          // 16-byte pieces per half tile (2048)
-    constexpr int NST = HALF16 / SW_THREADS;         // pieces per thread per half (8)
-    constexpr int XCHUNK16 = SW_KC * XS / 2;         // 16-byte pieces of the x chunk
-    static_assert(XCHUNK16 <= SW_THREADS, "x chunk staging");
-    f64x2 st[NST];
-    f64x2 xpend;
-    auto half_load = [&](long long tile, int half) {
-        const f64x2* g = (const f64x2*)(a.linv + tile * SW_TILE) + half * HALF16 + t;
-#pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = g[i * SW_THREADS];
-    };
-    auto half_store = [&](int buf, int half) {
-        f64x2* l = (f64x2*)(Abuf + buf * SW_TILE) + half * HALF16 + t;
-#pragma unroll
-        for (int i = 0; i < NST; ++i) l[i * SW_THREADS] = st[i];
-    };
-    // two pieces (j0, j0+1) of a half tile: the staging traffic is dealt two
-    // instructions per sub-block pair into the MFMA stream (non-fp64 instructions
-    // cost ~1 cycle there; a cluster of them idles the matrix pipe)
-    auto piece_load = [&](long long tile, int half, int j0) {
-        const f64x2* g = (const f64x2*)(a.linv + tile * SW_TILE) + half * HALF16 + t;
-        st[j0] = g[j0 * SW_THREADS];
-        st[j0 + 1] = g[(j0 + 1) * SW_THREADS];
-    };
-    auto piece_store = [&](int buf, int half, int j0) {
-        f64x2* l = (f64x2*)(Abuf + buf * SW_TILE) + half * HALF16 + t;
-        l[j0 * SW_THREADS] = st[j0];
-        l[(j0 + 1) * SW_THREADS] = st[j0 + 1];
-    };
-    // NOTE: every load below is UNCONDITIONAL (indices are clamped instead): a load
-    // under an `if` makes hipcc merge "loaded or old" values and drain vmcnt(0) at
-    // the join, exposing the full memory latency (cdna guide, .s-level trap (c)).
-    const int xt = t < XCHUNK16 ? t : 0;
-    auto x_load = [&](int kc) {
-        xpend = *((const f64x2*)(a.xs + (long long)kc * SW_KC * XS) + xt);
-    };
-    auto x_store = [&](int buf) {
-        if (t < XCHUNK16) *((f64x2*)(Xbuf + buf * SW_KC * XS) + t) = xpend;
-    };
-
-    // tile sequence: row block ib, chunks kc = 0 .. min((ib+1)*CPB, kc_lim) - 1;
-    // packed tile index = CPB*ib*(ib+1)/2 + kc
-    auto tile_index = [&](int ib, int kc) { return (long long)CPB * ib * (ib + 1) / 2 + kc; };
-    auto nkc_of = [&](int ib) { const int v = CPB * (ib + 1); return v < kc_lim ? v : kc_lim; };
-
-    half_load(0, 0); half_store(0, 0);
-    half_load(0, 1); half_store(0, 1);
-    x_load(0); x_store(0);
-    __syncthreads();
-
-    int buf = 0;
     for (int ib = 0; ib < a.nrb; ++ib) {
         const int nkc = nkc_of(ib);
+        const int nparked = CPB * ib;          // chunks generated by an earlier row block
+        // drain the vector-memory counter once per row block (s_waitcnt vmcnt(0)): whatever
+        // spill traffic hipcc placed between candidate blocks must not be pending at the
+        // tile loop's entry, or every wait inside the loop degrades to a full drain
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         double acc[RS][4];
 #pragma unroll
         for (int s = 0; s < RS; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
-        // mu = k* . alpha: only the last row block's pass (which visits every k)
-        // survives -- mupart is reset at the top of each pass
-        mupart = 0.0;
         int kc = 0;
-        auto do_tile = [&](auto diag_tag) {
-            constexpr bool DIAG = decltype(diag_tag)::value;
-            if (TIMING) tq = __builtin_amdgcn_s_memtime();
-            // next tile in the sequence (possibly the first of the next row block)
-            int nib = ib, nk = kc + 1;
-            if (nk >= nkc) { nib = ib + 1; nk = 0; }
-            const bool more = nib < a.nrb;
-            if (!more) { nib = 0; nk = 0; }          // harmless dummy prefetch on the last tile
+        // One tile body for every case (a second unrolled body makes hipcc shuffle the
+        // 128 accumulators through scratch at the loop joins); what varies is uniform:
+        //  * pairs [p0, p1) hold non-zero rows (diagonal block: W is lower triangular;
+        //    last row block: rows >= N are padding) -- the others skip reads and MFMAs;
+        //  * gen: the B operands are generated (first visit of chunk kc, or parking
+        //    disabled), otherwise they were prefetched from the slot's scratch stream.
+        auto do_tile = [&]() {
+#ifdef SW_X_NOGEN
+            const bool gen = false;
+#else
+            const bool gen = !park || kc >= nparked;
+#endif
+            if (TIMING) { tq = __builtin_amdgcn_s_memtime(); ++ntiles[gen ? 1 : 0]; }
+            int nib = ib, nk = kc;
+            successor(nib, nk);
             const long long ntile = tile_index(nib, nk);
+            int pib = nib, pk = nk;
+            successor(pib, pk);
+            const long long nntile = tile_index(pib, pk);
+            const int h1 = h0 == 2 ? 0 : h0 + 1;
+            const int h2 = h1 == 2 ? 0 : h1 + 1;
             x_load(nk);
-            const double* Xb = Xbuf + buf * SW_KC * XS;
-            const f64x2* A2 = (const f64x2*)(Abuf + buf * SW_TILE);
+            const double* Xb = Xbuf + xb * SW_KC * XS;
             SW_TICK(0);
-            // ---- generate the B operands of the tile's four k-steps:
-            //      k*(candidate cl, x_k), k = kc*16 + 4 kk + kq
             double bfv[NKK];
-            {
+            if (gen) {
+                // ---- generate the B operands of the tile's four k-steps:
+                //      k*(candidate cl, x_k), k = kc*16 + 4 kk + kq
                 // written across the four k-steps so the four dependent fp64 chains
                 // interleave; two partial sums per chain halve its length
                 double s2[NKK], s3[NKK], al[NKK];
@@ -228,11 +324,12 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 for (int kk = 0; kk < NKK; ++kk) { s2[kk] = 0.0; s3[kk] = 0.0; }
 #pragma unroll
                 for (int d = 0; d < DPAD; d += 2) {
+                    const f64x2 tc = *((const f64x2*)Tc + (d >> 1) * SW_THREADS + t);
 #pragma unroll
                     for (int kk = 0; kk < NKK; ++kk) {
                         const double* xr = Xb + (kk * 4 + kq) * XS;
-                        const double df0 = tt[d] - xr[d];
-                        const double df1 = tt[d + 1] - xr[d + 1];
+                        const double df0 = tc.x - xr[d];
+                        const double df1 = tc.y - xr[d + 1];
                         s2[kk] = fma(df0, df0, s2[kk]);
                         s3[kk] = fma(df1, df1, s3[kk]);
                     }
@@ -248,115 +345,130 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 // exponent would perturb every entry by ~|log amp| ulps, which matters
                 // once cond(K) approaches 1/eps)
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) {
-                    bfv[kk] *= a.amp;
-                    mupart = fma(bfv[kk], al[kk], mupart);
-                }
-            }
-            // keep the A-fragment prefetch below the generation phase (register pressure)
-            __builtin_amdgcn_sched_barrier(0);
-            if (TIMING) { asm volatile("" :: "v"(bfv[0]), "v"(bfv[1]), "v"(bfv[2]), "v"(bfv[3])); SW_TICK(1); }
-            // ---- A fragments: per 16-row sub-block, eight ds_read_b128 fetch the
-            //      four rotations x four k-steps (tile layout [s][kp][lane][q]).
-            auto load_a = [&](f64x2 (&dst)[4][2], int sb) {
+                for (int kk = 0; kk < NKK; ++kk) bfv[kk] *= a.amp;
+                if (kc >= nparked) {
+                    // first visit of this chunk: mu = k* . alpha picks it up exactly once
+                    double mupart = Mp[t];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int kp = 0; kp < 2; ++kp) dst[r][kp] = A2[(sb * 2 + kp) * 64 + rot[r]];
-            };
-            if (!DIAG) {
-                // sub-blocks in pairs: 8 independent accumulators per (kk, r) sweep keep
-                // the dependent-accumulate distance at 8 MFMAs; A fragments are
-                // software-pipelined one pair ahead.
-                f64x2 av[2][2][4][2];
-                load_a(av[0][0], 0);
-                load_a(av[0][1], 1);
-#pragma unroll
-                for (int pr = 0; pr < RS / 2; ++pr) {
-                    auto mfma_pair = [&](int kk) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            acc[2 * pr][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
-                                av[pr & 1][0][r][kk >> 1][kk & 1], bfv[kk], acc[2 * pr][r], 0, 0, 0);
-                            acc[2 * pr + 1][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
-                                av[pr & 1][1][r][kk >> 1][kk & 1], bfv[kk], acc[2 * pr + 1][r], 0, 0, 0);
-                        }
-                    };
-                    // The LDS counter saturates at 15: issuing the next pair's 16 reads
-                    // BEFORE this pair's first MFMA would force a wait on fresh reads.
-                    // So: first k-step (its operands landed during the previous pair),
-                    // then the prefetch, then the remaining three k-steps.
-                    mfma_pair(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (pr + 1 < RS / 2) {
-                        load_a(av[(pr + 1) & 1][0], 2 * pr + 2);
-                        load_a(av[(pr + 1) & 1][1], 2 * pr + 3);
+                    for (int kk = 0; kk < NKK; ++kk) mupart = fma(bfv[kk], al[kk], mupart);
+                    Mp[t] = mupart;
+                    if (park && ib + 1 < a.nrb) {      // later row blocks revisit this chunk
+                        const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
+                        f64x2 q0, q1;
+                        q0.x = bfv[0]; q0.y = bfv[1]; q1.x = bfv[2]; q1.y = bfv[3];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_k, toff, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_k, toff,
+                                                               soff + SW_THREADS * 16, 0);
                     }
-                    mfma_pair(1);
-                    mfma_pair(2);
-                    mfma_pair(3);
-                    // staging of the next tile, two instructions per pair:
-                    // pairs 0-3 load half 0, 4-7 store it, 8-11 load half 1, 12-15 store it
-                    if (pr < 4) piece_load(ntile, 0, 2 * pr);
-                    else if (pr < 8) piece_store(buf ^ 1, 0, 2 * (pr - 4));
-                    else if (pr < 12) piece_load(ntile, 1, 2 * (pr - 8));
-                    else piece_store(buf ^ 1, 1, 2 * (pr - 12));
-                    if (pr == RS / 2 - 1) x_store(buf ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
-                // diagonal row block: W is lower triangular, so 16-row sub-blocks above
-                // the chunk's k range are structurally zero, and rows >= N are padding.
-                const int smin = kc - CPB * ib;
-                const int smax = sb_lim - RS * ib;
-                f64x2 av[2][4][2];
-                load_a(av[0], 0);
+                bfv[0] = bpend[0].x; bfv[1] = bpend[0].y;
+                bfv[2] = bpend[1].x; bfv[3] = bpend[1].y;
+            }
+            // the four block-rotations of the B operand (see the instruction note above)
+            double brot[4][NKK];
 #pragma unroll
-                for (int sb = 0; sb < RS; ++sb) {
-                    if (sb + 1 < RS) load_a(av[(sb + 1) & 1], sb + 1);
-                    if (sb >= smin && sb < smax) {
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int kk = 0; kk < NKK; ++kk)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                acc[sb][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
-                                    av[sb & 1][r][kk >> 1][kk & 1], bfv[kk], acc[sb][r], 0, 0, 0);
-                    }
-                    if ((sb & 1) == 1) {
-                        const int pr = sb >> 1;
-                        if (pr < 4) piece_load(ntile, 0, 2 * pr);
-                        else if (pr < 8) piece_store(buf ^ 1, 0, 2 * (pr - 4));
-                        else if (pr < 12) piece_load(ntile, 1, 2 * (pr - 8));
-                        else piece_store(buf ^ 1, 1, 2 * (pr - 12));
-                        if (pr == RS / 2 - 1) x_store(buf ^ 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int kk = 0; kk < NKK; ++kk) brot[r][kk] = rot16(bfv[kk], r);
+            __builtin_amdgcn_sched_barrier(0);
+            if (TIMING) { asm volatile("" :: "v"(bfv[0]), "v"(bfv[1]), "v"(bfv[2]), "v"(bfv[3])); SW_TICK(1); }
+            // pair pr of this tile: park the piece requested 8 pairs ago, request the
+            // one consumed 17 pairs from now (same register), see the ring comment
+            auto stage = [&](int pr) {
+#ifdef SW_X_NOSTAGE
+                return;
+#endif
+                const int j = (pr + 1) & 7;
+                if (pr < 7) {
+                    *lpiece(h1, j) = R[j];
+                    R[j] = gpiece(ntile, 0, j);
+                } else if (pr < 15) {
+                    *lpiece(h2, j) = R[j];
+                    R[j] = gpiece(ntile, 1, j);
+                } else {
+                    *lpiece(h0, 0) = R[0];
+                    R[0] = gpiece(nntile, 0, 0);
                 }
+                if (pr == 5) b_load(nk);
+                if (pr == 9) x_store(xb ^ 1);
+            };
+            // the one barrier per half tile sits after the first k-step of pairs 4 and 12:
+            // no LDS operation of this wavefront is in flight there (the barrier's
+            // lgkmcnt(0) is free) and the matrix pipe still has that k-step queued
+            auto ring_barrier = [&](int pr) {
+#ifdef SW_X_NOBAR
+                return;
+#endif
+                if (pr == 4 || pr == 12) __syncthreads();
+            };
+            auto mfma_pair = [&](int pr, int kk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[2 * pr][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                        av[pr & 1][0][kk >> 1][kk & 1], brot[r][kk], acc[2 * pr][r], 0, 0, 0);
+                    acc[2 * pr + 1][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                        av[pr & 1][1][kk >> 1][kk & 1], brot[r][kk], acc[2 * pr + 1][r], 0, 0, 0);
+                }
+            };
+            // LDS slot / pair index inside the half of pair pr (pr == NP: next tile's first)
+            auto prefetch_a = [&](int pr) {
+#ifdef SW_X_NOLDS
+                return;
+#endif
+                if (pr < 8) load_a(av[pr & 1], h0, pr);
+                else if (pr < NP) load_a(av[pr & 1], h1, pr - 8);
+                else load_a(av[0], h2, 0);
+            };
+            // sub-blocks in pairs: 8 independent accumulators per (kk, r) sweep keep the
+            // dependent-accumulate distance at 8 MFMAs; A fragments are software-pipelined
+            // one pair ahead (across tile boundaries too), requested in two groups of
+            // eight reads (the LDS counter saturates at 15), each right after the k-steps
+            // whose registers it can take over: peak A-fragment footprint 96 VGPRs.
+            // sub-blocks in pairs: 8 independent accumulators per (kk, r) sweep keep the
+            // dependent-accumulate distance at 8 MFMAs; the four ds_read_b128 of the next
+            // pair are requested after the first k-step (one pair ahead, across tile
+            // boundaries too).  Every load is unconditional and there is no branch in the
+            // body, so hipcc's wait counters stay exact.
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                mfma_pair(pr, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ring_barrier(pr);
+                prefetch_a(pr + 1);
+                mfma_pair(pr, 1);
+                mfma_pair(pr, 2);
+                mfma_pair(pr, 3);
+                stage(pr);
+                __builtin_amdgcn_sched_barrier(0);
             }
             SW_TICK(2);
-            SW_TICK(3);
-            __syncthreads();
-            SW_TICK(4);
-            buf ^= 1;
+            h0 = h2;
+            xb ^= 1;
         };
-        // first chunk that needs the predicated path: the diagonal block, or every
-        // chunk when the row block has padded rows (N not a multiple of 512)
-        const int ndiag0 = (sb_lim - RS * ib < RS) ? 0 : CPB * ib;
-        for (; kc < nkc && kc < ndiag0; ++kc) do_tile(std::false_type{});
-        for (; kc < nkc; ++kc) do_tile(std::true_type{});
+        for (; kc < nkc; ++kc) do_tile();
         // row block finished: fold ||V||^2 into the per-candidate sum
+        // (per rotation: the accumulators of rotation r belong to the candidate of the lane
+        // 4r further along the 16-lane row)
 #pragma unroll
-        for (int s = 0; s < RS; ++s)
+        for (int r = 0; r < 4; ++r) {
+            double qr = Qp[r * SW_THREADS + t];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) qpart = fma(acc[s][r], acc[s][r], qpart);
+            for (int s = 0; s < RS; ++s) qr = fma(acc[s][r], acc[s][r], qr);
+            Qp[r * SW_THREADS + t] = qr;
+        }
     }
+    // rotate the partial sums back to their candidates' lanes (inverse rotation: 16 - 4r)
+    double qpart = Qp[t] + rot16(Qp[SW_THREADS + t], 3) + rot16(Qp[2 * SW_THREADS + t], 2) +
+                   rot16(Qp[3 * SW_THREADS + t], 1);
+    double mupart = Mp[t];
+    // recomputed behind an opaque barrier: CSE with the copy above would keep a 64-bit
+    // VGPR alive (= spilled) across the whole tile stream
+    int lane2 = t;
+    asm volatile("" : "+v"(lane2));
+    const long long crow = blk * SW_CAND + (lane2 >> 6) * 16 + (lane2 & 15);
+    const bool adm = (Fl[t] & 1) != 0, has_nan = (Fl[t] & 2) != 0;
 
-    if (TIMING && a.dbg && blockIdx.x == 0 && t == 0) {
-        for (int i = 0; i < 5; ++i) a.dbg[i] = tph[i];
-        long long nt = 0;
-        for (int ib = 0; ib < a.nrb; ++ib) nt += nkc_of(ib);
-        a.dbg[5] = (unsigned long long)nt;
-    }
     // ---- reduce over the four k-quarters / row-quarters of the wavefront ------
     qpart += __shfl_xor(qpart, 16);
     qpart += __shfl_xor(qpart, 32);
@@ -376,21 +488,27 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
             best_merge(bu, bi, uu, a.idx_offset + crow);
         }
     }
-    if (a.kind == APGP_UTIL_NONE) return;
-    // wavefront arg-min, then workgroup arg-min through LDS
+    if (a.kind == APGP_UTIL_NONE) continue;
+    // wavefront arg-min, then workgroup arg-min through LDS (the slots are not
+    // rewritten before the next candidate block's tile barriers have passed)
     for (int o = 8; o > 0; o >>= 1) {
         double ou = __shfl_xor(bu, o);
         long long oi = __shfl_xor(bi, o);
         best_merge(bu, bi, ou, oi);
     }
-    double* red_u = smem;                    // LDS is free again (all tiles consumed)
-    long long* red_i = (long long*)(smem + 8);
     if (lane == 0) { red_u[w] = bu; red_i[w] = bi; }
     __syncthreads();
     if (t == 0) {
         for (int i = 1; i < SW_THREADS / 64; ++i) best_merge(bu, bi, red_u[i], red_i[i]);
-        a.part_u[blockIdx.x] = bu;
-        a.part_i[blockIdx.x] = bi;
+        a.part_u[blk] = bu;
+        a.part_i[blk] = bi;
+    }
+    }   // candidate blocks
+
+    if (TIMING && a.dbg && blockIdx.x == 0 && t == 0) {
+        for (int i = 0; i < 6; ++i) a.dbg[i] = tph[i];
+        a.dbg[6] = ntiles[0];
+        a.dbg[7] = ntiles[1];
     }
 }
 
@@ -418,20 +536,22 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 
 template <int DPAD>
 static int launch_sweep(const SweepArgs& a, hipStream_t s) {
-    const size_t lds = (2 * SW_TILE + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N) * sizeof(double);
+    const size_t lds = (3 * (SW_TILE / 2) + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + 8 + DPAD * SW_THREADS +
+                        5 * SW_THREADS + SW_THREADS / 2 + 3 * APGP_MAX_DIM) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const unsigned nblk = (unsigned)((a.m + SW_CAND - 1) / SW_CAND);
+    const long long ncb = (a.m + SW_CAND - 1) / SW_CAND;
+    const unsigned nblk = (unsigned)(ncb < SW_GRID ? ncb : SW_GRID);
     static int timing = -1;
     if (timing < 0) { const char* e = getenv("APGP_SWEEP_TIMING"); timing = (e && e[0] == '1') ? 1 : 0; }
     if (timing && DPAD == 8) {
         // developer instrumentation: per-phase s_memtime cycles of block 0 / wave 0
         static unsigned long long* dbg = nullptr;
-        if (!dbg) (void)hipMalloc(&dbg, 8 * sizeof(unsigned long long));
+        if (!dbg) (void)hipMalloc(&dbg, 16 * sizeof(unsigned long long));
         SweepArgs b = a;
         b.dbg = dbg;
         (void)hipFuncSetAttribute((const void*)sweep_kernel<8, true>,
@@ -440,12 +560,27 @@ static int launch_sweep(const SweepArgs& a, hipStream_t s) {
         unsigned long long h[8];
         (void)hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
-        fprintf(stderr, "[apgp sweep timing] tiles %llu | per tile cycles: stage %.0f gen %.0f mfma %.0f commit %.0f wait+barrier %.0f\n",
-                h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
+        for (int g = 0; g < 2; ++g) {
+            const double nt = (double)(h[6 + g] ? h[6 + g] : 1);
+            fprintf(stderr, "[apgp sweep timing] %s tiles %llu | per tile cycles: head %.0f gen/fetch %.0f mfma+stage %.0f\n",
+                    g ? "generating" : "parked", h[6 + g], h[3 * g] / nt, h[3 * g + 1] / nt, h[3 * g + 2] / nt);
+        }
         return 0;
     }
     hipLaunchKernelGGL((sweep_kernel<DPAD, false>), dim3(nblk), dim3(SW_THREADS), lds, s, a);
     return 0;
+}
+
+// chunks whose B operands are revisited by a later row block
+static inline long long sweep_ncache(int64_t n) {
+    return (long long)(SW_ROWS / SW_KC) * (apgp_npad(n) / APGP_ROW_BLOCK - 1);
+}
+
+extern "C" int64_t apgp_acquire_work_len(int64_t m, int64_t n) {
+    if (m < 1 || n < 1) return 0;
+    const long long ncb = (m + SW_CAND - 1) / SW_CAND;
+    const long long slots = ncb < SW_GRID ? ncb : SW_GRID;
+    return 2 * ncb + slots * sweep_ncache(n) * SW_BCH;
 }
 
 extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
@@ -456,7 +591,9 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     APGP_CHECK_ARG(T && packed_linv && xs && kern, "null pointer");
     APGP_CHECK_ARG(m >= 1 && n >= 1, "m >= 1 and n >= 1 required");
     APGP_CHECK_ARG(kind >= APGP_UTIL_AGP && kind <= APGP_UTIL_NONE, "unknown utility kind");
-    APGP_CHECK_ARG(kind == APGP_UTIL_NONE || (part && best), "part/best required for an acquisition");
+    APGP_CHECK_ARG(kind == APGP_UTIL_NONE || best, "best required for an acquisition");
+    APGP_CHECK_ARG(part || (kind == APGP_UTIL_NONE && sweep_ncache(n) == 0),
+                   "part (apgp_acquire_work_len doubles) required");
     APGP_CHECK_ARG((lo == NULL) == (hi == NULL), "lo and hi must be given together");
     KernConst kc;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
@@ -466,6 +603,20 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     const long long nblk = (m + SW_CAND - 1) / SW_CAND;
     a.part_u = (double*)part;
     a.part_i = part ? (long long*)((double*)part + nblk) : NULL;
+    a.ncache = (int)sweep_ncache(n);
+    {   // developer A/B switch: APGP_SWEEP_PARK=0 regenerates k* for every row block
+        static int park = -1;
+        if (park < 0) { const char* e = getenv("APGP_SWEEP_PARK"); park = (e && e[0] == '0') ? 0 : 1; }
+        if (!park) a.ncache = 0;
+    }
+    // N <= 512: nothing is parked; the (unconditional, discarded) prefetch then reads the factor
+    a.kcache = a.ncache > 0 ? (double*)part + 2 * nblk : (double*)packed_linv;
+    {
+        const long long wb = apgp_packed_linv_len(n) * 8, xb = apgp_packed_train_len(n, kc.ndim) * 8;
+        const long long kb = a.ncache > 0 ? (long long)a.ncache * SW_BCH * 8 : SW_BCH * 8;
+        APGP_CHECK_ARG(wb < (1ll << 31) && kb < (1ll << 31), "n too large for the sweep's 32-bit stream offsets");
+        a.linv_bytes = (unsigned)wb; a.xs_bytes = (unsigned)xb; a.kslot_bytes = (unsigned)kb;
+    }
     a.m = m; a.idx_offset = idx_offset;
     a.ndim = kc.ndim; a.nrb = (int)(apgp_npad(n) / APGP_ROW_BLOCK); a.kind = kind; a.n = (int)n;
     a.has_box = lo != NULL;

@@ -611,8 +611,8 @@ class GP(object):
             mu = torch.empty(m, dtype=torch.float64, device=dev) if "mu" in want else None
             var = torch.empty(m, dtype=torch.float64, device=dev) if "var" in want else None
             u = torch.empty(m, dtype=torch.float64, device=dev) if "u" in want else None
-            nblk = (m + 3) // 4 if use_solve else (m + 63) // 64
-            part = torch.empty(2 * nblk, dtype=torch.float64, device=dev)
+            nwork = 2 * ((m + 3) // 4) if use_solve else int(lib.apgp_acquire_work_len(m, n))
+            part = torch.empty(max(nwork, 2), dtype=torch.float64, device=dev)
             best = torch.empty(2, dtype=torch.float64, device=dev)
             lo = hi = None
             if bounds is not None:

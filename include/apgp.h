@@ -154,9 +154,13 @@ int apgp_pack_train(const double* X, const double* alpha, int64_t n,
  * and the arg-min over candidates (ties -> lowest index, NaN never wins):
  * the batched counterpart of utility.minimizeObjective (utility.py:253-372).
  * mu / var / u may be NULL (not stored).  lo/hi are host arrays or NULL.
- * part: scratch of 2 * ceil(m/APGP_CAND_BLOCK) doubles (8 B each).
+ * part: scratch of apgp_acquire_work_len(m, n) doubles, 16-byte aligned: the
+ *       per-block arg-min partials plus, for n > APGP_ROW_BLOCK, the stream in
+ *       which each persistent workgroup parks the k* operands it generated for
+ *       one row block so that later row blocks do not regenerate them.
  * best: device apgp_best_t, written by the final reduction kernel.
  * ybest = max(y) and zeta are used by JONES only.                            */
+int64_t apgp_acquire_work_len(int64_t m, int64_t n);
 int apgp_acquire(const double* T, int64_t m, int64_t idx_offset,
                  const double* packed_linv, const double* xs, int64_t n,
                  const apgp_kernel_t* kern /*host*/, double mean, int32_t kind,
