@@ -106,8 +106,9 @@ __device__ __forceinline__ void best_merge(double& bu, long long& bi, double u, 
 // 128 MFMAs; one wavefront per SIMD, everything latency-critical is prefetched.
 template <int DPAD, bool TIMING = false>
 __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tq = 0, ntiles[2] = {0, 0};
-#define SW_TICK(i) do { if (TIMING) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); tph[(gen ? 3 : 0) + i] += n_ - tq; tq = n_; } } while (0)
+    // (compile-time indices only: a runtime-indexed array would live in scratch and drain vmcnt)
+    unsigned long long tp[3] = {0, 0, 0}, tg[3] = {0, 0, 0}, tq = 0, ntp = 0, ntg = 0;
+#define SW_TICK(i) do { if (TIMING) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); tg[i] += gen ? n_ - tq : 0ull; tp[i] += gen ? 0ull : n_ - tq; tq = n_; } } while (0)
     constexpr int XS = DPAD + 2;
     constexpr int RS = SW_ROWS / 16;           // 16-row sub-blocks per tile (32)
     constexpr int NP = RS / 2;                 // sub-block pairs per tile (16)
@@ -148,20 +149,21 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     // A half tile (256 rows x 16 k, 32 KiB) is eight 16-byte "pieces" per thread;
     // piece q holds exactly the sub-block pair q of that half.  The stream is
     // software-pipelined at the granularity of one piece per sub-block pair:
-    // at pair g a thread parks (ds_write_b128) the piece it requested 8 pairs
-    // (~4400 cycles) earlier and re-uses the register for the piece that will
-    // be consumed 17 pairs later.  The half tiles live in a ring of three LDS
-    // slots; a piece is written >= 8 pairs before it is read and >= 15 pairs
-    // after the previous occupant's last read, so ONE barrier every 8 pairs
-    // (placed in the middle of the MFMA stream, where no LDS read waits on it)
-    // covers both hazards and there is no pipeline restart at tile boundaries.
+    // at pair g a thread parks (ds_write_b128) the piece it requested 16 pairs
+    // -- one whole tile, whatever that tile's length -- earlier and re-uses the
+    // register for the piece that will be consumed 25 pairs later.  The half
+    // tiles live in a ring of three LDS slots; a piece is written >= 8 pairs
+    // before it is read and >= 15 pairs after the previous occupant's last
+    // read, so ONE barrier every 8 pairs (placed in the middle of the MFMA
+    // stream, where no LDS read waits on it) covers both hazards and there is
+    // no pipeline restart at tile boundaries.
     // (global_load_lds was measured at ~55 issue cycles per KiB on the issuing
     // wavefront; with one wavefront per SIMD nothing hides that.)
     constexpr int HALF16 = HT / 2;                   // 16-byte pieces per half tile (2048)
     constexpr int NST = HALF16 / SW_THREADS;         // pieces per thread per half (8)
     constexpr int XCHUNK16 = SW_KC * XS / 2;         // 16-byte pieces of the x chunk
     static_assert(NST == 8 && XCHUNK16 <= SW_THREADS, "staging layout");
-    f64x2 R[NST];
+    f64x2 R[2 * NST];
     f64x2 xpend;
     f64x2 bpend[2];
     // All streams go through buffer descriptors (scalar base + scalar offset + one
@@ -235,14 +237,18 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     {
         int ib1 = 0, kc1 = 0;
         successor(ib1, kc1);
+        const long long t1 = tile_index(ib1, kc1);
 #pragma unroll
         for (int q = 0; q < NST; ++q) R[q] = gpiece(0, 0, q);
 #pragma unroll
         for (int q = 0; q < NST; ++q) *lpiece(0, q) = R[q];
         *lpiece(1, 0) = gpiece(0, 1, 0);
+        // what the (virtual) tile before would have requested, see stage()
 #pragma unroll
-        for (int q = 1; q < NST; ++q) R[q] = gpiece(0, 1, q);
-        R[0] = gpiece(tile_index(ib1, kc1), 0, 0);
+        for (int pr = 0; pr < 7; ++pr) R[pr] = gpiece(0, 1, pr + 1);
+#pragma unroll
+        for (int pr = 7; pr < 15; ++pr) R[pr] = gpiece(t1, 0, pr - 7);
+        R[15] = gpiece(t1, 1, 0);
         x_load(0); x_store(0);
         bpend[0] = R[0]; bpend[1] = R[0];
         __syncthreads();
@@ -295,13 +301,14 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
         //    last row block: rows >= N are padding) -- the others skip reads and MFMAs;
         //  * gen: the B operands are generated (first visit of chunk kc, or parking
         //    disabled), otherwise they were prefetched from the slot's scratch stream.
-        auto do_tile = [&]() {
+        auto do_tile = [&](auto pred_tag) {
+            constexpr bool PRED = decltype(pred_tag)::value;
 #ifdef SW_X_NOGEN
             const bool gen = false;
 #else
             const bool gen = !park || kc >= nparked;
 #endif
-            if (TIMING) { tq = __builtin_amdgcn_s_memtime(); ++ntiles[gen ? 1 : 0]; }
+            if (TIMING) { tq = __builtin_amdgcn_s_memtime(); ntg += gen ? 1 : 0; ntp += gen ? 0 : 1; }
             int nib = ib, nk = kc;
             successor(nib, nk);
             const long long ntile = tile_index(nib, nk);
@@ -319,27 +326,39 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 //      k*(candidate cl, x_k), k = kc*16 + 4 kk + kq
                 // written across the four k-steps so the four dependent fp64 chains
                 // interleave; two partial sums per chain halve its length
+                // (all LDS operands of a group of four dimensions are requested before any
+                // is used: left to itself hipcc serialises a dozen read->wait->use trips)
                 double s2[NKK], s3[NKK], al[NKK];
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) { s2[kk] = 0.0; s3[kk] = 0.0; }
+                for (int kk = 0; kk < NKK; ++kk) {
+                    s2[kk] = 0.0; s3[kk] = 0.0;
+                    al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
+                }
+                constexpr int DG = DPAD < 4 ? DPAD : 4;       // dimensions per group
 #pragma unroll
-                for (int d = 0; d < DPAD; d += 2) {
-                    const f64x2 tc = *((const f64x2*)Tc + (d >> 1) * SW_THREADS + t);
+                for (int d0 = 0; d0 < DPAD; d0 += DG) {
+                    f64x2 xa[NKK][DG / 2], tc[DG / 2];
 #pragma unroll
-                    for (int kk = 0; kk < NKK; ++kk) {
-                        const double* xr = Xb + (kk * 4 + kq) * XS;
-                        const double df0 = tc.x - xr[d];
-                        const double df1 = tc.y - xr[d + 1];
-                        s2[kk] = fma(df0, df0, s2[kk]);
-                        s3[kk] = fma(df1, df1, s3[kk]);
+                    for (int h = 0; h < DG / 2; ++h) {
+                        tc[h] = *((const f64x2*)Tc + ((d0 >> 1) + h) * SW_THREADS + t);
+#pragma unroll
+                        for (int kk = 0; kk < NKK; ++kk)
+                            xa[kk][h] = *(const f64x2*)(Xb + (kk * 4 + kq) * XS + d0 + 2 * h);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int h = 0; h < DG / 2; ++h)
+#pragma unroll
+                        for (int kk = 0; kk < NKK; ++kk) {
+                            const double df0 = tc[h].x - xa[kk][h].x;
+                            const double df1 = tc[h].y - xa[kk][h].y;
+                            s2[kk] = fma(df0, df0, s2[kk]);
+                            s3[kk] = fma(df1, df1, s3[kk]);
+                        }
                 }
                 double ex[NKK];
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) {
-                    ex[kk] = -(s2[kk] + s3[kk]);
-                    al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
-                }
+                for (int kk = 0; kk < NKK; ++kk) ex[kk] = -(s2[kk] + s3[kk]);
                 apgp_exp4(ex, bfv, Etab);
                 // the amplitude multiplies the exponential (folding log(amp) into the
                 // exponent would perturb every entry by ~|log amp| ulps, which matters
@@ -373,22 +392,23 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 for (int kk = 0; kk < NKK; ++kk) brot[r][kk] = rot16(bfv[kk], r);
             __builtin_amdgcn_sched_barrier(0);
             if (TIMING) { asm volatile("" :: "v"(bfv[0]), "v"(bfv[1]), "v"(bfv[2]), "v"(bfv[3])); SW_TICK(1); }
-            // pair pr of this tile: park the piece requested 8 pairs ago, request the
-            // one consumed 17 pairs from now (same register), see the ring comment
+            // pair pr of this tile: park the piece requested one tile ago, request the
+            // one consumed 25 pairs from now (same register), see the ring comment
             auto stage = [&](int pr) {
 #ifdef SW_X_NOSTAGE
                 return;
 #endif
-                const int j = (pr + 1) & 7;
+                // park: pairs 9..15 of this tile, then 0..8 of the next one;
+                // request: the same pairs one tile further on
                 if (pr < 7) {
-                    *lpiece(h1, j) = R[j];
-                    R[j] = gpiece(ntile, 0, j);
+                    *lpiece(h1, pr + 1) = R[pr];
+                    R[pr] = gpiece(ntile, 1, pr + 1);
                 } else if (pr < 15) {
-                    *lpiece(h2, j) = R[j];
-                    R[j] = gpiece(ntile, 1, j);
+                    *lpiece(h2, pr - 7) = R[pr];
+                    R[pr] = gpiece(nntile, 0, pr - 7);
                 } else {
-                    *lpiece(h0, 0) = R[0];
-                    R[0] = gpiece(nntile, 0, 0);
+                    *lpiece(h0, 0) = R[15];
+                    R[15] = gpiece(nntile, 1, 0);
                 }
                 if (pr == 5) b_load(nk);
                 if (pr == 9) x_store(xb ^ 1);
@@ -421,24 +441,28 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 else load_a(av[0], h2, 0);
             };
             // sub-blocks in pairs: 8 independent accumulators per (kk, r) sweep keep the
-            // dependent-accumulate distance at 8 MFMAs; A fragments are software-pipelined
-            // one pair ahead (across tile boundaries too), requested in two groups of
-            // eight reads (the LDS counter saturates at 15), each right after the k-steps
-            // whose registers it can take over: peak A-fragment footprint 96 VGPRs.
-            // sub-blocks in pairs: 8 independent accumulators per (kk, r) sweep keep the
             // dependent-accumulate distance at 8 MFMAs; the four ds_read_b128 of the next
             // pair are requested after the first k-step (one pair ahead, across tile
-            // boundaries too).  Every load is unconditional and there is no branch in the
-            // body, so hipcc's wait counters stay exact.
+            // boundaries too).
+            // W is lower triangular: in the diagonal block, chunk kc only reaches rows
+            // >= 16 (kc - nparked), i.e. sub-block pairs >= p0.  The structurally-zero
+            // pairs skip their 32 MFMAs (uniform branch) but nothing else: every LDS read,
+            // staging step and barrier stays unconditional, so no memory operation sits
+            // under a branch and hipcc's wait counters stay exact.
+            int p0 = (kc - nparked) >> 1;
+            if (p0 < 0) p0 = 0;
 #pragma unroll
             for (int pr = 0; pr < NP; ++pr) {
-                mfma_pair(pr, 0);
+                const bool act = !PRED || pr >= p0;
+                if (act) mfma_pair(pr, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 ring_barrier(pr);
                 prefetch_a(pr + 1);
-                mfma_pair(pr, 1);
-                mfma_pair(pr, 2);
-                mfma_pair(pr, 3);
+                if (act) {
+                    mfma_pair(pr, 1);
+                    mfma_pair(pr, 2);
+                    mfma_pair(pr, 3);
+                }
                 stage(pr);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -446,7 +470,11 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
             h0 = h2;
             xb ^= 1;
         };
-        for (; kc < nkc; ++kc) do_tile();
+        // two copies of the body: the diagonal block's skips its structurally-zero pairs
+        // (two uniform branches per pair, ~18 cycles each in an MFMA stream), the other
+        // one is branch-free
+        for (; kc < nparked; ++kc) do_tile(std::false_type{});
+        for (; kc < nkc; ++kc) do_tile(std::true_type{});
         // row block finished: fold ||V||^2 into the per-candidate sum
         // (per rotation: the accumulators of rotation r belong to the candidate of the lane
         // 4r further along the 16-lane row)
@@ -506,9 +534,9 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     }   // candidate blocks
 
     if (TIMING && a.dbg && blockIdx.x == 0 && t == 0) {
-        for (int i = 0; i < 6; ++i) a.dbg[i] = tph[i];
-        a.dbg[6] = ntiles[0];
-        a.dbg[7] = ntiles[1];
+        for (int i = 0; i < 3; ++i) { a.dbg[i] = tp[i]; a.dbg[3 + i] = tg[i]; }
+        a.dbg[6] = ntp;
+        a.dbg[7] = ntg;
     }
 }
 
