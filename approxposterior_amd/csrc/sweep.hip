@@ -38,6 +38,12 @@
 #define SW_GRID 256                  // persistent workgroups = K* scratch slots (one per CU)
 #define SW_BCH (SW_THREADS * 4)      // doubles of parked B operands per chunk per slot
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// cache policy of the parked-operand stream: each workgroup slot is written once and read
+// back once per later row block, 256 slots x 2 MB never fit the L2 -- marked non-temporal
+// (aux bit 1 = nt).  Measured neutral at C3 (L2 hit rate and kernel time unchanged).
+#ifndef SW_KAUX
+#define SW_KAUX 2
+#endif
 
 struct SweepArgs {
     const double* T;
@@ -198,8 +204,8 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     const bool park = a.ncache > 0;
     auto b_load = [&](int c) {
         const unsigned soff = (unsigned)(c < cmax ? c : cmax) * (unsigned)(SW_BCH * 8);
-        bpend[0] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, toff, soff, 0));
-        bpend[1] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, toff, soff + SW_THREADS * 16, 0));
+        bpend[0] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, toff, soff, SW_KAUX));
+        bpend[1] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, toff, soff + SW_THREADS * 16, SW_KAUX));
     };
 
     // tile sequence: row block ib, chunks kc = 0 .. min((ib+1)*CPB, kc_lim) - 1, then
@@ -375,23 +381,24 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                         const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
                         f64x2 q0, q1;
                         q0.x = bfv[0]; q0.y = bfv[1]; q1.x = bfv[2]; q1.y = bfv[3];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_k, toff, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_k, toff, soff, SW_KAUX);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_k, toff,
-                                                               soff + SW_THREADS * 16, 0);
+                                                               soff + SW_THREADS * 16, SW_KAUX);
                     }
                 }
             } else {
                 bfv[0] = bpend[0].x; bfv[1] = bpend[0].y;
                 bfv[2] = bpend[1].x; bfv[3] = bpend[1].y;
             }
-            // the four block-rotations of the B operand (see the instruction note above)
+            // the four block-rotations of the B operand (see the instruction note above);
+            // (moving these DPP moves under the previous tile's MFMAs was measured: zero-sum)
             double brot[4][NKK];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) brot[r][kk] = rot16(bfv[kk], r);
             __builtin_amdgcn_sched_barrier(0);
-            if (TIMING) { asm volatile("" :: "v"(bfv[0]), "v"(bfv[1]), "v"(bfv[2]), "v"(bfv[3])); SW_TICK(1); }
+            if (TIMING) { asm volatile("" :: "v"(brot[0][0]), "v"(brot[0][1]), "v"(brot[0][2]), "v"(brot[0][3])); SW_TICK(1); }
             // pair pr of this tile: park the piece requested one tile ago, request the
             // one consumed 25 pairs from now (same register), see the ring comment
             auto stage = [&](int pr) {
@@ -411,6 +418,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                     R[15] = gpiece(nntile, 1, 0);
                 }
                 if (pr == 5) b_load(nk);
+
                 if (pr == 9) x_store(xb ^ 1);
             };
             // the one barrier per half tile sits after the first k-step of pairs 4 and 12:
@@ -451,9 +459,12 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
             // under a branch and hipcc's wait counters stay exact.
             int p0 = (kc - nparked) >> 1;
             if (p0 < 0) p0 = 0;
+            // ... and in the last row block rows >= N are padding: pairs >= p1 are zero too
+            int p1 = (a.n - SW_ROWS * ib + 31) >> 5;
+            if (p1 > NP) p1 = NP;
 #pragma unroll
             for (int pr = 0; pr < NP; ++pr) {
-                const bool act = !PRED || pr >= p0;
+                const bool act = !PRED || (pr >= p0 && pr < p1);
                 if (act) mfma_pair(pr, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 ring_barrier(pr);
@@ -470,10 +481,12 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
             h0 = h2;
             xb ^= 1;
         };
-        // two copies of the body: the diagonal block's skips its structurally-zero pairs
+        // two copies of the body: the one for the diagonal block (and for a last row block
+        // with padded rows) skips its structurally-zero pairs
         // (two uniform branches per pair, ~18 cycles each in an MFMA stream), the other
         // one is branch-free
-        for (; kc < nparked; ++kc) do_tile(std::false_type{});
+        const int nstraight = (a.n - SW_ROWS * ib >= SW_ROWS) ? nparked : 0;
+        for (; kc < nstraight; ++kc) do_tile(std::false_type{});
         for (; kc < nkc; ++kc) do_tile(std::true_type{});
         // row block finished: fold ||V||^2 into the per-candidate sum
         // (per rotation: the accumulators of rotation r belong to the candidate of the lane
