@@ -7,10 +7,12 @@
 //
 // Data flow per workgroup (256 threads = 4 wavefronts, one per SIMD, 64 candidates):
 //   * wavefront w owns candidates [16 w, 16 w + 16) (one MFMA column block);
-//     the scaled candidate coordinates live in registers for the whole kernel.
+//     the scaled candidate coordinates are parked in LDS (only generating
+//     tiles need them).
 //   * the packed factor W = L^-1 is streamed tile by tile (512 rows x 16 k,
-//     64 KiB, A-fragment order) L2/MALL -> registers -> LDS, double buffered,
-//     shared by the four wavefronts (one barrier per tile).
+//     64 KiB, A-fragment order) L2/MALL -> registers -> LDS (ring of three
+//     half-tile slots, one 16-byte piece per thread per sub-block pair, one
+//     barrier per half tile), shared by the four wavefronts.
 //   * each lane generates the k*(t_m, x_k) value it must feed as the MFMA B
 //     operand (lane -> candidate lane&15, k lane>>4) on the VALU (D sub + D fma
 //     + table-driven exp) the FIRST time chunk k is visited (the diagonal row
@@ -100,12 +102,15 @@ __device__ __forceinline__ void best_merge(double& bu, long long& bi, double u, 
 //   v_fma_f64 (VALU)           64-70 TF, and MFMA + VALU f64 do NOT overlap: they
 //                              share the DP pipes (sum stays ~70 TF for any mix).
 // So the contraction uses the 4x4x4 four-block instruction.  Its blocks are
-// independent (CBSZ/ABID broadcast is ignored for f64 on gfx950), so a
-// 16 x 16 x 4 product takes four instructions whose A operand is the same
-// 16 x 4 fragment with its 4-row groups rotated across the blocks:
+// independent (CBSZ/ABID broadcast is ignored for f64 on gfx950):
 //   A lane = i + 4 b + 16 k,  B lane = j + 4 b + 16 k,  D lane = j + 4 b + 16 i.
-// The candidate of a lane is lane & 15 for every rotation, which is all the
-// variance reduction needs (sum over rows of V^2).
+// A 16 x 16 x 4 product is four instructions with the SAME A fragment and the B
+// operand rotated by 4 r lanes inside each row of 16 lanes (DPP row_ror): block b
+// then multiplies row group b with candidate group (b + r) mod 4.  The candidate
+// of an accumulator depends on r, which the variance reduction (sum over rows of
+// V^2 per candidate) undoes once per row block with the inverse rotation.
+// (Rotating the A fragment instead keeps lane <-> candidate fixed but needs four
+// times the LDS reads and A registers: it ran the LDS at 73 % of its bandwidth.)
 // Because K* generation costs DP cycles too, each generated value must feed as
 // many rows as possible: a wavefront owns 512 rows x 16 candidates (128 f64
 // accumulators per lane = the whole AGPR file), so one generated B value feeds
