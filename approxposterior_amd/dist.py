@@ -19,7 +19,7 @@ Nelder-Mead, utility.py:253-372); this is the multi-GPU form of
 
 import numpy as np
 
-__all__ = ["shard_bounds", "combine_best", "sharded_acquire"]
+__all__ = ["shard_bounds", "combine_best", "sharded_acquire", "replicated_ensembles"]
 
 
 def shard_bounds(m, world_size, rank):
@@ -71,3 +71,42 @@ def sharded_acquire(local_acquire, idx_offset, group=None, device=None):
         h = g.cpu().numpy()
         pairs.append((float(h[0]), int(h[1:2].view(np.int64)[0])))
     return combine_best(pairs)
+
+
+def replicated_ensembles(local_sample, seed=0, group=None, device=None):
+    """MCMC over the GP surrogate on several GPUs: *replicas only* (SURVEY.md
+    section 8e, row "MCMC _gpll").  A stretch-move step couples all walkers of an
+    ensemble, so an ensemble does not shard; instead every rank runs its own
+    independent ensemble(s) with a rank-specific seed --
+    ``local_sample(seed + rank) -> (chain (iterations, W, D), log_prob (iterations, W))``,
+    typically ``lambda s: (lambda r: (r["chain"], r["log_prob"]))(gp.sample_ensemble(y, p0, iters,
+    bounds, seed=s))`` -- and the chains are concatenated along the walker axis with
+    ONE all-gather at the end (no collective inside the sampling loop).
+    Returns (chain (iterations, world*W, D), log_prob (iterations, world*W)) on every rank.
+    """
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if distributed else 0
+    chain, logp = local_sample(int(seed) + rank)
+    chain = np.ascontiguousarray(chain, dtype=np.float64)
+    logp = np.ascontiguousarray(logp, dtype=np.float64)
+    if chain.ndim != 3 or logp.shape != chain.shape[:2]:
+        raise ValueError("local_sample must return chain (iterations, W, D) and log_prob (iterations, W)")
+    if not distributed:
+        return chain, logp
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) \
+            if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    world = dist.get_world_size(group)
+    # one record per rank: [chain | log_prob] flattened (same shape on every rank)
+    mine = torch.from_numpy(np.concatenate([chain.ravel(), logp.ravel()])).to(device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    chains, logps = [], []
+    for g in gathered:
+        h = g.cpu().numpy()
+        chains.append(h[:chain.size].reshape(chain.shape))
+        logps.append(h[chain.size:].reshape(logp.shape))
+    return np.concatenate(chains, axis=1), np.concatenate(logps, axis=1)

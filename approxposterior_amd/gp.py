@@ -597,6 +597,11 @@ class GP(object):
             self._ensure_xs(y)
             T = cand_device if cand_device is not None else torch.from_numpy(cand).to(dev)
             m = T.shape[0]
+            if m == 0:
+                # empty candidate set: nothing admissible (index -1, +inf), empty arrays
+                empty = {"best": (-1, float("inf")), "mu": (np.empty(0),), "var": (np.empty(0),),
+                         "u": (np.empty(0),)}
+                return tuple(v for w_ in want for v in empty[w_])
             if not need_var:
                 mu = torch.empty(m, dtype=torch.float64, device=dev)
                 _lib.check(lib.apgp_predict_mean(T.data_ptr(), m, self._xs.data_ptr(), n,

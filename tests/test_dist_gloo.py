@@ -80,3 +80,44 @@ def test_sharded_acquire_world2_gloo(tmp_path, case):
     for r in range(2):
         got = np.load(out % r)
         assert int(got[0]) == want[0] and got[1] == want[1]
+
+
+def _replica_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from approxposterior_amd.dist import replicated_ensembles
+
+    def local(seed):          # stand-in for gp.sample_ensemble: the chain depends on the seed only
+        rs = np.random.RandomState(seed)
+        return rs.normal(size=(7, 4, 3)), rs.normal(size=(7, 4))
+
+    chain, logp = replicated_ensembles(local, seed=100)
+    np.savez(out_path % rank, chain=chain, logp=logp)
+    dist.destroy_process_group()
+
+
+def test_replicated_ensembles_world2_gloo(tmp_path):
+    """the MCMC does not shard per step; ranks run independent ensembles
+    (rank-specific seeds) and gather the chains once at the end."""
+    from approxposterior_amd.dist import replicated_ensembles
+    port = _free_port()
+    out = str(tmp_path / "c%d.npz")
+    mp.spawn(_replica_worker, args=(2, port, out), nprocs=2, join=True)
+    want_chain, want_logp = [], []
+    for r in range(2):
+        rs = np.random.RandomState(100 + r)
+        want_chain.append(rs.normal(size=(7, 4, 3)))
+        want_logp.append(rs.normal(size=(7, 4)))
+    want_chain = np.concatenate(want_chain, axis=1)
+    want_logp = np.concatenate(want_logp, axis=1)
+    for r in range(2):
+        got = np.load(out % r)
+        assert got["chain"].shape == (7, 8, 3)
+        assert np.array_equal(got["chain"], want_chain) and np.array_equal(got["logp"], want_logp)
+    # without a process group: the local ensemble, unchanged
+    c, l = replicated_ensembles(lambda s: (np.ones((2, 4, 3)) * s, np.zeros((2, 4))), seed=5)
+    assert c.shape == (2, 4, 3) and np.all(c == 5)
+    with pytest.raises(ValueError):
+        replicated_ensembles(lambda s: (np.ones((2, 4)), np.zeros((2, 4))))

@@ -288,6 +288,23 @@ def test_full_size_properties(lib_loaded):
     # device-resident candidates give the same answer as host candidates
     T = torch.from_numpy(cands).cuda()
     assert gp.acquire(y, T, "agp", bounds=[(-5, 5)] * D) == (bi, bu)
+    # (d) BASELINE.json's full candidate count (1e6: 62 rounds of the persistent grid, every
+    #     workgroup slot's parked-operand stream re-used): the result for a candidate does not
+    #     depend on which block / round / slot evaluated it (to rounding: the order in which
+    #     the four row-group partial sums of sigma^2 are added depends on the candidate's lane)
+    M1 = 1000000
+    big = rs.uniform(-5.0, 5.0, size=(M1, D))
+    Tb = torch.from_numpy(big).cuda()
+    fbi, fbu, fu, fmu, fvar = gp.acquire(y, Tb, "agp", bounds=[(-5, 5)] * D, return_all=True)
+    assert fbi == int(np.argmin(fu)) and fbu == fu[fbi] and np.isfinite(fu).all()
+    pick = np.sort(rs.choice(M1, size=5000, replace=False))
+    sbi, sbu, su, smu, svar = gp.acquire(y, big[pick], "agp", bounds=[(-5, 5)] * D, return_all=True)
+    assert np.array_equal(smu, fmu[pick])
+    assert np.abs(svar - fvar[pick]).max() <= 1e-13 and np.abs(su - fu[pick]).max() <= 1e-11 * np.abs(fu).max()
+    # (e) an empty candidate set: nothing admissible
+    assert gp.acquire(y, np.empty((0, D)), "agp") == (-1, np.inf)
+    emu, evar = gp.predict(y, np.empty((0, D)), return_var=True)
+    assert emu.shape == (0,) and evar.shape == (0,)
 
 
 def test_error_behaviour(lib_loaded):
