@@ -4,15 +4,28 @@
 // gpUtils.py:178; approx.py:717).  rocSOLVER's dpotrf reaches ~2 TFLOP/s at
 // N = 4096 on MI355X (11.8 ms, dozens of tiny kernels); this version is two
 // launches per 64-column block step:
-//   panel : every workgroup re-factorises the 64x64 diagonal block in LDS
-//           (redundantly -- it is the critical path either way, and it saves a
-//           launch + a grid-wide dependency), then solves its 256 rows of the
-//           panel against it (row-parallel forward substitution);
+//   panel : every workgroup (one wavefront) re-factorises the 64x64 diagonal
+//           block in registers (redundantly -- it is the critical path either
+//           way, and it saves a launch + a grid-wide dependency), then solves
+//           its 64 rows of the panel against it (row-per-lane substitution);
 //   update: trailing lower-triangle tiles A_ik -= L_ij L_kj^T (64x64x64 MFMA
 //           f64 tiles; HBM-bound: each tile is read-modify-written once).
 // info follows LAPACK: 0 = OK, k > 0 = leading minor of order k not positive
 // definite (first failing pivot).
 #include "apgp_common.h"
+#include <type_traits>
+#include <utility>
+
+// compile-time loop: the body sees its index as a constant expression, so the register
+// arrays below are indexed statically whatever hipcc's unroll heuristics decide
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 #define PB 64
 
@@ -25,93 +38,182 @@ struct PotrfArgs {
     int* info;
 };
 
-// factorise the 64x64 block held in LDS (S[64][65]); 256 threads
-__device__ __forceinline__ void potf2_lds(double (*S)[PB + 1], double* invd, int bs, long long j0, int* info,
-                                          bool reporter) {
-    const int t = threadIdx.x;
-    for (int k = 0; k < bs; ++k) {
-        const double piv = S[k][k];
-        // every thread reads the same pivot: uniform decision, no extra barrier
-        const bool bad = !(piv > 0.0) || !(piv < INFINITY);
-        const double d = bad ? 1.0 : sqrt(piv);
-        const double inv = 1.0 / d;
-        if (bad && reporter && t == 0) atomicMin((unsigned int*)info, (unsigned int)(j0 + k + 1));
-        __syncthreads();
-        if (t == 0) { S[k][k] = d; invd[k] = inv; }
-        if (t > k && t < bs) S[t][k] *= inv;
-        __syncthreads();
-        // trailing update of the lower triangle: (i, j) with k < j <= i < bs;
-        // 16 x 16 thread grid striding both indices (no integer division)
-        for (int i = k + 1 + (t >> 4); i < bs; i += 16) {
-            const double lik = S[i][k];
-            for (int j = k + 1 + (t & 15); j <= i; j += 16) S[i][j] = fma(-lik, S[j][k], S[i][j]);
-        }
-        __syncthreads();
-    }
-}
-
-// panel kernel: blockIdx.x = 0 also writes the diagonal factor back.
-// Workgroup b >= 0 owns panel rows [j0 + 64 + 256 b, +256).
-__global__ __launch_bounds__(256) void potrf_panel_kernel(PotrfArgs a) {
-    __shared__ double S[PB][PB + 1];
-    __shared__ double invd[PB];
+// Panel step, one wavefront per workgroup: workgroup b owns the 64 panel rows
+// [j0 + 64 + 64 b, +64) and re-factorises the 64x64 diagonal block itself (it is the
+// critical path either way; redundancy saves a launch and a grid-wide dependency).
+//
+// The diagonal block is factorised in REGISTERS: lane i holds row i (64 doubles),
+// right-looking, fully unrolled.  Per pivot k: the pivot is a v_readlane, its
+// reciprocal square root a v_rsq_f64 + two Newton steps (no IEEE sqrt + divide on the
+// critical path), the scaled column goes through a 512-byte LDS line and comes back as
+// broadcast ds_read_b128 for the rank-1 update.  One wavefront, in-order LDS: no barrier
+// anywhere.  ~1650 cycles per pivot with the earlier 256-thread LDS version (three
+// barriers + IEEE sqrt/div per pivot), ~250 here.
+// The panel rows are then solved one row per lane, x L_jj^T = a, against broadcast
+// reads of L_jj (four partial sums per dot product).
+// scheduling fence for the straight-line panel code: the asm memory clobber stops the
+// SelectionDAG from hoisting the (address-independent) LDS reads of later steps, the
+// sched_barrier stops the machine scheduler -- without both, hundreds of reads are in
+// flight at once and the two 64-double register rows spill
+#define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+__global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
+    __shared__ __attribute__((aligned(16))) double col[2][PB];
+    __shared__ __attribute__((aligned(16))) double Ls[PB][PB];
+    __shared__ __attribute__((aligned(16))) double invd[PB];
     __shared__ double zblk[PB];
-    const int t = threadIdx.x;
-    if (t < PB) invd[t] = 1.0;
+    __shared__ double Xs[PB][PB + 1];
+    const int lane = threadIdx.x;
     const long long j0 = a.j0;
     const int bs = (int)((a.n - j0) < PB ? (a.n - j0) : PB);
-    for (int e = t; e < PB * PB; e += 256) {
-        const int i = e >> 6, k = e & 63;
-        double v = (i == k) ? 1.0 : 0.0;
-        if (i < bs && k <= i) v = a.A[(j0 + i) * a.lda + j0 + k];
-        S[i][k] = v;
-    }
-    __syncthreads();
-    potf2_lds(S, invd, bs, j0, a.info, blockIdx.x == 0);
-    if (blockIdx.x == 0) {
-        for (int e = t; e < PB * PB; e += 256) {
-            const int i = e >> 6, k = e & 63;
-            if (i < bs && k <= i) a.A[(j0 + i) * a.lda + j0 + k] = S[i][k];
-        }
-    }
-    // fused forward solve z = L^-1 (rhs): every workgroup solves the 64-block of
-    // the right-hand side against the fresh diagonal factor (wavefront 0, shuffle
-    // forward substitution), then each panel row subtracts its share below.
-    if (a.rhs) {
-        if (t < 64) {
-            double ri = (t < bs) ? a.rhs[j0 + t] : 0.0;
-            for (int k = 0; k < bs; ++k) {
-                const double zk = __shfl(ri, k) * invd[k];
-                if (t == k) ri = zk;
-                else if (t > k) ri = fma(-S[t][k], zk, ri);
-            }
-            zblk[t] = ri;
-            if (blockIdx.x == 0 && t < bs) a.rhs[j0 + t] = ri;
-        }
-        __syncthreads();
-    }
-    // rows of the panel below the diagonal block: x L_jj^T = a  (row-wise forward substitution)
-    const long long row = j0 + PB + (long long)blockIdx.x * 256 + t;
-    if (row < a.n) {
-        double* ap = a.A + row * a.lda + j0;
-        double x[PB];
+    const long long row = j0 + PB + (long long)blockIdx.x * PB + lane;
+    const bool has_row = row < a.n;
+
+    // row `lane` of the diagonal block (identity past the matrix edge / above the diagonal);
+    // one base address + immediate offsets (a per-element clamp costs a 64-bit address each)
+    double ar[PB];
+    if (bs == PB) {
+        const double* src = a.A + (j0 + lane) * a.lda + j0;
 #pragma unroll
-        for (int k = 0; k < PB; ++k) x[k] = ap[k];
+        for (int k = 0; k < PB; ++k) ar[k] = src[k];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) ar[k] = k <= lane ? ar[k] : 0.0;
+    } else {
+        const double* src = a.A + (j0 + (lane < bs ? lane : 0)) * a.lda + j0;
 #pragma unroll
         for (int k = 0; k < PB; ++k) {
-            // four partial sums: the dependent-FMA chain is the cost here
-            double s0 = x[k], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int m = 0; m + 3 < k; m += 4) {
-                s0 = fma(-x[m], S[k][m], s0);
-                s1 = fma(-x[m + 1], S[k][m + 1], s1);
-                s2 = fma(-x[m + 2], S[k][m + 2], s2);
-                s3 = fma(-x[m + 3], S[k][m + 3], s3);
-            }
-#pragma unroll
-            for (int m = k & ~3; m < k; ++m) s0 = fma(-x[m], S[k][m], s0);
-            x[k] = ((s0 + s1) + (s2 + s3)) * invd[k];
+            double v = 0.0;
+            if (lane < bs && k <= lane) v = src[k];
+            ar[k] = (lane < bs && k <= lane) ? v : (k == lane ? 1.0 : 0.0);
         }
+    }
+    // this lane's panel row rides along: requested now, parked in LDS while the
+    // factorisation has the VGPRs (two 64-double register rows do not fit the 256
+    // VALU-addressable registers); panel rows exist only below a full 64-column block
+    {
+        const double* src = a.A + (has_row ? row : j0) * a.lda + j0;
+        double xin[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) xin[k] = bs == PB ? src[k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) Xs[lane][k] = xin[k];
+    }
+    PANEL_FENCE();
+
+    static_for<PB>([&](auto kc_) {
+        constexpr int k = decltype(kc_)::value;
+        const double piv = __shfl(ar[k], k);
+        const bool bad = !(piv > 0.0) || !(piv < INFINITY);
+        if (bad && blockIdx.x == 0 && lane == 0) atomicMin((unsigned int*)a.info, (unsigned int)(j0 + k + 1));
+        const double pv = bad ? 1.0 : piv;
+        // 1/sqrt(pv): hardware estimate + two Newton steps, then one residual correction of
+        // the root itself (d = sqrt(pv) to within an ulp; LAPACK's own roots differ by as much
+        // between libraries)
+        double r = __builtin_amdgcn_rsq(pv);
+        r = r * fma(-0.5 * pv * r, r, 1.5);
+        r = r * fma(-0.5 * pv * r, r, 1.5);
+        double d = pv * r;
+        d = fma(0.5 * r, fma(-d, d, pv), d);
+        const double inv = r;
+        if (lane == k) { ar[k] = d; invd[k] = inv; }
+        else ar[k] *= inv;                       // lanes > k: L_ik (lanes < k: unused upper part)
+        double* cb = col[k & 1];
+        cb[lane] = ar[k];
+        // rank-1 update of the trailing columns: ar[j] -= L_ik * L_jk  (L_jk broadcast from LDS)
+        const double lik = ar[k];
+        if (((k + 1) & 1) && k + 1 < PB) {       // odd start: one 8-byte read, then aligned pairs
+            const double ljk = cb[k + 1];
+            ar[k + 1] = fma(-lik, ljk, ar[k + 1]);
+            asm volatile("" : "+v"(ar[k + 1]));
+        }
+        // (groups of 16 columns, fenced: hipcc would otherwise request the whole column --
+        // and the columns of later pivots -- at once and spill the register rows)
+#pragma unroll
+        for (int j0g = (k + 2) & ~1; j0g + 1 < PB; j0g += 16) {
+            f64x2 l2[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (j0g + 2 * g + 1 < PB) l2[g] = *(const f64x2*)(cb + j0g + 2 * g);
+            PANEL_FENCE();
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (j0g + 2 * g + 1 < PB) {
+                    ar[j0g + 2 * g] = fma(-lik, l2[g].x, ar[j0g + 2 * g]);
+                    ar[j0g + 2 * g + 1] = fma(-lik, l2[g].y, ar[j0g + 2 * g + 1]);
+                    // pin the update here: left alone, hipcc sinks every column's updates
+                    // down to that column's own pivot (a left-looking order that keeps all
+                    // 2016 broadcast values alive -- in scratch)
+                    asm volatile("" : "+v"(ar[j0g + 2 * g]), "+v"(ar[j0g + 2 * g + 1]));
+                }
+            PANEL_FENCE();
+        }
+    });
+    // L_jj rows to LDS for the broadcast reads below (zeros above the diagonal)
+#pragma unroll
+    for (int k = 0; k < PB; k += 2) {
+        f64x2 v;
+        v.x = k <= lane ? ar[k] : 0.0;
+        v.y = k + 1 <= lane ? ar[k + 1] : 0.0;
+        *(f64x2*)(&Ls[lane][k]) = v;
+    }
+    if (blockIdx.x == 0 && lane < bs) {
+        double* dst = a.A + (j0 + lane) * a.lda + j0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+            if (k <= lane) dst[k] = ar[k];
+    }
+    // fused forward solve z = L^-1 (rhs): the 64-block of the right-hand side against the
+    // fresh diagonal factor (shuffle forward substitution), then each panel row subtracts
+    // its share below.
+    if (a.rhs) {
+        double ri = (lane < bs) ? a.rhs[j0 + lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) {
+            const double zk = __shfl(ri, k) * invd[k];
+            if (lane == k) ri = zk;
+            else if (lane > k) ri = fma(-ar[k], zk, ri);
+        }
+        zblk[lane] = ri;
+        if (blockIdx.x == 0 && lane < bs) a.rhs[j0 + lane] = ri;
+    }
+    // rows of the panel below the diagonal block: x L_jj^T = a  (row-wise forward substitution)
+    PANEL_FENCE();
+    double x[PB];
+#pragma unroll
+    for (int k = 0; k < PB; ++k) x[k] = Xs[lane][k];
+    PANEL_FENCE();
+    static_for<PB>([&](auto kc_) {
+        constexpr int k = decltype(kc_)::value;
+        // four partial sums: the dependent-FMA chain is the cost here
+        double s0 = x[k], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int m0 = 0; m0 + 3 < k; m0 += 16) {
+            f64x2 lq[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (m0 + 2 * g + 1 < (k & ~3)) lq[g] = *(const f64x2*)(&Ls[k][m0 + 2 * g]);
+            PANEL_FENCE();
+#pragma unroll
+            for (int g = 0; g < 8; g += 2)
+                if (m0 + 2 * g + 3 < k) {
+                    const int m = m0 + 2 * g;
+                    s0 = fma(-x[m], lq[g].x, s0);
+                    s1 = fma(-x[m + 1], lq[g].y, s1);
+                    s2 = fma(-x[m + 2], lq[g + 1].x, s2);
+                    s3 = fma(-x[m + 3], lq[g + 1].y, s3);
+                }
+            asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));   // pin (see above)
+            PANEL_FENCE();
+        }
+#pragma unroll
+        for (int m = k & ~3; m < k; ++m) s0 = fma(-x[m], Ls[k][m], s0);
+        x[k] = ((s0 + s1) + (s2 + s3)) * invd[k];
+        asm volatile("" : "+v"(x[k]));
+        // keep hipcc from hoisting the (address-independent) LDS reads of later k's up
+        // here: hundreds of them in flight spill the two 64-double register rows
+        PANEL_FENCE();
+    });
+    if (has_row) {
+        double* ap = a.A + row * a.lda + j0;
 #pragma unroll
         for (int k = 0; k < PB; ++k) ap[k] = x[k];
         if (a.rhs) {
@@ -204,8 +306,8 @@ extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, do
     for (long long jb = 0; jb < nb; ++jb) {
         a.j0 = jb * PB;
         const long long below = n - (a.j0 + PB);
-        const unsigned pg = below > 0 ? (unsigned)((below + 255) / 256) : 1u;
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg), dim3(256), 0, s, a);
+        const unsigned pg = below > 0 ? (unsigned)((below + PB - 1) / PB) : 1u;
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg), dim3(PB), 0, s, a);
         if (below > 0) {
             const long long tb = (below + PB - 1) / PB;
             hipLaunchKernelGGL(potrf_update_kernel, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, s, a);
