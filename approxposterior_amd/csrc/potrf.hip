@@ -55,10 +55,30 @@ struct PotrfArgs {
 // SelectionDAG from hoisting the (address-independent) LDS reads of later steps, the
 // sched_barrier stops the machine scheduler -- without both, hundreds of reads are in
 // flight at once and the two 64-double register rows spill
+#ifdef APGP_PANEL_TIMING
+__device__ unsigned long long apgp_panel_stamps[8];
+#define PANEL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) apgp_panel_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PANEL_STAMP(i) do { } while (0)
+#endif
+// broadcast of lane `src` (compile-time constant): two v_readlane_b32 (a few cycles) --
+// __shfl with a constant lane still goes through ds_bpermute (an LDS round trip)
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// staging of the panel solve: 16-column groups of row k before its last (k & 3) columns
+__host__ __device__ constexpr int trsm_ng(int k) { return ((k & ~3) + 15) / 16; }
+__host__ __device__ constexpr int trsm_gcount(int k, int g) {
+    int c = g;
+    for (int q = 0; q < k; ++q) c += trsm_ng(q);
+    return c;
+}
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
     __shared__ __attribute__((aligned(16))) double col[2][PB];
-    __shared__ __attribute__((aligned(16))) double Ls[PB][PB];
+    __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];   // +2: row-per-lane writes spread over the banks
     __shared__ __attribute__((aligned(16))) double invd[PB];
     __shared__ double zblk[PB];
     __shared__ double Xs[PB][PB + 1];
@@ -68,6 +88,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
     const long long row = j0 + PB + (long long)blockIdx.x * PB + lane;
     const bool has_row = row < a.n;
 
+    PANEL_STAMP(0);
     // row `lane` of the diagonal block (identity past the matrix edge / above the diagonal);
     // one base address + immediate offsets (a per-element clamp costs a 64-bit address each)
     double ar[PB];
@@ -99,9 +120,10 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
     }
     PANEL_FENCE();
 
+    PANEL_STAMP(1);
     static_for<PB>([&](auto kc_) {
         constexpr int k = decltype(kc_)::value;
-        const double piv = __shfl(ar[k], k);
+        const double piv = bcast_lane(ar[k], k);
         const bool bad = !(piv > 0.0) || !(piv < INFINITY);
         if (bad && blockIdx.x == 0 && lane == 0) atomicMin((unsigned int*)a.info, (unsigned int)(j0 + k + 1));
         const double pv = bad ? 1.0 : piv;
@@ -114,8 +136,8 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
         double d = pv * r;
         d = fma(0.5 * r, fma(-d, d, pv), d);
         const double inv = r;
-        if (lane == k) { ar[k] = d; invd[k] = inv; }
-        else ar[k] *= inv;                       // lanes > k: L_ik (lanes < k: unused upper part)
+        if (lane == k) invd[k] = inv;
+        ar[k] = lane == k ? d : ar[k] * inv;     // lanes > k: L_ik (lanes < k: unused upper part)
         double* cb = col[k & 1];
         cb[lane] = ar[k];
         // rank-1 update of the trailing columns: ar[j] -= L_ik * L_jk  (L_jk broadcast from LDS)
@@ -147,6 +169,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
             PANEL_FENCE();
         }
     });
+    PANEL_STAMP(2);
     // L_jj rows to LDS for the broadcast reads below (zeros above the diagonal)
 #pragma unroll
     for (int k = 0; k < PB; k += 2) {
@@ -166,52 +189,86 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
     // its share below.
     if (a.rhs) {
         double ri = (lane < bs) ? a.rhs[j0 + lane] : 0.0;
-#pragma unroll
-        for (int k = 0; k < PB; ++k) {
-            const double zk = __shfl(ri, k) * invd[k];
-            if (lane == k) ri = zk;
-            else if (lane > k) ri = fma(-ar[k], zk, ri);
-        }
+        static_for<PB>([&](auto kc_) {
+            constexpr int k = decltype(kc_)::value;
+            const double zk = bcast_lane(ri, k) * invd[k];
+            ri = lane == k ? zk : (lane > k ? fma(-ar[k], zk, ri) : ri);
+        });
         zblk[lane] = ri;
         if (blockIdx.x == 0 && lane < bs) a.rhs[j0 + lane] = ri;
     }
+    PANEL_STAMP(3);
     // rows of the panel below the diagonal block: x L_jj^T = a  (row-wise forward substitution)
     PANEL_FENCE();
     double x[PB];
 #pragma unroll
     for (int k = 0; k < PB; ++k) x[k] = Xs[lane][k];
     PANEL_FENCE();
+    // x[k] = (a[k] - sum_{m<k} x[m] L[k][m]) / L[k][k], k ascending.  The L values are
+    // broadcast LDS reads; they are requested ONE STAGE AHEAD of their use (a stage = 16
+    // columns of row k, or the row's last <= 3 columns + 1/L[k][k]) so that no LDS latency
+    // sits between the dependent dot products.
+    f64x2 lq[2][8], tq[2][2];
+    double ivq[2];
+    auto load_wide = [&](auto kt, auto gt) {          // columns [16 g, 16 g + 16) of row k
+        constexpr int k = decltype(kt)::value, g = decltype(gt)::value;
+        constexpr int buf = trsm_gcount(k, g) & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (16 * g + 2 * i + 1 < (k & ~3)) lq[buf][i] = *(const f64x2*)(&Ls[k][16 * g + 2 * i]);
+    };
+    auto load_tail = [&](auto kt) {                   // columns [k & ~3, +4) of row k and 1/L[k][k]
+        constexpr int k = decltype(kt)::value;
+        tq[k & 1][0] = *(const f64x2*)(&Ls[k][k & ~3]);
+        tq[k & 1][1] = *(const f64x2*)(&Ls[k][(k & ~3) + 2]);
+        ivq[k & 1] = invd[k];
+    };
+    auto load_first_of = [&](auto kt) {
+        constexpr int k = decltype(kt)::value;
+        if constexpr (k < PB) {
+            if constexpr (trsm_ng(k) > 0) load_wide(kt, std::integral_constant<int, 0>{});
+            else load_tail(kt);
+        }
+    };
+    load_first_of(std::integral_constant<int, 0>{});
     static_for<PB>([&](auto kc_) {
         constexpr int k = decltype(kc_)::value;
         // four partial sums: the dependent-FMA chain is the cost here
         double s0 = x[k], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        static_for<4>([&](auto gc_) {
+            constexpr int g = decltype(gc_)::value;
+            if constexpr (g < trsm_ng(k)) {
+                if constexpr (g + 1 < trsm_ng(k)) load_wide(kc_, std::integral_constant<int, g + 1>{});
+                else load_tail(kc_);
+                PANEL_FENCE();
+                constexpr int buf = trsm_gcount(k, g) & 1;
 #pragma unroll
-        for (int m0 = 0; m0 + 3 < k; m0 += 16) {
-            f64x2 lq[8];
+                for (int i = 0; i < 8; i += 2)
+                    if (16 * g + 2 * i + 3 < k) {
+                        const int m = 16 * g + 2 * i;
+                        s0 = fma(-x[m], lq[buf][i].x, s0);
+                        s1 = fma(-x[m + 1], lq[buf][i].y, s1);
+                        s2 = fma(-x[m + 2], lq[buf][i + 1].x, s2);
+                        s3 = fma(-x[m + 3], lq[buf][i + 1].y, s3);
+                    }
+                asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));   // pin (see above)
+                PANEL_FENCE();
+            }
+        });
+        load_first_of(std::integral_constant<int, k + 1>{});
+        PANEL_FENCE();
+        {
+            const double tl[4] = {tq[k & 1][0].x, tq[k & 1][0].y, tq[k & 1][1].x, tq[k & 1][1].y};
 #pragma unroll
-            for (int g = 0; g < 8; ++g)
-                if (m0 + 2 * g + 1 < (k & ~3)) lq[g] = *(const f64x2*)(&Ls[k][m0 + 2 * g]);
-            PANEL_FENCE();
-#pragma unroll
-            for (int g = 0; g < 8; g += 2)
-                if (m0 + 2 * g + 3 < k) {
-                    const int m = m0 + 2 * g;
-                    s0 = fma(-x[m], lq[g].x, s0);
-                    s1 = fma(-x[m + 1], lq[g].y, s1);
-                    s2 = fma(-x[m + 2], lq[g + 1].x, s2);
-                    s3 = fma(-x[m + 3], lq[g + 1].y, s3);
-                }
-            asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));   // pin (see above)
-            PANEL_FENCE();
+            for (int m = k & ~3; m < k; ++m) s0 = fma(-x[m], tl[m - (k & ~3)], s0);
         }
-#pragma unroll
-        for (int m = k & ~3; m < k; ++m) s0 = fma(-x[m], Ls[k][m], s0);
-        x[k] = ((s0 + s1) + (s2 + s3)) * invd[k];
+        x[k] = ((s0 + s1) + (s2 + s3)) * ivq[k & 1];
         asm volatile("" : "+v"(x[k]));
-        // keep hipcc from hoisting the (address-independent) LDS reads of later k's up
-        // here: hundreds of them in flight spill the two 64-double register rows
+        // (the fences also keep hipcc from hoisting the address-independent LDS reads of later
+        // k's up here: hundreds of them in flight spill the 64-double register row)
         PANEL_FENCE();
     });
+    PANEL_STAMP(4);
     if (has_row) {
         double* ap = a.A + row * a.lda + j0;
 #pragma unroll
@@ -226,6 +283,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
             a.rhs[row] -= d0 + d1;
         }
     }
+    PANEL_STAMP(5);
 }
 
 // trailing update: tile (bi, bk), bi >= bk, of the blocks below/right of column block j:

@@ -1,0 +1,23 @@
+// developer probe: per-phase cycles of potrf_panel_kernel (s_memtime stamps, workgroup 0)
+#define APGP_PANEL_TIMING 1
+#include "../approxposterior_amd/csrc/potrf.hip"
+#include "../approxposterior_amd/csrc/gram.hip"
+#include <vector>
+int main() {
+    const long long n = 4096;
+    std::vector<double> h(n * n, 0.0), y(n, 1.0);
+    for (long long i = 0; i < n; ++i) for (long long j = 0; j <= i; ++j) h[i * n + j] = (i == j) ? 4.0 + 0.001 * i : 0.5 / (1.0 + (i - j));
+    double *A, *yd, *z; int* info;
+    (void)hipMalloc(&A, n * n * 8); (void)hipMalloc(&yd, n * 8); (void)hipMalloc(&z, n * 8); (void)hipMalloc(&info, 4);
+    (void)hipMemcpy(yd, y.data(), n * 8, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) {
+        (void)hipMemcpy(A, h.data(), n * n * 8, hipMemcpyHostToDevice);
+        int rc = apgp_potrf(A, n, n, yd, 0.0, z, info, nullptr);
+        (void)hipDeviceSynchronize();
+        unsigned long long s[8];
+        (void)hipMemcpyFromSymbol(s, HIP_SYMBOL(apgp_panel_stamps), sizeof(s));
+        printf("rc %d | last panel step cycles: load+park %llu potf2 %llu Ls+writeback+zsolve %llu xload %llu trsm %llu store %llu\n", rc,
+               s[1] - s[0], s[2] - s[1], s[3] - s[2], 0ull, s[4] - s[3], s[5] - s[4]);
+    }
+    return 0;
+}
