@@ -5,6 +5,7 @@
 //   g_k    = 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta_k
 //   dK/dlog_constant = amp * k_se           (white noise excluded)
 //   dK/dlog_M_d      = K * 0.5 * dx_d^2 / M_d
+//   g_white_noise    = 0.5 * exp(white_noise) * trace(alpha alpha^T - Kinv)   (fit_white_noise)
 // K^-1 = W^T W (W = L^-1) is formed with an MFMA-f64 GEMM; K and dK are
 // regenerated in registers from X (no N x N x P tensor in HBM).
 #include "apgp_common.h"
@@ -142,16 +143,18 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
     }
 }
 
-// out[0] = sum alpha ; out[1] = 0.5 * sum A K ; out[2+d] = 0.5 * sum A K dx_d^2 w_d / 2
+// out[0] = sum alpha ; out[1] = 0.5 * sum A K ; out[2+d] = 0.5 * sum A K dx_d^2 w_d / 2 ;
+// out[2 + APGP_MAX_DIM] = 0.5 * trace(A)
 __global__ __launch_bounds__(1024) void grad_final_kernel(const double* partial, long long nblk, int pw,
-                                                          const double* alpha, long long n, int ndim,
-                                                          double* out) {
+                                                          const double* alpha, const double* Kinv,
+                                                          long long n, int ndim, double* out) {
     __shared__ double red[16];
     const int t = threadIdx.x;
-    for (int p = 0; p <= pw; ++p) {   // p == pw: sum(alpha)
+    for (int p = 0; p <= pw + 1; ++p) {   // p == pw: sum(alpha); p == pw + 1: trace(A)
         double v = 0.0;
         if (p < pw) for (long long b = t; b < nblk; b += 1024) v += partial[b * pw + p];
-        else for (long long i = t; i < n; i += 1024) v += alpha[i];
+        else if (p == pw) for (long long i = t; i < n; i += 1024) v += alpha[i];
+        else for (long long i = t; i < n; i += 1024) v += alpha[i] * alpha[i] - Kinv[i * n + i];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if ((t & 63) == 0) red[t >> 6] = v;
         __syncthreads();
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(1024) void grad_final_kernel(const double* partial,
             double s = 0.0;
             for (int i = 0; i < 16; ++i) s += red[i];
             if (p == pw) out[0] = s;
+            else if (p == pw + 1) out[2 + APGP_MAX_DIM] = 0.5 * s;
             else if (p == 0) out[1] = 0.5 * s;
             else if (p - 1 < ndim) out[2 + (p - 1)] = 0.5 * s;
         }
@@ -194,7 +198,7 @@ extern "C" int apgp_grad_loglik(const double* X, const double* alpha, const doub
         default: hipLaunchKernelGGL(grad_tile_kernel<16>, dim3(nb, nb), dim3(256), 0, s, g); break;
     }
     hipLaunchKernelGGL(grad_final_kernel, dim3(1), dim3(1024), 0, s, (const double*)g.partial,
-                       (long long)nb * nb, pw, alpha, (long long)n, g.kc.ndim, out);
+                       (long long)nb * nb, pw, alpha, (const double*)work, (long long)n, g.kc.ndim, out);
     APGP_CHECK_LAUNCH();
     return 0;
 }

@@ -733,7 +733,7 @@ class GP(object):
                 self._solve(y, need_alpha=True)
                 self._ensure_linv()
                 work = torch.empty(lib.apgp_grad_work_len(n), dtype=torch.float64, device=dev)
-                out = torch.empty(2 + _lib.MAX_DIM, dtype=torch.float64, device=dev)
+                out = torch.empty(3 + _lib.MAX_DIM, dtype=torch.float64, device=dev)
                 np64 = (n + 63) // 64 * 64
                 _lib.check(lib.apgp_grad_loglik(self._x_d.data_ptr(), self._alpha.data_ptr(),
                                                 self._work.data_ptr(), np64, n, ctypes.byref(ks),
@@ -748,11 +748,12 @@ class GP(object):
 
     def _assemble_gradient(self, o, ndim):
         """Order device results as george orders its parameter vector."""
-        if self.fit_white_noise:
-            raise NotImplementedError("fit_white_noise=True is not on the MI355X hot path")
         grad = []
         if self.fit_mean:
             grad.append(o[0])
+        if self.fit_white_noise:
+            # d/d white_noise = 0.5 * exp(wn) * trace(alpha alpha^T - K^-1)  (SURVEY.md A.6)
+            grad.append(float(np.exp(self.white_noise.value)) * o[2 + _lib.MAX_DIM])
 
         def walk(k):
             if isinstance(k, Product):

@@ -213,7 +213,9 @@ int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kernel_t* kern 
  * its work buffer (ldw = n rounded up to 64).  work: apgp_grad_work_len(n)
  * doubles (K^-1 = W^T W is formed there).  out (device, 2+ndim doubles):
  *   out[0] = sum(alpha) (d/d mean), out[1] = d/d log_constant (amp part),
- *   out[2+d] = d/d log_M_d_d.                                               */
+ *   out[2+d] = d/d log_M_d_d (d < ndim),
+ *   out[2+APGP_MAX_DIM] = 0.5 * trace(alpha alpha^T - K^-1): times exp(white_noise)
+ *   it is d/d white_noise (george fit_white_noise=True).  out: 3 + APGP_MAX_DIM doubles. */
 int64_t apgp_grad_work_len(int64_t n);
 int apgp_grad_loglik(const double* X, const double* alpha, const double* winv, int64_t ldw,
                      int64_t n, const apgp_kernel_t* kern /*host*/,

@@ -148,6 +148,33 @@ def test_fixture_gradient(golden_dir, name, lib_loaded):
     assert np.allclose(grad, g["grad"], rtol=tol, atol=tol * np.abs(g["grad"]).max())
 
 
+def test_fit_white_noise_protocol_and_gradient(lib_loaded):
+    """george's fit_white_noise=True (the reference's defaultGP fixes it to False,
+    gpUtils.py:176-177, but the GP boundary accepts such an object): the white-noise
+    parameter sits between the mean and the kernel parameters, likelihood and gradient
+    follow the oracle (whose white-noise derivative is finite-difference checked in the
+    CPU suite)."""
+    go, agp = _mods()
+    rs = np.random.RandomState(11)
+    X = rs.uniform(-3, 3, size=(150, 3))
+    y = np.sin(X).sum(axis=1) + 0.05 * rs.normal(size=150)
+    def make(mod):
+        k = 2.0 * mod.ExpSquaredKernel(np.array([1.5, 0.7, 2.0]), ndim=3)
+        return mod.GP(kernel=k, fit_mean=True, mean=0.1, white_noise=np.log(2.5e-3), fit_white_noise=True)
+    gpo, gp = make(go), make(agp)
+    assert gp.get_parameter_names() == gpo.get_parameter_names()
+    assert gp.get_parameter_names()[1] == "white_noise:value" and len(gp) == 6
+    gpo.compute(X); gp.compute(X)
+    assert abs(gp.log_likelihood(y) - gpo.log_likelihood(y)) <= 1e-10 * abs(gpo.log_likelihood(y))
+    g, go_ = gp.grad_log_likelihood(y), gpo.grad_log_likelihood(y)
+    assert np.allclose(g, go_, rtol=1e-9, atol=1e-9 * np.abs(go_).max())
+    p = gp.get_parameter_vector(); p[1] += 0.7
+    gp.set_parameter_vector(p); gpo.set_parameter_vector(p)
+    assert not gp.computed
+    assert abs(gp.log_likelihood(y) - gpo.log_likelihood(y)) <= 1e-10 * abs(gpo.log_likelihood(y))
+    assert np.allclose(gp.grad_log_likelihood(y), gpo.grad_log_likelihood(y), rtol=1e-9, atol=1e-9 * np.abs(go_).max())
+
+
 def test_reference_known_answers(golden_dir, lib_loaded):
     """The reference's own known-answer constants (test_InitGP.py:43,76;
     test_GPUtil.py:50-62,101-113) through the HIP-backed defaultGP + utilities."""

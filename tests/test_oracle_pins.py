@@ -144,3 +144,25 @@ def test_oracle_gradient_finite_difference(golden_dir, name):
         fd = (lp - lm) / (2 * h)
         assert np.isclose(fd, grad[i], rtol=2e-5, atol=1e-6 * abs(g["ll"]) * 1e-3 + 1e-6), (i, fd, grad[i])
     gp.set_parameter_vector(p0)
+
+
+def test_oracle_white_noise_gradient_finite_difference():
+    """fit_white_noise=True (george; never switched on by the reference's defaultGP):
+    parameter order mean | white_noise | kernel, and d ll / d white_noise =
+    0.5 exp(wn) trace(alpha alpha^T - K^-1) against central differences."""
+    rs = np.random.RandomState(11)
+    X = rs.uniform(-3, 3, size=(60, 3))
+    y = np.sin(X).sum(axis=1) + 0.05 * rs.normal(size=60)
+    k = 2.0 * go.ExpSquaredKernel(np.array([1.5, 0.7, 2.0]), ndim=3)
+    gp = go.GP(kernel=k, fit_mean=True, mean=0.1, white_noise=np.log(2.5e-3), fit_white_noise=True)
+    assert gp.get_parameter_names()[:2] == ("mean:value", "white_noise:value") and len(gp) == 6
+    gp.compute(X)
+    p0 = gp.get_parameter_vector()
+    grad = gp.grad_log_likelihood(y)
+    for i in range(len(p0)):
+        h = 1e-5
+        pp = p0.copy(); pp[i] += h
+        gp.set_parameter_vector(pp); lp = gp.log_likelihood(y)
+        pm = p0.copy(); pm[i] -= h
+        gp.set_parameter_vector(pm); lm = gp.log_likelihood(y)
+        assert np.isclose((lp - lm) / (2 * h), grad[i], rtol=1e-5, atol=1e-6), (i, grad[i])
