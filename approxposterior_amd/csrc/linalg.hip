@@ -213,7 +213,7 @@ extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* 
     size_t lds = (nr + TRSV_B * (TRSV_B + 1) + 16 * 64) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)trsv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)trsv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
         attr_set = true;
     }

@@ -904,3 +904,30 @@ extern "C" int apgp_predict_mean(const double* T, int64_t m, const double* xs, i
     APGP_CHECK_LAUNCH();
     return 0;
 }
+
+// Host-buffer form of apgp_predict_mean for the latency-bound caller: an ensemble
+// sampler's half-step evaluates a few dozen points per call (approx.py:178-180 through
+// emcee), 4e4 calls per chain.  One entry point = H2D of the points, the kernel, D2H of
+// the means and ONE stream synchronisation, instead of four host-side round trips.
+extern "C" int apgp_predict_mean_host(const double* T_host, int64_t m, const double* xs, int64_t n,
+                                      const apgp_kernel_t* kern, double mean, double* mu_host,
+                                      double* work, void* stream) {
+    APGP_CHECK_ARG(T_host && mu_host && work && kern, "null pointer");
+    APGP_CHECK_ARG(m >= 1, "m >= 1 required");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t tb = (size_t)m * (size_t)kern->ndim * sizeof(double);
+    double* T_dev = work;
+    double* mu_dev = work + (size_t)m * (size_t)kern->ndim;
+    if (hipMemcpyAsync(T_dev, T_host, tb, hipMemcpyHostToDevice, s) != hipSuccess) {
+        apgp_set_error("apgp_predict_mean_host: H2D copy failed");
+        return -2;
+    }
+    const int rc = apgp_predict_mean(T_dev, m, xs, n, kern, mean, mu_dev, stream);
+    if (rc != 0) return rc;
+    if (hipMemcpyAsync(mu_host, mu_dev, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        apgp_set_error("apgp_predict_mean_host: D2H copy failed");
+        return -2;
+    }
+    return 0;
+}

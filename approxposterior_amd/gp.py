@@ -245,11 +245,15 @@ class GP(object):
         self._work = None         # trtri work (dense L^-1 in first panel)
         self._xs = None           # packed training stream (depends on alpha)
         self._xs_key = None
+        self._mean_work = getattr(self, "_mean_work", None)   # scratch survives refits
         self.cond_estimate = None
         self.log_determinant = None
 
     def _rt(self):
         """(torch, device, lib) -- fails loudly without GPU / extension."""
+        rt = getattr(self, "_rt_cache", None)
+        if rt is not None:
+            return rt
         import torch
         lib = _lib.load()
         if not torch.cuda.is_available():
@@ -259,10 +263,16 @@ class GP(object):
             dev = torch.device("cuda", torch.cuda.current_device())
         elif not isinstance(dev, torch.device):
             dev = torch.device(dev)
-        return torch, dev, lib
+        self._rt_cache = (torch, dev, lib)
+        return self._rt_cache
 
     @staticmethod
     def _stream(torch):
+        # the raw-handle query is ~30x cheaper than torch.cuda.current_stream() and this
+        # sits on the per-call path of the sampler's log-probability
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if raw is not None:
+            return ctypes.c_void_p(raw(torch.cuda.current_device()))
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def _kernel_struct(self):
@@ -595,6 +605,19 @@ class GP(object):
         with torch.cuda.device(dev):
             st = self._stream(torch)
             self._ensure_xs(y)
+            if not need_var and cand_device is None and 0 < len(cand) <= 4096:
+                # latency-bound mean-only call (the sampler's _gpll batches): host buffers
+                # in and out through ONE library call and one synchronisation
+                m = len(cand)
+                need = m * (ks.ndim + 1)
+                if self._mean_work is None or self._mean_work.numel() < need:
+                    self._mean_work = torch.empty(max(need, 1024), dtype=torch.float64, device=dev)
+                mu_h = np.empty(m, dtype=np.float64)
+                _lib.check(lib.apgp_predict_mean_host(cand.ctypes.data, m, self._xs.data_ptr(), n,
+                                                      ctypes.byref(ks), float(self.mean.value),
+                                                      mu_h.ctypes.data, self._mean_work.data_ptr(), st),
+                           "apgp_predict_mean_host")
+                return (mu_h,)
             T = cand_device if cand_device is not None else torch.from_numpy(cand).to(dev)
             m = T.shape[0]
             if m == 0:

@@ -189,6 +189,14 @@ int apgp_predict_mean(const double* T, int64_t m, const double* xs, int64_t n,
                       const apgp_kernel_t* kern /*host*/, double mean,
                       double* mu, void* stream);
 
+/* Same, from / to HOST buffers in one call (H2D, kernel, D2H, one stream
+ * synchronisation): the per-half-step call of an ensemble sampler
+ * (approx.py:839-846 -> _gpll, approx.py:178-180) is latency-bound.
+ * work: device scratch of m * (ndim + 1) doubles.                            */
+int apgp_predict_mean_host(const double* T_host, int64_t m, const double* xs, int64_t n,
+                           const apgp_kernel_t* kern /*host*/, double mean,
+                           double* mu_host, double* work, void* stream);
+
 /* ---- on-device ensemble MCMC over the GP-mean surrogate ---------------------
  * The whole loop of ApproxPosterior.runMCMC (approx.py:839-846): emcee's stretch
  * move (a = a_stretch, red/blue halves with a random cyclic offset per iteration)
