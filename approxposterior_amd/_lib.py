@@ -53,6 +53,7 @@ SIGNATURES = {
     "apgp_potrf": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, _P, _P, _P]),
     "apgp_logdet": (ctypes.c_int, [_P, _I64, _I64, _P, _P]),
     "apgp_fit_summary": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
+    "apgp_nll_eval": (ctypes.c_int, [_P, _I64, _KP, _P, _F64, _P, _P, _P, _P, _P, _P]),
     "apgp_trsv": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, ctypes.c_int, _P, _P, _P]),
     "apgp_trtri_pack": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
     "apgp_pack_train": (ctypes.c_int, [_P, _P, _I64, _KP, _P, _P]),

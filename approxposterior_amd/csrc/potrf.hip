@@ -375,3 +375,30 @@ extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, do
     APGP_CHECK_LAUNCH();
     return 0;
 }
+
+// One gpUtils._nll evaluation (gpUtils.py:46-80) as ONE library call: Gram matrix ->
+// Cholesky with the forward solve riding along -> summary record -> 40-byte D2H -> one
+// stream synchronisation.  Powell / Nelder-Mead call this hundreds to thousands of times
+// per fit; at N = 50 the separate calls' host overhead was as long
+// as the kernels themselves.
+extern "C" int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern, double* K, int64_t ldk, void* stream);
+extern "C" int apgp_fit_summary(const double* L, int64_t n, int64_t ldl, const double* z, const int32_t* info_dev,
+                                double* out5, void* stream);
+extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern, const double* y, double mean,
+                             double* K, double* z, int32_t* info_dev, double* out5_dev, double* out5_host,
+                             void* stream) {
+    APGP_CHECK_ARG(X && kern && y && K && z && info_dev && out5_dev && out5_host, "null pointer");
+    int rc = apgp_gram(X, n, kern, K, n, stream);
+    if (rc != 0) return rc;
+    rc = apgp_potrf(K, n, n, y, mean, z, info_dev, stream);
+    if (rc != 0) return rc;
+    rc = apgp_fit_summary(K, n, n, z, info_dev, out5_dev, stream);
+    if (rc != 0) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        apgp_set_error("apgp_nll_eval: D2H copy failed");
+        return -2;
+    }
+    return 0;
+}

@@ -246,6 +246,7 @@ class GP(object):
         self._xs = None           # packed training stream (depends on alpha)
         self._xs_key = None
         self._mean_work = getattr(self, "_mean_work", None)   # scratch survives refits
+        self._nll_scratch = getattr(self, "_nll_scratch", None)
         self.cond_estimate = None
         self.log_determinant = None
 
@@ -421,33 +422,42 @@ class GP(object):
             st = self._stream(torch)
             self._x_d = keep_x if keep_x is not None else torch.from_numpy(x).to(dev)
             K = torch.empty((n, n), dtype=torch.float64, device=dev)
-            _lib.check(lib.apgp_gram(self._x_d.data_ptr(), n, ctypes.byref(ks), K.data_ptr(), n, st),
-                       "apgp_gram")
-            out5 = torch.empty(5, dtype=torch.float64, device=dev)
             z = None
-            if _USE_ROCSOLVER:
-                # rocSOLVER potrf works column-major: asking for the UPPER factor makes
-                # its memory image the row-major LOWER factor the kernels stream.
-                U, info = torch.linalg.cholesky_ex(K, upper=True, check_errors=False)
-                L = U.mT
-                if not L.is_contiguous():
-                    L = L.contiguous()
-                info = info.to(torch.int32).reshape(1)
+            if yv is not None and not _USE_ROCSOLVER:
+                # the whole _nll evaluation as one library call and one synchronisation
+                y_d = keep_y if keep_y is not None else torch.from_numpy(yv).to(dev)
+                z = torch.empty(n, dtype=torch.float64, device=dev)
+                scr = self._nll_scratch
+                if scr is None:
+                    scr = self._nll_scratch = (torch.empty(1, dtype=torch.int32, device=dev),
+                                               torch.empty(5, dtype=torch.float64, device=dev))
+                o = np.empty(5, dtype=np.float64)
+                _lib.check(lib.apgp_nll_eval(self._x_d.data_ptr(), n, ctypes.byref(ks), y_d.data_ptr(),
+                                             float(self.mean.value), K.data_ptr(), z.data_ptr(),
+                                             scr[0].data_ptr(), scr[1].data_ptr(), o.ctypes.data, st),
+                           "apgp_nll_eval")
+                L = K
             else:
-                # own blocked Cholesky (csrc/potrf.hip), in place on the Gram matrix
-                info = torch.empty(1, dtype=torch.int32, device=dev)
-                if yv is not None:
-                    y_d = keep_y if keep_y is not None else torch.from_numpy(yv).to(dev)
-                    z = torch.empty(n, dtype=torch.float64, device=dev)
-                    _lib.check(lib.apgp_potrf(K.data_ptr(), n, n, y_d.data_ptr(), float(self.mean.value),
-                                              z.data_ptr(), info.data_ptr(), st), "apgp_potrf")
+                _lib.check(lib.apgp_gram(self._x_d.data_ptr(), n, ctypes.byref(ks), K.data_ptr(), n, st),
+                           "apgp_gram")
+                out5 = torch.empty(5, dtype=torch.float64, device=dev)
+                if _USE_ROCSOLVER:
+                    # rocSOLVER potrf works column-major: asking for the UPPER factor makes
+                    # its memory image the row-major LOWER factor the kernels stream.
+                    U, info = torch.linalg.cholesky_ex(K, upper=True, check_errors=False)
+                    L = U.mT
+                    if not L.is_contiguous():
+                        L = L.contiguous()
+                    info = info.to(torch.int32).reshape(1)
                 else:
+                    # own blocked Cholesky (csrc/potrf.hip), in place on the Gram matrix
+                    info = torch.empty(1, dtype=torch.int32, device=dev)
                     _lib.check(lib.apgp_potrf(K.data_ptr(), n, n, None, 0.0, None, info.data_ptr(), st),
                                "apgp_potrf")
-                L = K
-            _lib.check(lib.apgp_fit_summary(L.data_ptr(), n, n, z.data_ptr() if z is not None else None,
-                                            info.data_ptr(), out5.data_ptr(), st), "apgp_fit_summary")
-            o = out5.cpu().numpy()          # the only synchronisation of the evaluation
+                    L = K
+                _lib.check(lib.apgp_fit_summary(L.data_ptr(), n, n, None, info.data_ptr(), out5.data_ptr(), st),
+                           "apgp_fit_summary")
+                o = out5.cpu().numpy()          # the only synchronisation of the evaluation
         if int(o[4]) != 0:
             # same failure mode as scipy.linalg.cholesky inside george
             raise LinAlgError("%d-th leading minor of the array is not positive definite" % int(o[4]))

@@ -118,6 +118,16 @@ int apgp_logdet(const double* L, int64_t n, int64_t ldl, double* out5, void* str
 int apgp_fit_summary(const double* L, int64_t n, int64_t ldl, const double* z,
                      const int32_t* info_dev, double* out5, void* stream);
 
+/* ---- one gpUtils._nll evaluation (gpUtils.py:46-80) in one call ---------------
+ * apgp_gram -> apgp_potrf (z = L^-1 (y - mean) riding along) -> apgp_fit_summary ->
+ * 40-byte D2H into out5_host -> one stream synchronisation.  K: n x n work (holds
+ * the factor on return), z: n, info_dev / out5_dev: device scratch.  Status as the
+ * parts'; a non-PD matrix is reported in out5_host[4] (> 0), not in the status.  */
+int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
+                  const double* y, double mean, double* K, double* z,
+                  int32_t* info_dev, double* out5_dev, double* out5_host /*host*/,
+                  void* stream);
+
 /* ---- K3: triangular solves for z = L^-1 (b - shift), alpha = L^-T z --------
  * Replaces BasicSolver.apply_inverse / dot_solve on a vector (scipy cho_solve;
  * george GP.log_likelihood and _compute_alpha; gpUtils.py:78, utility.py:131).
