@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libapgp.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_DIM = 16
 
 UTIL_AGP, UTIL_BAPE, UTIL_JONES, UTIL_NONE = 0, 1, 2, 3
@@ -22,9 +22,9 @@ class ApgpError(RuntimeError):
 
 class KernelStruct(ctypes.Structure):
     """``apgp_kernel_t`` (include/apgp.h)."""
-    _fields_ = [("ndim", ctypes.c_int32), ("_pad", ctypes.c_int32),
+    _fields_ = [("ndim", ctypes.c_int32), ("lin_order", ctypes.c_int32),
                 ("amp", ctypes.c_double), ("diag_add", ctypes.c_double),
-                ("inv_metric", ctypes.c_double * MAX_DIM)]
+                ("inv_metric", ctypes.c_double * MAX_DIM), ("lin_coef", ctypes.c_double)]
 
 
 class BestStruct(ctypes.Structure):

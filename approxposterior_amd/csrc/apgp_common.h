@@ -39,14 +39,34 @@ static inline int64_t apgp_round_up(int64_t n, int64_t b) { return (n + b - 1) /
 // evaluates the squared-exponential kernel, so that K (Gram), K* (sweep) and
 // dK (gradient) use bit-identical expressions:
 //   k(x,x') = amp * exp(-sum_d (xs_d - xs'_d)^2),  xs = x * sqrt(inv_metric/2)
+// and, when lin_coef != 0, the linear-regression term in the same scaled coordinates:
+//   k_lin(x,x') = lin_coef * sum_d (xs_d xs'_d lw_d)^P,  lw_d = 1 / sc_d^2
 struct KernConst {
     double sc[APGP_MAX_DIM];
+    double lw[APGP_MAX_DIM];
     double log_amp;
     double amp;
     double diag_add;
+    double lin_coef;
+    int lin_order;
     int ndim;
     int dpad;
 };
+
+// sum_d (p_d)^P over the real dimensions, p_d = xs_d xs'_d lw_d (padded dimensions carry
+// xs = 0: their product is 0 for P >= 1; P = 0 counts ndim ones as george does)
+#define APGP_LIN_SUM(acc, DP, ndim, order, prod_d)                         \
+    do {                                                                   \
+        acc = 0.0;                                                         \
+        if ((order) == 0) acc = (double)(ndim);                            \
+        else                                                               \
+            for (int d_ = 0; d_ < (DP); ++d_) {                            \
+                const double p_ = (prod_d);                                \
+                double q_ = p_;                                            \
+                for (int e_ = 1; e_ < (order); ++e_) q_ *= p_;             \
+                acc += q_;                                                 \
+            }                                                              \
+    } while (0)
 
 static inline int apgp_make_kernconst(const apgp_kernel_t* k, KernConst* c) {
     if (!k || k->ndim < 1 || k->ndim > APGP_MAX_DIM) return -1;
@@ -56,8 +76,13 @@ static inline int apgp_make_kernconst(const apgp_kernel_t* k, KernConst* c) {
     c->amp = k->amp;
     c->log_amp = log(k->amp);
     c->diag_add = k->diag_add;
-    for (int d = 0; d < APGP_MAX_DIM; ++d)
+    if (!(k->lin_coef >= 0.0) || k->lin_order < 0 || k->lin_order > 16) return -1;
+    c->lin_coef = k->lin_coef;
+    c->lin_order = k->lin_order;
+    for (int d = 0; d < APGP_MAX_DIM; ++d) {
         c->sc[d] = d < k->ndim ? sqrt(0.5 * k->inv_metric[d]) : 0.0;
+        c->lw[d] = d < k->ndim ? 2.0 / k->inv_metric[d] : 0.0;
+    }
     return 0;
 }
 

@@ -23,10 +23,10 @@ struct EnsArgs {
     double* logp_chain;    // iterations x E x W or NULL
     long long* naccept;    // E x W
     long long n, iterations;
-    int ndim, nwalkers;
+    int ndim, nwalkers, lin_order;
     unsigned long long seed;
-    double mean, amp, a_stretch;
-    double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM];
+    double mean, amp, a_stretch, lin_coef;
+    double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
 };
 
 __device__ __forceinline__ void philox4x32(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
@@ -98,7 +98,13 @@ __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
                 s = fma(df0, df0, s);
                 s3 = fma(df1, df1, s3);
             }
-            acc = fma(a.amp * apgp_exp(-(s + s3), etab), xr[DPAD], acc);
+            double kv = a.amp * apgp_exp(-(s + s3), etab);
+            if (a.lin_coef != 0.0) {
+                double ls;
+                APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, tt[d_] * xr[d_] * a.lw[d_]);
+                kv = fma(a.lin_coef, ls, kv);
+            }
+            acc = fma(kv, xr[DPAD], acc);
         }
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
         return acc + a.mean;
@@ -201,7 +207,9 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
     a.naccept = (long long*)naccept; a.n = apgp_npad(n); a.iterations = iterations;
     a.ndim = kc.ndim; a.nwalkers = nwalkers; a.seed = seed; a.mean = mean; a.amp = kc.amp;
     a.a_stretch = a_stretch;
+    a.lin_coef = kc.lin_coef; a.lin_order = kc.lin_order;
     for (int d = 0; d < APGP_MAX_DIM; ++d) {
+        a.lw[d] = kc.lw[d];
         a.sc[d] = d < kc.ndim ? kc.sc[d] : 1.0;
         a.lo[d] = d < kc.ndim ? lo[d] * kc.sc[d] : 0.0;     // bounds in scaled coordinates
         a.hi[d] = d < kc.ndim ? hi[d] * kc.sc[d] : 0.0;

@@ -67,7 +67,7 @@ struct GradArgs {
     const double* X;
     const double* alpha;
     const double* Kinv;
-    double* partial;     // nblocks x (1 + DPAD)
+    double* partial;     // nblocks x (2 + DPAD): amp | metric d ... | linear term
     long long n;
     KernConst kc;
 };
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
     __shared__ double xi[64][DPAD + 1];
     __shared__ double xj[64][DPAD + 1];
     __shared__ double ai[64], aj[64];
-    __shared__ double red[4][1 + DPAD];
+    __shared__ double red[4][2 + DPAD];
     __shared__ double etab[APGP_EXP_TAB_N];
     apgp_exp_tab_load(etab);
     const int t = threadIdx.x;
@@ -103,9 +103,9 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
 #pragma unroll
     for (int d = 0; d < DPAD; ++d) xc[d] = xj[c][d];
     const long long gj = j0 + c;
-    double gsum[1 + DPAD];
+    double gsum[2 + DPAD];
 #pragma unroll
-    for (int p = 0; p < 1 + DPAD; ++p) gsum[p] = 0.0;
+    for (int p = 0; p < 2 + DPAD; ++p) gsum[p] = 0.0;
     for (int q = 0; q < 16; ++q) {
         const int r = g + 4 * q;
         const long long gi = i0 + r;
@@ -127,24 +127,30 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
             gsum[0] += Ak;
 #pragma unroll
             for (int d = 0; d < DPAD; ++d) gsum[1 + d] = fma(Ak, df2[d], gsum[1 + d]);
+            if (a.kc.lin_coef != 0.0) {
+                // d/d log_constant2 = k_lin, d/d log_gamma2 = -k_lin (the host applies the sign)
+                double ls;
+                APGP_LIN_SUM(ls, DPAD, a.kc.ndim, a.kc.lin_order, xi[r][d_] * xc[d_] * a.kc.lw[d_]);
+                gsum[1 + DPAD] = fma(A * a.kc.lin_coef, ls, gsum[1 + DPAD]);
+            }
         }
     }
 #pragma unroll
-    for (int p = 0; p < 1 + DPAD; ++p) {
+    for (int p = 0; p < 2 + DPAD; ++p) {
         double v = gsum[p];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if ((t & 63) == 0) red[g][p] = v;
     }
     __syncthreads();
-    if (t < 1 + DPAD) {
+    if (t < 2 + DPAD) {
         double v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
         const long long blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-        a.partial[blk * (1 + DPAD) + t] = v;
+        a.partial[blk * (2 + DPAD) + t] = v;
     }
 }
 
 // out[0] = sum alpha ; out[1] = 0.5 * sum A K ; out[2+d] = 0.5 * sum A K dx_d^2 w_d / 2 ;
-// out[2 + APGP_MAX_DIM] = 0.5 * trace(A)
+// out[2 + APGP_MAX_DIM] = 0.5 * trace(A) ; out[3 + APGP_MAX_DIM] = 0.5 * sum A K_lin
 __global__ __launch_bounds__(1024) void grad_final_kernel(const double* partial, long long nblk, int pw,
                                                           const double* alpha, const double* Kinv,
                                                           long long n, int ndim, double* out) {
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(1024) void grad_final_kernel(const double* partial,
             if (p == pw) out[0] = s;
             else if (p == pw + 1) out[2 + APGP_MAX_DIM] = 0.5 * s;
             else if (p == 0) out[1] = 0.5 * s;
+            else if (p == pw - 1) out[3 + APGP_MAX_DIM] = 0.5 * s;
             else if (p - 1 < ndim) out[2 + (p - 1)] = 0.5 * s;
         }
         __syncthreads();
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(1024) void grad_final_kernel(const double* partial,
 
 extern "C" int64_t apgp_grad_work_len(int64_t n) {
     int64_t nb = (n + 63) / 64;
-    return n * n + nb * nb * (1 + APGP_MAX_DIM);
+    return n * n + nb * nb * (2 + APGP_MAX_DIM);
 }
 
 extern "C" int apgp_grad_loglik(const double* X, const double* alpha, const double* winv, int64_t ldw,
@@ -190,7 +197,7 @@ extern "C" int apgp_grad_loglik(const double* X, const double* alpha, const doub
     sa.W = winv; sa.Kinv = work; sa.ldw = ldw; sa.np = np; sa.n = n;
     hipLaunchKernelGGL(syrk_wtw_kernel, dim3(nb, nb), dim3(256), 0, s, sa);
     g.X = X; g.alpha = alpha; g.Kinv = work; g.partial = work + n * n; g.n = n;
-    const int pw = 1 + g.kc.dpad;
+    const int pw = 2 + g.kc.dpad;
     switch (g.kc.dpad) {
         case 2: hipLaunchKernelGGL(grad_tile_kernel<2>, dim3(nb, nb), dim3(256), 0, s, g); break;
         case 4: hipLaunchKernelGGL(grad_tile_kernel<4>, dim3(nb, nb), dim3(256), 0, s, g); break;

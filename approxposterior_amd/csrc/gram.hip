@@ -1,4 +1,4 @@
-// K1 "gram": N x N squared-exponential Gram matrix  K_ij = amp * exp(-|xs_i - xs_j|^2), LDS-tiled, coalesced row
+// K1 "gram": N x N Gram matrix  K_ij = amp * exp(-|xs_i - xs_j|^2) [+ lin_coef * sum_d (x_id x_jd)^P], LDS-tiled, coalesced row
 // writes.  HBM-write-bound (8 N^2 bytes out, 8 N D bytes in).
 // Reference semantics: george ExpSquaredKernel.get_value + the diagonal update
 // of GP.compute (called from gpUtils.py:178,244,254; approx.py:717).
@@ -67,6 +67,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
             s3 = fma(df1, df1, s3);
         }
         double k = a.kc.amp * apgp_exp(-(s + s3), etab);
+        if (a.kc.lin_coef != 0.0) {
+            double ls;
+            APGP_LIN_SUM(ls, DPAD, a.kc.ndim, a.kc.lin_order, xi[r][d_] * xc[d_] * a.kc.lw[d_]);
+            k = fma(a.kc.lin_coef, ls, k);
+        }
         if (gi == gj) k += a.kc.diag_add;
         if (gi < a.n && gj < a.n) a.K[gi * a.ldk + gj] = k;
     }
@@ -121,7 +126,14 @@ __global__ __launch_bounds__(256) void kernel_cross_kernel(CrossArgs a) {
         s = fma(df0, df0, s);
         s3 = fma(df1, df1, s3);
     }
-    a.C[i * a.ldc + j] = a.kc.amp * apgp_exp(-(s + s3), etab);
+    double k = a.kc.amp * apgp_exp(-(s + s3), etab);
+    if (a.kc.lin_coef != 0.0) {
+        double ls;
+        APGP_LIN_SUM(ls, a.kc.ndim, a.kc.ndim, a.kc.lin_order,
+                     a.X1[i * a.kc.ndim + d_] * a.X2[j * a.kc.ndim + d_]);
+        k = fma(a.kc.lin_coef, ls, k);
+    }
+    a.C[i * a.ldc + j] = k;
 }
 
 extern "C" int apgp_kernel_cross(const double* X1, int64_t m, const double* X2, int64_t n,

@@ -60,9 +60,9 @@ struct SweepArgs {
     double* kcache;            // parked B operands: SW_GRID slots x ncache chunks x SW_BCH
     unsigned linv_bytes, xs_bytes, kslot_bytes;   // buffer-descriptor extents
     long long m, idx_offset;
-    int ndim, nrb, kind, has_box, n, ncache;
-    double mean, amp, zeta, ybest;
-    double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM];
+    int ndim, nrb, kind, has_box, n, ncache, lin_order;
+    double mean, amp, zeta, ybest, lin_coef;
+    double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
     unsigned long long* dbg;   // phase cycle counters (APGP_SWEEP_TIMING=1 builds only)
 };
 
@@ -115,7 +115,10 @@ __device__ __forceinline__ void best_merge(double& bu, long long& bi, double u, 
 // many rows as possible: a wavefront owns 512 rows x 16 candidates (128 f64
 // accumulators per lane = the whole AGPR file), so one generated B value feeds
 // 128 MFMAs; one wavefront per SIMD, everything latency-critical is prefetched.
-template <int DPAD, bool TIMING = false>
+// LIN: the kernel carries a linear-regression term (defaultGP(order=...)).  A template
+// parameter, not a uniform branch: the extra code in the generating path costs the
+// LIN-free kernel 3 % through register allocation alone.
+template <int DPAD, bool TIMING = false, bool LIN = false>
 __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     // (compile-time indices only: a runtime-indexed array would live in scratch and drain vmcnt)
     unsigned long long tp[3] = {0, 0, 0}, tg[3] = {0, 0, 0}, tq = 0, ntp = 0, ntg = 0;
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     double* Qp = Tc + DPAD * SW_THREADS;       // ||V||^2 partial sums, one per B rotation
     double* Mp = Qp + 4 * SW_THREADS;          // mu partial sums
     int* Fl = (int*)(Mp + SW_THREADS);         // bit 0: admissible, bit 1: NaN coordinate
-    double* Cst = (double*)(Fl + SW_THREADS);  // sc | lo | hi (3 x APGP_MAX_DIM)
+    double* Cst = (double*)(Fl + SW_THREADS);  // sc | lo | hi | lw (4 x APGP_MAX_DIM)
+    double* Ktt = Cst + 4 * APGP_MAX_DIM;      // k(t,t) per lane (amp + linear term)
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cl = lane & 15, kq = lane >> 4;
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
             Cst[d] = a.sc[d];
             Cst[APGP_MAX_DIM + d] = a.lo[d];
             Cst[2 * APGP_MAX_DIM + d] = a.hi[d];
+            Cst[3 * APGP_MAX_DIM + d] = a.lw[d];
         }
     }
 
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
         const long long crow = blk * SW_CAND + w * 16 + cl;
         const bool inb = crow < a.m;
         bool adm = inb, has_nan = false;
+        double ktl = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;     // sum_d (t_d^2)^P
 #pragma unroll
         for (int d = 0; d < DPAD; ++d) {
             double v = 0.0;
@@ -285,7 +291,14 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 if (v != v) has_nan = true;
             }
             Tc[((d >> 1) * SW_THREADS + t) * 2 + (d & 1)] = v * Cst[d];
+            if (LIN && a.lin_order > 0) {
+                const double p = v * v;
+                double q = p;
+                for (int e = 1; e < a.lin_order; ++e) q *= p;
+                ktl += q;
+            }
         }
+        if (LIN) Ktt[t] = fma(a.lin_coef, ktl, a.amp);     // k(t,t): no white noise (george predict)
         if (inb && a.mask && a.mask[crow] == 0) adm = false;
         Fl[t] = (adm ? 1 : 0) | (has_nan ? 2 : 0);
 #pragma unroll
@@ -339,10 +352,11 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 // interleave; two partial sums per chain halve its length
                 // (all LDS operands of a group of four dimensions are requested before any
                 // is used: left to itself hipcc serialises a dozen read->wait->use trips)
-                double s2[NKK], s3[NKK], al[NKK];
+                double s2[NKK], s3[NKK], al[NKK], lsum[NKK];
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) {
                     s2[kk] = 0.0; s3[kk] = 0.0;
+                    lsum[kk] = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;
                     al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
                 }
                 constexpr int DG = DPAD < 4 ? DPAD : 4;       // dimensions per group
@@ -366,6 +380,19 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                             s2[kk] = fma(df0, df0, s2[kk]);
                             s3[kk] = fma(df1, df1, s3[kk]);
                         }
+                    if (LIN && a.lin_order > 0) {
+                        // linear-regression term: sum_d (t_d x_d)^P in the scaled coordinates
+#pragma unroll
+                        for (int h = 0; h < DG / 2; ++h)
+#pragma unroll
+                            for (int kk = 0; kk < NKK; ++kk) {
+                                const double p0 = tc[h].x * xa[kk][h].x * Cst[3 * APGP_MAX_DIM + d0 + 2 * h];
+                                const double p1 = tc[h].y * xa[kk][h].y * Cst[3 * APGP_MAX_DIM + d0 + 2 * h + 1];
+                                double q0 = p0, q1 = p1;
+                                for (int e = 1; e < a.lin_order; ++e) { q0 *= p0; q1 *= p1; }
+                                lsum[kk] += q0 + q1;
+                            }
+                    }
                 }
                 double ex[NKK];
 #pragma unroll
@@ -375,7 +402,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
                 // exponent would perturb every entry by ~|log amp| ulps, which matters
                 // once cond(K) approaches 1/eps)
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) bfv[kk] *= a.amp;
+                for (int kk = 0; kk < NKK; ++kk) bfv[kk] = LIN ? fma(a.lin_coef, lsum[kk], bfv[kk] * a.amp) : bfv[kk] * a.amp;
                 if (kc >= nparked) {
                     // first visit of this chunk: mu = k* . alpha picks it up exactly once
                     double mupart = Mp[t];
@@ -524,7 +551,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     long long bi = -1;
     if (kq == 0 && crow < a.m) {
         double mu = mupart + a.mean;
-        double var = a.amp - qpart;
+        double var = (LIN ? Ktt[t] : a.amp) - qpart;
         if (has_nan) { mu = NAN; var = NAN; }     // george propagates NaN coordinates
         if (a.mu) a.mu[crow] = mu;
         if (a.var) a.var[crow] = var;
@@ -583,7 +610,7 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 template <int DPAD>
 static int launch_sweep(const SweepArgs& a, hipStream_t s) {
     const size_t lds = (3 * (SW_TILE / 2) + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + 8 + DPAD * SW_THREADS +
-                        5 * SW_THREADS + SW_THREADS / 2 + 3 * APGP_MAX_DIM) * sizeof(double);
+                        6 * SW_THREADS + SW_THREADS / 2 + 4 * APGP_MAX_DIM) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD, false>,
@@ -611,6 +638,16 @@ static int launch_sweep(const SweepArgs& a, hipStream_t s) {
             fprintf(stderr, "[apgp sweep timing] %s tiles %llu | per tile cycles: head %.0f gen/fetch %.0f mfma+stage %.0f\n",
                     g ? "generating" : "parked", h[6 + g], h[3 * g] / nt, h[3 * g + 1] / nt, h[3 * g + 2] / nt);
         }
+        return 0;
+    }
+    if (a.lin_coef != 0.0) {
+        static bool lin_attr_set = false;
+        if (!lin_attr_set) {
+            (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD, false, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lin_attr_set = true;
+        }
+        hipLaunchKernelGGL((sweep_kernel<DPAD, false, true>), dim3(nblk), dim3(SW_THREADS), lds, s, a);
         return 0;
     }
     hipLaunchKernelGGL((sweep_kernel<DPAD, false>), dim3(nblk), dim3(SW_THREADS), lds, s, a);
@@ -667,8 +704,10 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     a.ndim = kc.ndim; a.nrb = (int)(apgp_npad(n) / APGP_ROW_BLOCK); a.kind = kind; a.n = (int)n;
     a.has_box = lo != NULL;
     a.mean = mean; a.amp = kc.amp; a.zeta = zeta; a.ybest = ybest;
+    a.lin_coef = kc.lin_coef; a.lin_order = kc.lin_order;
     for (int d = 0; d < APGP_MAX_DIM; ++d) {
         a.sc[d] = kc.sc[d];
+        a.lw[d] = kc.lw[d];
         a.lo[d] = (lo && d < kc.ndim) ? lo[d] : 0.0;
         a.hi[d] = (hi && d < kc.ndim) ? hi[d] : 0.0;
     }
@@ -708,9 +747,9 @@ struct SolveArgs {
     double* part_u;
     long long* part_i;
     long long m, idx_offset, ldl;
-    int ndim, n, kind, has_box;
-    double mean, amp, zeta, ybest;
-    double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM];
+    int ndim, n, kind, has_box, lin_order;
+    double mean, amp, zeta, ybest, lin_coef;
+    double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
 };
 
 template <int DPAD>
@@ -752,7 +791,12 @@ __global__ __launch_bounds__(256) void sweep_solve_kernel(SolveArgs a) {
                 s2 = fma(df0, df0, s2);
                 s3 = fma(df1, df1, s3);
             }
-            const double kv = a.amp * apgp_exp(-(s2 + s3), etab);
+            double kv = a.amp * apgp_exp(-(s2 + s3), etab);
+            if (a.lin_coef != 0.0) {
+                double ls;
+                APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, tt[d_] * xr[d_] * a.lw[d_]);
+                kv = fma(a.lin_coef, ls, kv);
+            }
             v[k] = kv;
             mup = fma(kv, xr[DPAD], mup);
         }
@@ -768,7 +812,13 @@ __global__ __launch_bounds__(256) void sweep_solve_kernel(SolveArgs a) {
             q = fma(vi, vi, q);
         }
         double mu = mup + a.mean;
-        double var = a.amp - q;
+        double ktt = a.amp;                       // k(t,t): no white noise (george predict)
+        if (a.lin_coef != 0.0) {
+            double ls;
+            APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, tt[d_] * tt[d_] * a.lw[d_]);
+            ktt = fma(a.lin_coef, ls, ktt);
+        }
+        double var = ktt - q;
         if (has_nan) { mu = NAN; var = NAN; }
         if (lane == 0) {
             if (a.mu) a.mu[crow] = mu;
@@ -811,8 +861,10 @@ extern "C" int apgp_acquire_solve(const double* T, int64_t m, int64_t idx_offset
     a.m = m; a.idx_offset = idx_offset; a.ldl = ldl;
     a.ndim = kc.ndim; a.n = (int)n; a.kind = kind; a.has_box = lo != NULL;
     a.mean = mean; a.amp = kc.amp; a.zeta = zeta; a.ybest = ybest;
+    a.lin_coef = kc.lin_coef; a.lin_order = kc.lin_order;
     for (int d = 0; d < APGP_MAX_DIM; ++d) {
         a.sc[d] = kc.sc[d];
+        a.lw[d] = kc.lw[d];
         a.lo[d] = (lo && d < kc.ndim) ? lo[d] : 0.0;
         a.hi[d] = (hi && d < kc.ndim) ? hi[d] : 0.0;
     }
@@ -847,9 +899,9 @@ struct MeanArgs {
     const double* xs;
     double* mu;
     long long m, npad;
-    int ndim;
-    double mean, amp;
-    double sc[APGP_MAX_DIM];
+    int ndim, lin_order;
+    double mean, amp, lin_coef;
+    double sc[APGP_MAX_DIM], lw[APGP_MAX_DIM];
 };
 
 template <int DPAD>
@@ -875,7 +927,13 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(MeanArgs a) {
             s = fma(df0, df0, s);
             s3 = fma(df1, df1, s3);
         }
-        acc = fma(a.amp * apgp_exp(-(s + s3), etab), xr[DPAD], acc);
+        double kv = a.amp * apgp_exp(-(s + s3), etab);
+        if (a.lin_coef != 0.0) {
+            double ls;
+            APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, tt[d_] * xr[d_] * a.lw[d_]);
+            kv = fma(a.lin_coef, ls, kv);
+        }
+        acc = fma(kv, xr[DPAD], acc);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     bool bad = false;
@@ -891,8 +949,8 @@ extern "C" int apgp_predict_mean(const double* T, int64_t m, const double* xs, i
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
     MeanArgs a;
     a.T = T; a.xs = xs; a.mu = mu; a.m = m; a.npad = apgp_npad(n); a.ndim = kc.ndim;
-    a.mean = mean; a.amp = kc.amp;
-    for (int d = 0; d < APGP_MAX_DIM; ++d) a.sc[d] = kc.sc[d];
+    a.mean = mean; a.amp = kc.amp; a.lin_coef = kc.lin_coef; a.lin_order = kc.lin_order;
+    for (int d = 0; d < APGP_MAX_DIM; ++d) { a.sc[d] = kc.sc[d]; a.lw[d] = kc.lw[d]; }
     dim3 grid((unsigned)((m + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     switch (kc.dpad) {

@@ -97,11 +97,16 @@ class Kernel(object):
     __mul__ = __rmul__
 
     def __add__(self, other):
-        raise NotImplementedError(
-            "kernel sums (the optional LinearKernel of defaultGP(order=...), "
-            "gpUtils.py:169-173) are not part of the MI355X hot path yet")
+        # george: ``kernel + other`` -> Sum(kernel, other) (gpUtils.py:170, the optional
+        # linear-regression term of defaultGP(order=...))
+        if not hasattr(other, "is_kernel"):
+            raise NotImplementedError("only kernel + kernel sums are on the MI355X hot path")
+        return Sum(self, other)
 
-    __radd__ = __add__
+    def __radd__(self, other):
+        if not hasattr(other, "is_kernel"):
+            raise NotImplementedError("only kernel + kernel sums are on the MI355X hot path")
+        return Sum(other, self)
 
     def __len__(self):
         return len(self.get_parameter_vector())
@@ -148,6 +153,36 @@ class ExpSquaredKernel(Kernel):
         self.dirty = True
 
 
+class LinearKernel(Kernel):
+    """george.kernels.LinearKernel(log_gamma2, order, ndim) (gpUtils.py:170-173):
+    k(x,x') = sum_d (x_d x'_d)^P / gamma^2 with the per-axis sum george uses for its
+    non-stationary kernels; ``order`` P is a constant, ``log_gamma2`` the
+    only parameter.  No reference test pins it ("parity unpinned"); P must be an integer
+    >= 0 here."""
+
+    def __init__(self, log_gamma2=None, order=None, bounds=None, ndim=1, axes=None):
+        if log_gamma2 is None or order is None:
+            raise ValueError("log_gamma2 and order are required")
+        if axes is not None:
+            raise NotImplementedError("axes subsets are not on the MI355X hot path")
+        if int(order) != order or order < 0 or order > 16:
+            raise NotImplementedError("LinearKernel order must be an integer in [0, 16] on the device path")
+        self.log_gamma2 = float(log_gamma2)
+        self.order = int(order)
+        self.ndim = int(ndim)
+        self.dirty = True
+
+    def get_parameter_names(self):
+        return ("log_gamma2",)
+
+    def get_parameter_vector(self):
+        return np.array([self.log_gamma2])
+
+    def set_parameter_vector(self, v):
+        self.log_gamma2 = float(v[0])
+        self.dirty = True
+
+
 class Product(Kernel):
     def __init__(self, k1, k2):
         self.k1 = k1
@@ -177,36 +212,71 @@ class Product(Kernel):
         self.k2.set_parameter_vector(v[n1:])
 
 
+class Sum(Product):
+    """george.kernels.Sum: same parameter protocol as Product (k1:..., k2:...)."""
+
+
 class _KernelsNamespace(object):
     """Stands in for ``george.kernels``."""
     ExpSquaredKernel = ExpSquaredKernel
     ConstantKernel = ConstantKernel
+    LinearKernel = LinearKernel
     Product = Product
+    Sum = Sum
 
 
 kernels = _KernelsNamespace()
 
 
-def _flatten_kernel(kernel):
-    """(amp, log_M) of an ExpSquared kernel, optionally times constants."""
-    amp = 1.0
-    se = None
+def _flatten_term(kernel):
+    """One additive term: (constant factor, ExpSquaredKernel or None, LinearKernel or None)."""
+    amp, se, lin = 1.0, None, None
     stack = [kernel]
     while stack:
         k = stack.pop()
+        if isinstance(k, Sum):
+            raise NotImplementedError("nested kernel sums are not on the MI355X hot path")
         if isinstance(k, Product):
             stack += [k.k1, k.k2]
         elif isinstance(k, ConstantKernel):
             amp *= k.ndim * np.exp(k.log_constant)
         elif isinstance(k, ExpSquaredKernel):
-            if se is not None:
-                raise NotImplementedError("product of two ExpSquaredKernels")
+            if se is not None or lin is not None:
+                raise NotImplementedError("product of two non-constant kernels")
             se = k
+        elif isinstance(k, LinearKernel):
+            if se is not None or lin is not None:
+                raise NotImplementedError("product of two non-constant kernels")
+            lin = k
         else:
             raise NotImplementedError("kernel type %r is not on the MI355X hot path" % type(k))
-    if se is None:
-        raise NotImplementedError("an ExpSquaredKernel factor is required")
-    return float(amp), np.asarray(se.log_M, dtype=np.float64)
+    return float(amp), se, lin
+
+
+def _flatten_kernel(kernel, with_linear=False):
+    """(amp, log_M) of an ExpSquared kernel, optionally times constants; with
+    ``with_linear`` also (lin_coef, lin_order) of an added [constant *] LinearKernel
+    (``kernel + c * LinearKernel``, gpUtils.py:170-173), (0.0, 0) if there is none."""
+    terms = [kernel.k1, kernel.k2] if isinstance(kernel, Sum) else [kernel]
+    amp = log_M = None
+    lin_coef, lin_order = 0.0, 0
+    for term in terms:
+        c, se, lin = _flatten_term(term)
+        if se is not None:
+            if amp is not None:
+                raise NotImplementedError("sum of two ExpSquaredKernel terms")
+            amp, log_M = c, np.asarray(se.log_M, dtype=np.float64)
+        elif lin is not None:
+            if lin_coef != 0.0:
+                raise NotImplementedError("sum of two LinearKernel terms")
+            lin_coef, lin_order = c * float(np.exp(-lin.log_gamma2)), lin.order
+        else:
+            raise NotImplementedError("a purely constant kernel term is not on the MI355X hot path")
+    if amp is None:
+        raise NotImplementedError("an ExpSquaredKernel term is required")
+    if with_linear:
+        return amp, log_M, float(lin_coef), int(lin_order)
+    return amp, log_M
 
 
 # ---------------------------------------------------------------------------
@@ -277,10 +347,12 @@ class GP(object):
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def _kernel_struct(self):
-        amp, log_M = _flatten_kernel(self.kernel)
+        amp, log_M, lin_coef, lin_order = _flatten_kernel(self.kernel, with_linear=True)
         ks = _lib.KernelStruct()
         ks.ndim = len(log_M)
         ks.amp = amp
+        ks.lin_coef = lin_coef
+        ks.lin_order = lin_order
         ks.diag_add = float(self._yerr2) + float(np.exp(self.white_noise.value))
         for d in range(_lib.MAX_DIM):
             ks.inv_metric[d] = float(np.exp(-log_M[d])) if d < len(log_M) else 0.0
@@ -387,7 +459,10 @@ class GP(object):
                                                  ctypes.byref(ks), row.data_ptr(), n1, st), "apgp_kernel_cross")
                 _lib.check(lib.apgp_trsv(L.data_ptr(), j, n1, row.data_ptr(), 0.0, 0, L[j].data_ptr(),
                                          ss.data_ptr(), st), "apgp_trsv(append)")
-                d2 = ks.amp + ks.diag_add - float(ss.item())
+                kxx = ks.amp            # k(x_new, x_new): amplitude + the linear term's sum_d (x_d^2)^P
+                if ks.lin_coef != 0.0:
+                    kxx += ks.lin_coef * float(np.sum((self._x[j] * self._x[j]) ** ks.lin_order))
+                d2 = kxx + ks.diag_add - float(ss.item())
                 if not (d2 > 0.0 and np.isfinite(d2)):
                     self._reset_device_state()
                     raise LinAlgError("%d-th leading minor of the array is not positive definite" % (j + 1))
@@ -766,7 +841,7 @@ class GP(object):
                 self._solve(y, need_alpha=True)
                 self._ensure_linv()
                 work = torch.empty(lib.apgp_grad_work_len(n), dtype=torch.float64, device=dev)
-                out = torch.empty(3 + _lib.MAX_DIM, dtype=torch.float64, device=dev)
+                out = torch.empty(4 + _lib.MAX_DIM, dtype=torch.float64, device=dev)
                 np64 = (n + 63) // 64 * 64
                 _lib.check(lib.apgp_grad_loglik(self._x_d.data_ptr(), self._alpha.data_ptr(),
                                                 self._work.data_ptr(), np64, n, ctypes.byref(ks),
@@ -788,12 +863,19 @@ class GP(object):
             # d/d white_noise = 0.5 * exp(wn) * trace(alpha alpha^T - K^-1)  
             grad.append(float(np.exp(self.white_noise.value)) * o[2 + _lib.MAX_DIM])
 
-        def walk(k):
-            if isinstance(k, Product):
-                walk(k.k1); walk(k.k2)
+        o_lin = o[3 + _lib.MAX_DIM]       # 0.5 sum A K_lin
+
+        def walk(k, in_linear_term):
+            if isinstance(k, Sum):
+                for term in (k.k1, k.k2):
+                    walk(term, _flatten_term(term)[2] is not None)
+            elif isinstance(k, Product):
+                walk(k.k1, in_linear_term); walk(k.k2, in_linear_term)
             elif isinstance(k, ConstantKernel):
-                grad.append(o[1])
+                grad.append(o_lin if in_linear_term else o[1])     # d/d log_constant = that term
+            elif isinstance(k, LinearKernel):
+                grad.append(-o_lin)                                # d/d log_gamma2 = -K_lin
             else:
                 grad.extend(o[2:2 + ndim])
-        walk(self.kernel)
+        walk(self.kernel, False)
         return np.array(grad, dtype=np.float64)

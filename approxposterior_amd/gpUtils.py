@@ -54,8 +54,8 @@ def defaultGP(theta, y, order=None, white_noise=-12, fitAmp=False):
     amplitude ``var(y)``, constant mean ``median(y)`` and fixed white noise,
     factorised on the GPU (gpUtils.py:114-181).
 
-    ``order`` (an additional LinearKernel, gpUtils.py:167-173) is not on the
-    MI355X hot path and raises ``NotImplementedError``.
+    ``order`` adds ``(var(y)/10) * LinearKernel(log_gamma2=initialMetric[0], order)``
+    as the reference does (gpUtils.py:167-173); integer orders only on the device.
     """
     theta = np.asarray(theta).squeeze()
     y = np.asarray(y).squeeze()
@@ -67,9 +67,8 @@ def defaultGP(theta, y, order=None, white_noise=-12, fitAmp=False):
     if fitAmp:
         kernel = np.var(y) * kernel
     if order is not None:
-        raise NotImplementedError(
-            "defaultGP(order=...) adds a george LinearKernel (gpUtils.py:169-173); "
-            "that kernel is not part of the MI355X hot path")
+        kernel = kernel + (np.var(y) / 10.0) * george.kernels.LinearKernel(
+            log_gamma2=initialMetric[0], order=order, bounds=None, ndim=ndim)
     gp = george.GP(kernel=kernel, fit_mean=True, mean=np.median(y),
                    white_noise=white_noise, fit_white_noise=False)
     gp.compute(theta)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define APGP_ABI_VERSION 1
+#define APGP_ABI_VERSION 2
 #define APGP_MAX_DIM 16          /* feature dimension D supported by the kernels */
 #define APGP_ROW_BLOCK 512       /* rows per packed L^-1 row block (sweep tile)  */
 #define APGP_K_CHUNK 16          /* contraction depth per packed tile            */
@@ -43,20 +43,26 @@ extern "C" {
 #define APGP_UTIL_NONE 3         /* predict only (george.GP.predict)        */
 
 /*
- * ExpSquared(+Constant) kernel hyper-parameters in evaluated form
- * (george.kernels.ExpSquaredKernel with axis-aligned metric, optionally
- * ``c * kernel``; gpUtils.py:160-165):
+ * ExpSquared(+Constant)(+Constant*Linear) kernel hyper-parameters in evaluated
+ * form (george.kernels.ExpSquaredKernel with axis-aligned metric, optionally
+ * ``c * kernel``, optionally ``+ c2 * LinearKernel(log_gamma2, order)``;
+ * gpUtils.py:160-173):
  *   k(x,x') = amp * exp(-0.5 * sum_d (x_d-x'_d)^2 * inv_metric[d])
+ *           + lin_coef * sum_d (x_d * x'_d)^lin_order
  *   amp        = ndim*exp(log_constant) when fitAmp, else 1
  *   inv_metric = exp(-log_M_d_d)
+ *   lin_coef   = ndim*exp(log_constant2) * exp(-log_gamma2); 0 = no linear term.
+ *                The per-axis sum is george's convention for non-stationary
+ *                kernels; no reference test pins it for order > 1.
  *   diag_add   = yerr^2 + exp(white_noise), added to K_ii only (never to k(t,t))
  */
 typedef struct apgp_kernel {
     int32_t ndim;
-    int32_t _pad;
+    int32_t lin_order;   /* integer power P >= 0 of the linear-regression term */
     double amp;
     double diag_add;
     double inv_metric[APGP_MAX_DIM];
+    double lin_coef;
 } apgp_kernel_t;
 
 /* Result record of apgp_acquire (device or host memory, 16 bytes). */
@@ -233,7 +239,9 @@ int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kernel_t* kern 
  *   out[0] = sum(alpha) (d/d mean), out[1] = d/d log_constant (amp part),
  *   out[2+d] = d/d log_M_d_d (d < ndim),
  *   out[2+APGP_MAX_DIM] = 0.5 * trace(alpha alpha^T - K^-1): times exp(white_noise)
- *   it is d/d white_noise (george fit_white_noise=True).  out: 3 + APGP_MAX_DIM doubles. */
+ *   it is d/d white_noise (george fit_white_noise=True),
+ *   out[3+APGP_MAX_DIM] = 0.5 * sum_ij (alpha alpha^T - K^-1)_ij K_lin_ij: d/d log_constant
+ *   of the linear term, and minus d/d log_gamma2.  out: 4 + APGP_MAX_DIM doubles.   */
 int64_t apgp_grad_work_len(int64_t n);
 int apgp_grad_loglik(const double* X, const double* alpha, const double* winv, int64_t ldw,
                      int64_t n, const apgp_kernel_t* kern /*host*/,

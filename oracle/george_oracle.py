@@ -90,6 +90,13 @@ class Kernel(object):
 
     __mul__ = __rmul__
 
+    def __add__(self, other):
+        # george: kernel + kernel -> Sum (gpUtils.py:170)
+        return Sum(self, other)
+
+    def __radd__(self, other):
+        return Sum(other, self)
+
     def __len__(self):
         return len(self.get_parameter_vector())
 
@@ -215,11 +222,67 @@ class Product(Kernel):
         return np.concatenate([g1, g2], axis=2)
 
 
+class LinearKernel(Kernel):
+    """george.kernels.LinearKernel(log_gamma2, order, bounds, ndim), used only by
+    defaultGP(order=...) (gpUtils.py:170-173).  george's source is not available here
+    and NO reference test exercises it: "parity unpinned".  Restated from george's
+    published docs, k = (x . x')^P / gamma^2, with the per-axis evaluation george uses
+    for its non-stationary kernels (the same convention that makes the ConstantKernel
+    evaluate to ndim*exp(log_constant), pinned by test_InitGP.py:43 + test_GPUtil.py):
+        k(x, x') = sum_d (x_d x'_d)^P / gamma^2.
+    For P = 1 both readings coincide; for P > 1 this is an assumption.
+    Parameter: log_gamma2; ``order`` is a constant."""
+
+    def __init__(self, log_gamma2=None, order=None, bounds=None, ndim=1, axes=None):
+        self.log_gamma2 = float(log_gamma2)
+        self.order = int(order)
+        self.ndim = int(ndim)
+        self.dirty = True
+
+    def get_parameter_names(self):
+        return ("log_gamma2",)
+
+    def get_parameter_vector(self):
+        return np.array([self.log_gamma2])
+
+    def set_parameter_vector(self, v):
+        self.log_gamma2 = float(v[0])
+        self.dirty = True
+
+    def get_value(self, x1, x2=None, diag=False):
+        ig2 = np.exp(-self.log_gamma2)
+        if diag:
+            return ig2 * np.sum((x1 * x1) ** self.order, axis=1)
+        if x2 is None:
+            x2 = x1
+        out = np.zeros((len(x1), len(x2)))
+        for d in range(self.ndim):
+            out += (x1[:, d][:, None] * x2[:, d][None, :]) ** self.order
+        return ig2 * out
+
+    def get_gradient(self, x1):
+        # d k / d log_gamma2 = -k
+        return -self.get_value(x1)[:, :, None]
+
+
+class Sum(Product):
+    """george.kernels.Sum: parameter protocol of Product, values add."""
+
+    def get_value(self, x1, x2=None, diag=False):
+        return (self.k1.get_value(x1, x2, diag=diag) +
+                self.k2.get_value(x1, x2, diag=diag))
+
+    def get_gradient(self, x1):
+        return np.concatenate([self.k1.get_gradient(x1), self.k2.get_gradient(x1)], axis=2)
+
+
 class _KernelsNamespace(object):
     """Stands in for the ``george.kernels`` module (gpUtils.py:160)."""
     ExpSquaredKernel = ExpSquaredKernel
     ConstantKernel = ConstantKernel
+    LinearKernel = LinearKernel
     Product = Product
+    Sum = Sum
 
 
 kernels = _KernelsNamespace()

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_abi_version_and_sizes():
     lib = _lib.load()
-    assert lib.apgp_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.apgp_abi_version() == _lib.ABI_VERSION == 2
     assert lib.apgp_npad(1) == 512 and lib.apgp_npad(512) == 512 and lib.apgp_npad(513) == 1024
     # packed L^-1: row block ib holds (ib+1)*32 tiles of 512 x 16 doubles
     for n, nrb in ((100, 1), (4096, 8), (4097, 9)):
@@ -37,8 +37,8 @@ def test_abi_version_and_sizes():
     assert lib.apgp_packed_train_len(4096, 8) == 4096 * 10
     assert lib.apgp_packed_train_len(100, 3) == 512 * 6
     assert lib.apgp_trtri_work_len(100) == 2 * 128 * 128
-    assert lib.apgp_grad_work_len(64) == 64 * 64 + 17
-    assert ctypes.sizeof(_lib.KernelStruct) == 8 + 16 + 16 * 8
+    assert lib.apgp_grad_work_len(64) == 64 * 64 + 18
+    assert ctypes.sizeof(_lib.KernelStruct) == 8 + 16 + 16 * 8 + 8
     assert ctypes.sizeof(_lib.BestStruct) == 16
 
 

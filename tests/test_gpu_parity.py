@@ -175,6 +175,62 @@ def test_fit_white_noise_protocol_and_gradient(lib_loaded):
     assert np.allclose(gp.grad_log_likelihood(y), gpo.grad_log_likelihood(y), rtol=1e-9, atol=1e-9 * np.abs(go_).max())
 
 
+@pytest.mark.parametrize("order,fit_amp,n,d", [(1, False, 150, 3), (2, True, 150, 3), (1, True, 700, 8), (0, False, 60, 2)])
+def test_linear_kernel_term_parity(order, fit_amp, n, d, lib_loaded):
+    """defaultGP(order=...): ExpSquared [x amplitude] + c * LinearKernel (gpUtils.py:167-173)
+    through every device kernel that evaluates k(x,x') -- Gram/Cholesky (ll), K4 (gradient incl.
+    the two linear-term parameters), the sweep (mu, sigma^2 with the candidate-dependent k(t,t),
+    utilities, arg-min), the solve-based sweep, the mean-only kernel and the cross kernel of the
+    incremental factor extension -- against the oracle (the reference has no test with order !=
+    None: 'parity unpinned', see oracle LinearKernel)."""
+    go, agp = _mods()
+    rs = np.random.RandomState(20 + order)
+    X = rs.uniform(-2, 2, size=(n, d))
+    y = X[:, 0] - 0.5 * X[:, 1] + np.sin(X).sum(axis=1) + 0.01 * rs.normal(size=n)
+    def make(mod):
+        k = mod.ExpSquaredKernel(np.linspace(0.8, 2.0, d), ndim=d)
+        if fit_amp:
+            k = 2.0 * k
+        k = k + 0.3 * mod.kernels.LinearKernel(log_gamma2=0.4, order=order, bounds=None, ndim=d)
+        return mod.GP(kernel=k, fit_mean=True, mean=0.1, white_noise=-8.0, fit_white_noise=False)
+    gpo, gp = make(go), make(agp)
+    gpo.compute(X); gp.compute(X)
+    llo = gpo.log_likelihood(y)
+    cond = np.linalg.cond(gpo.kernel.get_value(X) + np.exp(-8.0) * np.eye(n))
+    tol = max(1e-11, 500 * cond * EPS)
+    assert abs(gp.log_likelihood(y) - llo) <= tol * abs(llo)
+    g, g0 = gp.grad_log_likelihood(y), gpo.grad_log_likelihood(y)
+    assert np.allclose(g, g0, rtol=tol, atol=tol * np.abs(g0).max())
+    T = rs.uniform(-2.2, 2.2, size=(333, d))
+    mo, vo = gpo.predict(y, T, return_var=True)
+    scale = np.abs(gpo.kernel.get_value(T, diag=True)).max()
+    for mode in ("inverse", "solve"):
+        os.environ["APGP_VARIANCE"] = mode
+        try:
+            mu, var = gp.predict(y, T, return_var=True)
+        finally:
+            os.environ.pop("APGP_VARIANCE")
+        assert np.abs(mu - mo).max() <= tol * max(1.0, np.abs(mo).max()) * 10
+        assert np.abs(var - vo).max() <= tol * scale * 10
+    assert np.abs(gp.predict(y, T, return_cov=False) - mo).max() <= tol * max(1.0, np.abs(mo).max()) * 10
+    bi, bu, u, _, _ = gp.acquire(y, T, "agp", bounds=[(-2, 2)] * d, return_all=True)
+    uo = -(mo + 0.5 * np.log(2 * np.pi * np.e * vo))
+    uo[np.any(np.abs(T) > 2, axis=1)] = np.inf
+    fin = np.isfinite(uo)
+    assert np.array_equal(np.isfinite(u), fin) and np.abs(u[fin] - uo[fin]).max() <= 1e-6 * np.abs(uo[fin]).max()
+    assert bi == int(np.argmin(np.where(np.isfinite(u), u, np.inf)))
+    # the on-device ensemble sampler evaluates the same mean (log-probability of its final state)
+    res = gp.sample_ensemble(y, rs.uniform(-1, 1, size=(4 * d, d)), 40, [(-2, 2)] * d, seed=9)
+    assert np.abs(res["final_log_prob"] - gpo.predict(y, res["coords"], return_cov=False)).max() \
+        <= tol * max(1.0, np.abs(mo).max()) * 10
+    # incremental extension (kernel_cross) with the linear term
+    Xn = np.vstack([X, rs.uniform(-2, 2, size=(3, d))])
+    yn = np.concatenate([y, [0.3, -0.2, 0.9]])
+    gp2, gpo2 = make(agp), make(go)
+    gp2.compute(Xn, previous=gp); gpo2.compute(Xn)
+    assert abs(gp2.log_likelihood(yn) - gpo2.log_likelihood(yn)) <= 10 * tol * abs(gpo2.log_likelihood(yn))
+
+
 def test_reference_known_answers(golden_dir, lib_loaded):
     """The reference's own known-answer constants (test_InitGP.py:43,76;
     test_GPUtil.py:50-62,101-113) through the HIP-backed defaultGP + utilities."""

@@ -171,3 +171,29 @@ def test_approxposterior_input_validation():
         approx.ApproxPosterior(theta=th, y=y, bounds=((-5, 5),) * 2, algorithm="nope", **kw)
     ap = approx.ApproxPosterior(theta=th, y=y, bounds=((-5, 5),) * 2, algorithm="Alternate", **kw)
     assert ap.utility is ut.AGPUtility and ap.ndim == 2
+
+
+def test_linear_kernel_sum_protocol_and_flattening():
+    """defaultGP(order=...) kernel tree (gpUtils.py:167-173): same names / order / values
+    as the oracle's george restatement, and the evaluated form handed to the C ABI."""
+    def make(mod, fit_amp):
+        k = mod.ExpSquaredKernel(np.array([1.5, 0.7, 2.0]), ndim=3)
+        if fit_amp:
+            k = 2.0 * k
+        return k + 0.3 * mod.kernels.LinearKernel(log_gamma2=0.4, order=2, bounds=None, ndim=3)
+    for fit_amp in (False, True):
+        ko, ka = make(go, fit_amp), make(agp, fit_amp)
+        assert ka.get_parameter_names() == ko.get_parameter_names()
+        assert np.allclose(ka.get_parameter_vector(), ko.get_parameter_vector())
+        amp, log_M, lin_coef, lin_order = agp._flatten_kernel(ka, with_linear=True)
+        assert amp == pytest.approx(2.0 if fit_amp else 1.0) and lin_order == 2
+        assert lin_coef == pytest.approx(0.3 * np.exp(-0.4))        # ndim*exp(log(c/ndim)) / gamma^2
+        assert np.allclose(log_M, np.log([1.5, 0.7, 2.0]))
+        p = ka.get_parameter_vector() + 0.1
+        ka.set_parameter_vector(p); ko.set_parameter_vector(p)
+        assert np.allclose(ka.get_parameter_vector(), ko.get_parameter_vector()) and ka.dirty
+    assert agp._flatten_kernel(agp.ExpSquaredKernel([1.0], ndim=1), with_linear=True)[2:] == (0.0, 0)
+    with pytest.raises(NotImplementedError):
+        agp.kernels.LinearKernel(log_gamma2=0.0, order=1.5, ndim=2)
+    with pytest.raises(NotImplementedError):
+        agp._flatten_kernel(agp.kernels.LinearKernel(log_gamma2=0.0, order=1, ndim=2))   # no SE term

@@ -166,3 +166,39 @@ def test_oracle_white_noise_gradient_finite_difference():
         pm = p0.copy(); pm[i] -= h
         gp.set_parameter_vector(pm); lm = gp.log_likelihood(y)
         assert np.isclose((lp - lm) / (2 * h), grad[i], rtol=1e-5, atol=1e-6), (i, grad[i])
+
+
+@pytest.mark.parametrize("order,fit_amp", [(1, False), (2, True), (0, False)])
+def test_oracle_linear_kernel_sum_gradient_finite_difference(order, fit_amp):
+    """defaultGP(order=...) (gpUtils.py:167-173): ExpSquared [x amplitude] + c * LinearKernel.
+    george is absent and the reference has no test with order != None ('parity unpinned',
+    see the LinearKernel docstring for the assumed per-axis form): the oracle's parameter
+    protocol follows george's Sum/Product naming and its gradient matches central differences."""
+    rs = np.random.RandomState(4)
+    X = rs.uniform(-2, 2, size=(40, 3))
+    y = X[:, 0] - 0.5 * X[:, 1] + np.sin(X[:, 2]) + 0.01 * rs.normal(size=40)
+    k = go.ExpSquaredKernel(np.array([1.5, 0.7, 2.0]), ndim=3)
+    if fit_amp:
+        k = 2.0 * k
+    k = k + 0.3 * go.kernels.LinearKernel(log_gamma2=0.4, order=order, bounds=None, ndim=3)
+    gp = go.GP(kernel=k, fit_mean=True, mean=0.1, white_noise=-6.0, fit_white_noise=False)
+    names = gp.get_parameter_names()
+    assert names[-2:] == ("kernel:k2:k1:log_constant", "kernel:k2:k2:log_gamma2")
+    assert names[1] == ("kernel:k1:k1:log_constant" if fit_amp else "kernel:k1:metric:log_M_0_0")
+    gp.compute(X)
+    p0 = gp.get_parameter_vector()
+    grad = gp.grad_log_likelihood(y)
+    for i in range(len(p0)):
+        h = 1e-5
+        pp = p0.copy(); pp[i] += h
+        gp.set_parameter_vector(pp); lp = gp.log_likelihood(y)
+        pm = p0.copy(); pm[i] -= h
+        gp.set_parameter_vector(pm); lm = gp.log_likelihood(y)
+        assert np.isclose((lp - lm) / (2 * h), grad[i], rtol=2e-5, atol=1e-6), (i, grad[i])
+    gp.set_parameter_vector(p0)
+    # predictive variance uses k(t,t) of the FULL kernel (no white noise)
+    t = rs.uniform(-2, 2, size=(5, 3))
+    mu, var = gp.predict(y, t, return_var=True)
+    Kxs = gp.kernel.get_value(t, X)
+    Kinv = np.linalg.inv(gp.kernel.get_value(X) + np.exp(-6.0) * np.eye(40))
+    assert np.allclose(var, np.diag(gp.kernel.get_value(t)) - np.einsum("ij,jk,ik->i", Kxs, Kinv, Kxs), atol=1e-9)
