@@ -59,6 +59,12 @@ struct SweepArgs {
     long long* part_i;
     double* kcache;            // parked B operands: SW_GRID slots x ncache chunks x SW_BCH
     unsigned linv_bytes, xs_bytes, kslot_bytes;   // buffer-descriptor extents
+    // candidate blocks [blk_begin, blk_end) of this launch; split != 0: one workgroup per
+    // (candidate block, row block), partial sums to sp_q / sp_mu (the short last round)
+    long long blk_begin, blk_end;
+    double* sp_q;
+    double* sp_mu;
+    int split;
     long long m, idx_offset;
     int ndim, nrb, kind, has_box, n, ncache, lin_order;
     double mean, amp, zeta, ybest, lin_coef;
@@ -225,9 +231,13 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     auto nkc_of = [&](int ib) { const int v = CPB * (ib + 1); return v < kc_lim ? v : kc_lim; };
     auto successor = [&](int& ib, int& kc) {
         ++kc;
-        if (kc >= nkc_of(ib)) { ++ib; kc = 0; }
+        if (kc >= nkc_of(ib)) { ib = a.split ? ib : ib + 1; kc = 0; }
         if (ib >= a.nrb) { ib = 0; kc = 0; }
     };
+    // split launch: workgroups are dealt heaviest row block first (row block ib costs ib + 1
+    // units): blockIdx = (nrb - 1 - ib) * nblocks + block
+    const unsigned sp_nb = (unsigned)(a.blk_end - a.blk_begin);
+    const int ib_first = a.split ? a.nrb - 1 - (int)(blockIdx.x / sp_nb) : 0;
     // A fragments of one sub-block pair: per 16-row sub-block two ds_read_b128 fetch
     // the four k-steps of the lane's row (half-tile layout [s][kp][lane][q]).
     f64x2 av[2][2][2];
@@ -251,17 +261,17 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
 
     // ---- pipeline prologue: tile (0,0) ------------------------------------------
     {
-        int ib1 = 0, kc1 = 0;
+        int ib1 = ib_first, kc1 = 0;
         successor(ib1, kc1);
-        const long long t1 = tile_index(ib1, kc1);
+        const long long t0 = tile_index(ib_first, 0), t1 = tile_index(ib1, kc1);
 #pragma unroll
-        for (int q = 0; q < NST; ++q) R[q] = gpiece(0, 0, q);
+        for (int q = 0; q < NST; ++q) R[q] = gpiece(t0, 0, q);
 #pragma unroll
         for (int q = 0; q < NST; ++q) *lpiece(0, q) = R[q];
-        *lpiece(1, 0) = gpiece(0, 1, 0);
+        *lpiece(1, 0) = gpiece(t0, 1, 0);
         // what the (virtual) tile before would have requested, see stage()
 #pragma unroll
-        for (int pr = 0; pr < 7; ++pr) R[pr] = gpiece(0, 1, pr + 1);
+        for (int pr = 0; pr < 7; ++pr) R[pr] = gpiece(t0, 1, pr + 1);
 #pragma unroll
         for (int pr = 7; pr < 15; ++pr) R[pr] = gpiece(t1, 0, pr - 7);
         R[15] = gpiece(t1, 1, 0);
@@ -273,8 +283,10 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     int h0 = 0;          // ring slot of the current tile's first half
     int xb = 0;          // x-chunk buffer of the current tile
 
-    const long long nblk = (a.m + SW_CAND - 1) / SW_CAND;
-    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long blk_first = a.blk_begin + (a.split ? (long long)(blockIdx.x % sp_nb) : (long long)blockIdx.x);
+    const long long blk_step = a.split ? (a.blk_end - a.blk_begin + 1) : (long long)gridDim.x;
+    const int ib_lo = ib_first, ib_hi = a.split ? ib_first + 1 : a.nrb;
+    for (long long blk = blk_first; blk < a.blk_end; blk += blk_step) {
     // ---- candidate of this lane (scaled coordinates parked in LDS: only the
     //      generating tiles need them, and VGPRs are the scarce resource) --------
     {
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
         Mp[t] = 0.0;
     }
 
-    for (int ib = 0; ib < a.nrb; ++ib) {
+    for (int ib = ib_lo; ib < ib_hi; ++ib) {
         const int nkc = nkc_of(ib);
         const int nparked = CPB * ib;          // chunks generated by an earlier row block
         // drain the vector-memory counter once per row block (s_waitcnt vmcnt(0)): whatever
@@ -520,21 +532,40 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
         const int nstraight = (a.n - SW_ROWS * ib >= SW_ROWS) ? nparked : 0;
         for (; kc < nstraight; ++kc) do_tile(std::false_type{});
         for (; kc < nkc; ++kc) do_tile(std::true_type{});
-        // row block finished: fold ||V||^2 into the per-candidate sum
-        // (per rotation: the accumulators of rotation r belong to the candidate of the lane
-        // 4r further along the 16-lane row)
+        // row block finished: this row block's SHARE of sum V^2 and of mu, reduced over the
+        // lanes of a candidate, then added to the running totals in row-block order.  (The
+        // split last round stores the shares instead and sweep_finish_kernel adds them in the
+        // same order: a candidate's result does not depend on how it was scheduled.)
+        // The accumulators of rotation r belong to the candidate of the lane 4r further along
+        // the 16-lane row: rotate back (inverse rotation: 16 - 4r).
+        double qr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double qr = Qp[r * SW_THREADS + t];
+            qr[r] = 0.0;
 #pragma unroll
-            for (int s = 0; s < RS; ++s) qr = fma(acc[s][r], acc[s][r], qr);
-            Qp[r * SW_THREADS + t] = qr;
+            for (int s = 0; s < RS; ++s) qr[r] = fma(acc[s][r], acc[s][r], qr[r]);
+        }
+        double qs = qr[0] + rot16(qr[1], 3) + rot16(qr[2], 2) + rot16(qr[3], 1);
+        qs += __shfl_xor(qs, 16);
+        qs += __shfl_xor(qs, 32);
+        double ms = Mp[t];
+        ms += __shfl_xor(ms, 16);
+        ms += __shfl_xor(ms, 32);
+        Mp[t] = 0.0;
+        if (a.split) {
+            if (kq == 0) {
+                const long long e = ((blk - a.blk_begin) * SW_CAND + w * 16 + cl) * a.nrb + ib;
+                a.sp_q[e] = qs;
+                a.sp_mu[e] = ms;
+            }
+        } else {
+            Qp[t] += qs;
+            Qp[SW_THREADS + t] += ms;
         }
     }
-    // rotate the partial sums back to their candidates' lanes (inverse rotation: 16 - 4r)
-    double qpart = Qp[t] + rot16(Qp[SW_THREADS + t], 3) + rot16(Qp[2 * SW_THREADS + t], 2) +
-                   rot16(Qp[3 * SW_THREADS + t], 1);
-    double mupart = Mp[t];
+    if (a.split) continue;
+    double qpart = Qp[t];
+    double mupart = Qp[SW_THREADS + t];
     // recomputed behind an opaque barrier: CSE with the copy above would keep a 64-bit
     // VGPR alive (= spilled) across the whole tile stream
     int lane2 = t;
@@ -542,11 +573,6 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
     const long long crow = blk * SW_CAND + (lane2 >> 6) * 16 + (lane2 & 15);
     const bool adm = (Fl[t] & 1) != 0, has_nan = (Fl[t] & 2) != 0;
 
-    // ---- reduce over the four k-quarters / row-quarters of the wavefront ------
-    qpart += __shfl_xor(qpart, 16);
-    qpart += __shfl_xor(qpart, 32);
-    mupart += __shfl_xor(mupart, 16);
-    mupart += __shfl_xor(mupart, 32);
     double bu = INFINITY;
     long long bi = -1;
     if (kq == 0 && crow < a.m) {
@@ -607,29 +633,85 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
     }
 }
 
+// The short last round of the persistent grid (and every launch with fewer candidate blocks
+// than CUs) is split by ROW BLOCK: one workgroup per (candidate block, row block) writes its
+// share of sum V^2 and of mu, this kernel adds the shares in row-block order (deterministic)
+// and finishes mu / sigma^2 / utility / block arg-min exactly like the sweep's own epilogue.
+// A candidate block is a serial stream of all its tiles otherwise: 9 blocks left over for
+// 256 CUs would keep 247 of them idle for a whole block time.
+__global__ __launch_bounds__(64) void sweep_finish_kernel(SweepArgs a) {
+    const int c = threadIdx.x;
+    const long long blk = a.blk_begin + blockIdx.x;
+    const long long crow = blk * SW_CAND + c;
+    double bu = INFINITY;
+    long long bi = -1;
+    if (crow < a.m) {
+        bool adm = true, has_nan = false;
+        double ktl = a.lin_order == 0 ? (double)a.ndim : 0.0;
+        for (int d = 0; d < a.ndim; ++d) {
+            const double v = a.T[crow * a.ndim + d];
+            if (a.has_box && !(v >= a.lo[d] && v <= a.hi[d])) adm = false;
+            if (v != v) has_nan = true;
+            if (a.lin_coef != 0.0 && a.lin_order > 0) {
+                const double p = v * v;
+                double q = p;
+                for (int e = 1; e < a.lin_order; ++e) q *= p;
+                ktl += q;
+            }
+        }
+        if (a.mask && a.mask[crow] == 0) adm = false;
+        const long long e0 = ((long long)blockIdx.x * SW_CAND + c) * a.nrb;
+        double q = 0.0, mup = 0.0;
+        for (int ib = 0; ib < a.nrb; ++ib) { q += a.sp_q[e0 + ib]; mup += a.sp_mu[e0 + ib]; }
+        double mu = mup + a.mean;
+        double var = fma(a.lin_coef, ktl, a.amp) - q;
+        if (has_nan) { mu = NAN; var = NAN; }
+        if (a.mu) a.mu[crow] = mu;
+        if (a.var) a.var[crow] = var;
+        if (a.kind != APGP_UTIL_NONE) {
+            const double uu = adm ? util_value(a.kind, mu, var, a.zeta, a.ybest) : INFINITY;
+            if (a.u) a.u[crow] = uu;
+            best_merge(bu, bi, uu, a.idx_offset + crow);
+        }
+    }
+    if (a.kind == APGP_UTIL_NONE) return;
+    for (int o = 32; o > 0; o >>= 1) {
+        double ou = __shfl_xor(bu, o);
+        long long oi = __shfl_xor(bi, o);
+        best_merge(bu, bi, ou, oi);
+    }
+    if (c == 0) { a.part_u[blk] = bu; a.part_i[blk] = bi; }
+}
+
+// blocks of the last round that are split by row block: at most half a grid's worth
+#define SW_SPLIT_MAX (SW_GRID / 2)
+
 template <int DPAD>
-static int launch_sweep(const SweepArgs& a, hipStream_t s) {
+static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     const size_t lds = (3 * (SW_TILE / 2) + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + 8 + DPAD * SW_THREADS +
                         6 * SW_THREADS + SW_THREADS / 2 + 4 * APGP_MAX_DIM) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    SweepArgs a = a0;
     const long long ncb = (a.m + SW_CAND - 1) / SW_CAND;
-    const unsigned nblk = (unsigned)(ncb < SW_GRID ? ncb : SW_GRID);
     static int timing = -1;
     if (timing < 0) { const char* e = getenv("APGP_SWEEP_TIMING"); timing = (e && e[0] == '1') ? 1 : 0; }
     if (timing && DPAD == 8) {
         // developer instrumentation: per-phase s_memtime cycles of block 0 / wave 0
         static unsigned long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, 16 * sizeof(unsigned long long));
-        SweepArgs b = a;
-        b.dbg = dbg;
+        a.dbg = dbg;
+        a.blk_begin = 0; a.blk_end = ncb; a.split = 0;
         (void)hipFuncSetAttribute((const void*)sweep_kernel<8, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((sweep_kernel<8, true>), dim3(nblk), dim3(SW_THREADS), lds, s, b);
+        hipLaunchKernelGGL((sweep_kernel<8, true>), dim3((unsigned)(ncb < SW_GRID ? ncb : SW_GRID)),
+                           dim3(SW_THREADS), lds, s, a);
         unsigned long long h[8];
         (void)hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
@@ -640,17 +722,29 @@ static int launch_sweep(const SweepArgs& a, hipStream_t s) {
         }
         return 0;
     }
-    if (a.lin_coef != 0.0) {
-        static bool lin_attr_set = false;
-        if (!lin_attr_set) {
-            (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD, false, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            lin_attr_set = true;
-        }
-        hipLaunchKernelGGL((sweep_kernel<DPAD, false, true>), dim3(nblk), dim3(SW_THREADS), lds, s, a);
-        return 0;
+    auto launch = [&](unsigned grid) {
+        if (a.lin_coef != 0.0)
+            hipLaunchKernelGGL((sweep_kernel<DPAD, false, true>), dim3(grid), dim3(SW_THREADS), lds, s, a);
+        else
+            hipLaunchKernelGGL((sweep_kernel<DPAD, false>), dim3(grid), dim3(SW_THREADS), lds, s, a);
+    };
+    // full rounds on the persistent grid, then the remainder split by row block
+    static int split_on = -1;
+    if (split_on < 0) { const char* e = getenv("APGP_SWEEP_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
+    long long rest = ncb % SW_GRID;
+    if (!split_on || a.nrb < 2 || rest > SW_SPLIT_MAX || a.sp_q == NULL) rest = 0;
+    const long long full = ncb - rest;
+    if (full > 0) {
+        a.blk_begin = 0; a.blk_end = full; a.split = 0;
+        launch((unsigned)(full < SW_GRID ? full : SW_GRID));
     }
-    hipLaunchKernelGGL((sweep_kernel<DPAD, false>), dim3(nblk), dim3(SW_THREADS), lds, s, a);
+    if (rest > 0) {
+        a.blk_begin = full; a.blk_end = ncb; a.split = 1;
+        a.ncache = 0;                                 // no parking across workgroups
+        a.kcache = (double*)a.linv; a.kslot_bytes = SW_BCH * 8;
+        launch((unsigned)(rest * a.nrb));
+        hipLaunchKernelGGL(sweep_finish_kernel, dim3((unsigned)rest), dim3(64), 0, s, a);
+    }
     return 0;
 }
 
@@ -663,7 +757,8 @@ extern "C" int64_t apgp_acquire_work_len(int64_t m, int64_t n) {
     if (m < 1 || n < 1) return 0;
     const long long ncb = (m + SW_CAND - 1) / SW_CAND;
     const long long slots = ncb < SW_GRID ? ncb : SW_GRID;
-    return 2 * ncb + slots * sweep_ncache(n) * SW_BCH;
+    const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
+    return 2 * ncb + slots * sweep_ncache(n) * SW_BCH + 2 * (long long)SW_SPLIT_MAX * SW_CAND * nrb;
 }
 
 extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
@@ -694,6 +789,13 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     }
     // N <= 512: nothing is parked; the (unconditional, discarded) prefetch then reads the factor
     a.kcache = a.ncache > 0 ? (double*)part + 2 * nblk : (double*)packed_linv;
+    {   // row-block shares of the split last round (after the parked-operand slots)
+        const long long slots = nblk < SW_GRID ? nblk : SW_GRID;
+        const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
+        a.sp_q = part ? (double*)part + 2 * nblk + slots * sweep_ncache(n) * SW_BCH : NULL;
+        a.sp_mu = a.sp_q ? a.sp_q + (long long)SW_SPLIT_MAX * SW_CAND * nrb : NULL;
+        a.blk_begin = 0; a.blk_end = nblk; a.split = 0;
+    }
     {
         const long long wb = apgp_packed_linv_len(n) * 8, xb = apgp_packed_train_len(n, kc.ndim) * 8;
         const long long kb = a.ncache > 0 ? (long long)a.ncache * SW_BCH * 8 : SW_BCH * 8;

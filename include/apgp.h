@@ -173,7 +173,9 @@ int apgp_pack_train(const double* X, const double* alpha, int64_t n,
  * part: scratch of apgp_acquire_work_len(m, n) doubles, 16-byte aligned: the
  *       per-block arg-min partials plus, for n > APGP_ROW_BLOCK, the stream in
  *       which each persistent workgroup parks the k* operands it generated for
- *       one row block so that later row blocks do not regenerate them.
+ *       one row block so that later row blocks do not regenerate them, and the
+ *       per-row-block shares of the candidate blocks of a short last round
+ *       (those are split over one workgroup per row block).
  * best: device apgp_best_t, written by the final reduction kernel.
  * ybest = max(y) and zeta are used by JONES only.                            */
 int64_t apgp_acquire_work_len(int64_t m, int64_t n);
