@@ -11,22 +11,38 @@ stats = glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recurs
 if stats:
     shutil.copy(stats[0], os.path.join(root, "kernel_stats.csv"))
 
+# one acquire call = the persistent launch + (short last round) the row-block-split launch of
+# the same kernel + sweep_finish_kernel + argmin_final_kernel: counters are summed over a
+# call's sweep_kernel dispatches and averaged over the calls (= argmin_final_kernel dispatches)
 counters = {}
 for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
-    per = {}
+    tot, calls = {}, set()
     for row in csv.DictReader(open(f)):
-        if KERNEL not in row["Kernel_Name"]:
+        if "argmin_final_kernel" in row["Kernel_Name"]:
+            calls.add(row["Dispatch_Id"])
+        if KERNEL + "<" not in row["Kernel_Name"]:
             continue
-        per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
-        per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
-    for name, by_dispatch in per.items():
-        v = list(by_dispatch.values())
-        counters[name] = {"launches": len(v), "mean": sum(v) / len(v)}
+        tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    for name, v in tot.items():
+        counters[name] = {"launches": len(calls), "mean": v / max(len(calls), 1)}
+
+trace = glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True)
+sweep_ms = None
+if trace:
+    dur, calls = 0.0, 0
+    for row in csv.DictReader(open(trace[0])):
+        if KERNEL + "<" in row["Kernel_Name"] or "sweep_finish_kernel" in row["Kernel_Name"]:
+            dur += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
+        if "argmin_final_kernel" in row["Kernel_Name"]:
+            calls += 1
+    sweep_ms = dur / max(calls, 1)
 
 def c(name):
     return counters[name]["mean"] if name in counters else None
 
 derived = {}
+if sweep_ms is not None:
+    derived["sweep_kernels_ms_per_call"] = sweep_ms   # rocprofv3 kernel trace: all sweep launches of one call
 if c("FETCH_SIZE") is not None and c("WRITE_SIZE") is not None:
     # FETCH_SIZE / WRITE_SIZE are reported in KiB; gfx950 under-counts 16 B/lane read
     # streams by 2x (MI355X_MICROARCH.md, HBM section)
