@@ -683,8 +683,9 @@ __global__ __launch_bounds__(64) void sweep_finish_kernel(SweepArgs a) {
     if (c == 0) { a.part_u[blk] = bu; a.part_i[blk] = bi; }
 }
 
-// blocks of the last round that are split by row block: at most half a grid's worth
-#define SW_SPLIT_MAX (SW_GRID / 2)
+// blocks of the last round that are split by row block (measured break-even at N = 4096:
+// ~230 of 256 -- the split launch regenerates every k* and its largest item is 22 % of a block)
+#define SW_SPLIT_MAX 216
 
 template <int DPAD>
 static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
