@@ -339,6 +339,8 @@ __global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
         //    disabled), otherwise they were prefetched from the slot's scratch stream.
         auto do_tile = [&](auto pred_tag) {
             constexpr bool PRED = decltype(pred_tag)::value;
+            // (SW_X_NOGEN / NOSTAGE / NOBAR / NOLDS: developer builds for the elimination runs
+            // quoted in DESIGN.md -- results are wrong, the timing tells what a phase costs)
 #ifdef SW_X_NOGEN
             const bool gen = false;
 #else
