@@ -328,6 +328,50 @@ def test_oracle_parity_seeded(n, d, m, metric, lib_loaded):
         assert bi == -1
 
 
+@pytest.mark.parametrize("m", [5000, 40000])
+def test_multi_row_block_utilities_mask_nan(m, lib_loaded):
+    """N > 512 (several row blocks: parked operands, persistent + split launches) with everything
+    the epilogue handles: the three utilities against the reference's formulas (utility.py:136,
+    183 with logsubexp :85-88, 229-244) on the oracle's mu / sigma^2, the host mask, the box
+    prior, NaN coordinates (george propagates NaN; a NaN utility never wins)."""
+    from scipy.stats import norm
+    go, agp = _mods()
+    n, d = 1100, 3
+    X, y = _synthetic(n, d)
+    def make(mod):
+        return mod.GP(kernel=mod.ExpSquaredKernel(np.full(d, 3.0), ndim=d), fit_mean=True, mean=np.median(y),
+                      white_noise=-12, fit_white_noise=False)
+    gpo, gp = make(go), make(agp)
+    gpo.compute(X); gp.compute(X)
+    rs = np.random.RandomState(2)
+    T = rs.uniform(-5.3, 5.3, size=(m, d))
+    T[7, 1] = np.nan
+    T[m - 3, 0] = np.nan
+    mask = rs.uniform(size=m) > 0.1
+    ok = ~np.isnan(T).any(axis=1)
+    mo = np.full(m, np.nan); vo = np.full(m, np.nan)
+    mo[ok], vo[ok] = gpo.predict(y, T[ok], return_var=True)
+    inside = np.all(np.abs(np.nan_to_num(T)) <= 5, axis=1)
+    adm = inside & mask & ok
+    ybest = y.max()
+    with np.errstate(all="ignore"):
+        sd = np.sqrt(vo)
+        imp = mo - ybest - 0.01
+        want = {"agp": -(mo + 0.5 * np.log(2 * np.pi * np.e * vo)),
+                "bape": -((2 * mo + vo) + np.where(vo <= 0, -np.inf, vo + np.log(1 - np.exp(-vo)))),
+                "jones": np.where(sd > 0, -(imp * norm.cdf(imp / sd) + sd * norm.pdf(imp / sd)), 0.0)}
+    for kind, uo in want.items():
+        bi, bu, u, mu, var = gp.acquire(y, T, kind, bounds=[(-5, 5)] * d, mask=mask, return_all=True)
+        assert np.isnan(mu[~ok]).all() and np.isnan(var[~ok]).all()
+        assert np.abs(mu[ok] - mo[ok]).max() <= 1e-9 * np.abs(mo[ok]).max() and np.abs(var[ok] - vo[ok]).max() <= 1e-9
+        assert np.all(np.isposinf(u[~inside | ~mask]))
+        # the utilities amplify the sigma^2 rounding where sigma^2 is tiny: compare where it is not
+        sel = adm & (vo > 1e-6)
+        assert np.allclose(u[sel], uo[sel], rtol=1e-6, atol=1e-6 * np.abs(uo[sel]).max())
+        fin = np.where(np.isfinite(u) & adm, u, np.inf)
+        assert adm[bi] and bu == u[bi] and bi == int(np.argmin(fin))
+
+
 def test_full_size_properties(lib_loaded):
     """BASELINE.json C3 shape (N=4096, D=8): size-independent properties.
     (a) at a training point the posterior mean reproduces y and the variance
