@@ -635,6 +635,452 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
     }
 }
 
+// ===========================================================================
+// Two-role sweep (round 1e): 8 wavefronts per workgroup, two per SIMD.
+//   wavefronts 0-3 ("matrix" role, one per SIMD): nothing but the MFMA stream, the LDS reads
+//     of its operands and one barrier per tile.  256 rows x 16 candidates per wavefront
+//     (64 accumulators): the 256 unified registers of a two-wave-per-SIMD kernel hold them.
+//   wavefronts 4-7 ("feeder" role): everything else -- the packed-factor stream L2 -> registers
+//     -> LDS, the B operands (generated on the first visit of a chunk, otherwise fetched from
+//     the parked stream) written to LDS for the matrix wavefront of the same candidates, mu,
+//     the candidate setup and the utility / arg-min epilogue.
+// tools/mfma_pair.hip: the SIMD issues the older wavefront first, so a companion's LDS / VMEM /
+// integer traffic costs the MFMA wavefront nothing (16.25 -> 16.4 cycles per MFMA), while in
+// the one-wave design every such instruction's issue time is lost to the matrix pipe (~15 %).
+// Only the feeder's fp64 VALU work (k* generation) still competes for the shared DP pipe.
+// Tiles are the 256-row HALVES of the packed 512 x 16 tiles (same packed format): row block jb
+// = half jb & 1 of packed row block jb >> 1, chunks 0 .. 16 (jb + 1) - 1.
+// Synchronisation: tile i+1 (A image into slot (i+1) % 3, B operands into buffer (i+1) & 1) is
+// written by the feeders between barrier i-1 and barrier i; the matrix wavefronts execute
+// barrier i after the first k-step of pair 4 of tile i and read tile i+1 only after it.
+// ===========================================================================
+#define S2_THREADS 512
+#define S2_ROWS 256
+#define S2_TILE (S2_ROWS * SW_KC)        // doubles per tile image (32 KiB)
+#define S2_CPB (S2_ROWS / SW_KC)         // chunks per row-block width (16)
+#define S2_NP (S2_ROWS / 32)             // sub-block pairs per tile (8)
+
+template <int DPAD, bool LIN>
+__global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
+    constexpr int XS = DPAD + 2;
+    constexpr int NKK = SW_KC / 4;
+    constexpr int NP = S2_NP;
+    constexpr int XCHUNK16 = SW_KC * XS / 2;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Aring = smem;                         // 3 tile images
+    double* Bbuf = Aring + 3 * S2_TILE;           // 2 x 4 wavefronts x [2][64] x 16 B
+    double* Xbuf = Bbuf + 2 * 4 * 256;            // 2 x SW_KC x XS
+    double* Etab = Xbuf + 2 * SW_KC * XS;
+    double* Shq = Etab + APGP_EXP_TAB_N;          // sum V^2 per candidate (matrix -> feeder)
+    double* red_u = Shq + SW_CAND;
+    long long* red_i = (long long*)(red_u + 4);
+    double* Cst = red_u + 8;                      // sc | lo | hi | lw (4 x APGP_MAX_DIM), feeder only
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int cl = lane & 15, kq = lane >> 4;
+    apgp_exp_tab_load(Etab);
+    if (t == 256) {
+#pragma unroll
+        for (int d = 0; d < APGP_MAX_DIM; ++d) {
+            Cst[d] = a.sc[d];
+            Cst[APGP_MAX_DIM + d] = a.lo[d];
+            Cst[2 * APGP_MAX_DIM + d] = a.hi[d];
+            Cst[3 * APGP_MAX_DIM + d] = a.lw[d];
+        }
+    }
+
+    const int kc_lim = (a.n + SW_KC - 1) / SW_KC;
+    const int nrb2 = (a.n + S2_ROWS - 1) / S2_ROWS;
+    auto nkc_of = [&](int jb) { const int v = S2_CPB * (jb + 1); return v < kc_lim ? v : kc_lim; };
+    // byte offset of tile (jb, kc) in the packed factor: half jb & 1 of packed tile (jb >> 1, kc)
+    auto tile_off = [&](int jb, int kc) {
+        const int ib = jb >> 1;
+        const unsigned tile = (unsigned)((SW_ROWS / SW_KC) * ib * (ib + 1) / 2 + kc);
+        return tile * (unsigned)(SW_TILE * 8) + (unsigned)((jb & 1) * S2_TILE * 8);
+    };
+    // (jb, kc, block) -> successor in the stream: next chunk, next row block, next candidate block
+    auto successor = [&](int& jb, int& kc, long long& blk) {
+        ++kc;
+        if (kc >= nkc_of(jb)) { ++jb; kc = 0; }
+        if (jb >= nrb2) { jb = 0; blk += gridDim.x; }
+    };
+    const long long blk0 = a.blk_begin + blockIdx.x;
+
+    if (w < 4) {
+        // =============================== matrix role ===============================
+        // lane whose B value this lane multiplies in rotation r (block b meets candidate
+        // group b + r): the rotation is an LDS read address, not a register move
+        int lr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lr[r] = (lane & 48) | ((lane + 4 * r) & 15);
+        f64x2 av[2][2][2];
+        auto load_a = [&](f64x2 (&dst)[2][2], int slot, int p) {
+            const f64x2* A2 = (const f64x2*)(Aring + slot * S2_TILE) + lane;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) dst[h][kp] = A2[((p * 2 + h) * 2 + kp) * 64];
+        };
+        __syncthreads();                          // C : constants staged
+        __syncthreads();                          // P0: x chunks staged (feeders)
+        __syncthreads();                          // P : tile 0 published
+        int slot = 0, bpar = 0;
+#ifdef S2_TIMING
+        unsigned long long s2_wait = 0, s2_nt = 0, s2_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        load_a(av[0], 0, 0);
+        for (long long blk = blk0; blk < a.blk_end; blk += gridDim.x) {
+            double qtot = 0.0;
+            for (int jb = 0; jb < nrb2; ++jb) {
+                const int nkc = nkc_of(jb);
+                const int ndiag0 = S2_CPB * jb;
+                double acc[2 * NP][4];
+#pragma unroll
+                for (int s_ = 0; s_ < 2 * NP; ++s_)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[s_][r] = 0.0;
+                int kc = 0;
+                auto do_tile = [&](auto pred_tag) {
+                    constexpr bool PRED = decltype(pred_tag)::value;
+                    const int nslot = slot == 2 ? 0 : slot + 1;
+                    // B operands of this tile, all four rotations (published by the last barrier)
+                    double brot[4][NKK];
+                    {
+                        const f64x2* Bw = (const f64x2*)(Bbuf + bpar * 1024 + w * 256);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f64x2 b0 = Bw[lr[r]], b1 = Bw[64 + lr[r]];
+                            brot[r][0] = b0.x; brot[r][1] = b0.y; brot[r][2] = b1.x; brot[r][3] = b1.y;
+                        }
+                    }
+                    auto mfma_pair = [&](int pr, int kk) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[2 * pr][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                                av[pr & 1][0][kk >> 1][kk & 1], brot[r][kk], acc[2 * pr][r], 0, 0, 0);
+                            acc[2 * pr + 1][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                                av[pr & 1][1][kk >> 1][kk & 1], brot[r][kk], acc[2 * pr + 1][r], 0, 0, 0);
+                        }
+                    };
+                    int p0 = (kc - ndiag0) >> 1;
+                    if (p0 < 0) p0 = 0;
+                    int p1 = (a.n - S2_ROWS * jb + 31) >> 5;
+                    if (p1 > NP) p1 = NP;
+#pragma unroll
+                    for (int pr = 0; pr < NP; ++pr) {
+                        const bool act = !PRED || (pr >= p0 && pr < p1);
+                        if (act) mfma_pair(pr, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+#ifndef S2_X_NOBAR
+#ifdef S2_TIMING
+                        if (pr == 4) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); s2_wait += __builtin_amdgcn_s_memtime() - t0_; ++s2_nt; }
+#else
+                        if (pr == 4) __syncthreads();          // barrier i: tile i+1 is complete
+#endif
+#endif
+#ifndef S2_X_NOLDS
+                        if (pr + 1 < NP) load_a(av[(pr + 1) & 1], slot, pr + 1);
+                        else load_a(av[0], nslot, 0);
+#endif
+                        if (act) {
+                            mfma_pair(pr, 1);
+                            mfma_pair(pr, 2);
+                            mfma_pair(pr, 3);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    slot = nslot;
+                    bpar ^= 1;
+                };
+                const int nstraight = (a.n - S2_ROWS * jb >= S2_ROWS) ? ndiag0 : 0;
+                for (; kc < nstraight; ++kc) do_tile(std::false_type{});
+                for (; kc < nkc; ++kc) do_tile(std::true_type{});
+                // this row block's share of sum V^2: rotation r's accumulators belong to the
+                // candidate of lane lr[r]; gather them back, reduce over the 4 row-lanes
+                double qr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    qr[r] = 0.0;
+#pragma unroll
+                    for (int s_ = 0; s_ < 2 * NP; ++s_) qr[r] = fma(acc[s_][r], acc[s_][r], qr[r]);
+                }
+                double qs = qr[0];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) qs += __shfl(qr[r], (lane & 48) | ((lane - 4 * r) & 15));
+                qs += __shfl_xor(qs, 16);
+                qs += __shfl_xor(qs, 32);
+                qtot += qs;
+            }
+            if (kq == 0) Shq[w * 16 + cl] = qtot;
+            __syncthreads();                      // E1: sums visible to the feeders
+            __syncthreads();                      // E2: block result written
+        }
+#ifdef S2_TIMING
+        if (a.dbg && blockIdx.x == 0 && t == 0) { a.dbg[0] = s2_wait; a.dbg[1] = s2_nt; a.dbg[2] = __builtin_amdgcn_s_memtime() - s2_t0; }
+#endif
+        return;
+    }
+
+    // ================================= feeder role =================================
+    const int hw = w - 4, ht = t - 256;
+    const unsigned hoff = (unsigned)ht * 16u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.linv, 0, (int)a.linv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, (int)a.xs_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.kcache + (long long)blockIdx.x * a.ncache * SW_BCH), 0, (int)a.kslot_bytes, 0x00020000);
+    auto gpiece = [&](unsigned toffs, int q) {
+        return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_w, hoff, toffs + (unsigned)(q * 256 * 16), 0));
+    };
+    auto lpiece = [&](int slot, int q) { return (f64x2*)(Aring + slot * S2_TILE) + q * 256 + ht; };
+    // park the eight pieces of a tile image; the slot is a uniform run-time value, but an
+    // address computed from it would be a VALU instruction -- and a feeder VALU instruction
+    // waits ~32 cycles for an issue slot next to the MFMA stream (tools/mfma_pair.hip) --
+    // so there is one copy per slot with immediate offsets
+    auto put_tile = [&](int slot, const f64x2 (&R)[8]) {
+        if (slot == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *lpiece(0, q) = R[q];
+        } else if (slot == 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *lpiece(1, q) = R[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *lpiece(2, q) = R[q];
+        }
+    };
+    const unsigned xoff = ht < XCHUNK16 ? hoff : 0u;
+    auto x_fetch = [&](int kc) {
+        return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0));
+    };
+    auto x_put = [&](int xb, f64x2 v) {
+        if (ht < XCHUNK16) {
+            if (xb == 0) *((f64x2*)Xbuf + ht) = v;
+            else *((f64x2*)(Xbuf + SW_KC * XS) + ht) = v;
+        }
+    };
+    const int cmax = a.ncache > 0 ? a.ncache - 1 : 0;
+    const bool park = a.ncache > 0;
+    auto b_fetch = [&](int c, f64x2 (&bp)[2]) {
+        const unsigned soff = (unsigned)(c < cmax ? c : cmax) * (unsigned)(SW_BCH * 8);
+        bp[0] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, hoff, soff, SW_KAUX));
+        bp[1] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, hoff, soff + 256 * 16, SW_KAUX));
+    };
+    // per-candidate state of the block being fed (cur) and of the finished one (fin)
+    double tt[DPAD];
+    double ktt_cur = a.amp, ktt_fin = a.amp, mu_cur = 0.0, mu_fin = 0.0;
+    int fl_cur = 0, fl_fin = 0;
+    long long blk_cur = -1, blk_fin = -1;
+    auto load_candidates = [&](long long blk) {
+        // snapshot the finished block, then set up the new one
+        double m = mu_cur;
+        m += __shfl_xor(m, 16);
+        m += __shfl_xor(m, 32);
+        mu_fin = m; ktt_fin = ktt_cur; fl_fin = fl_cur; blk_fin = blk_cur;
+        blk_cur = blk; mu_cur = 0.0;
+        const long long crow = blk * SW_CAND + hw * 16 + cl;
+        const bool inb = blk < a.blk_end && crow < a.m;
+        bool adm = inb, has_nan = false;
+        double ktl = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;
+#pragma unroll
+        for (int d = 0; d < DPAD; ++d) {
+            double v = 0.0;
+            if (inb && d < a.ndim) {
+                v = a.T[crow * a.ndim + d];
+                if (a.has_box && !(v >= Cst[APGP_MAX_DIM + d] && v <= Cst[2 * APGP_MAX_DIM + d])) adm = false;
+                if (v != v) has_nan = true;
+            }
+            tt[d] = v * Cst[d];
+            if (LIN && a.lin_order > 0) {
+                const double p = v * v;
+                double q = p;
+                for (int e = 1; e < a.lin_order; ++e) q *= p;
+                ktl += q;
+            }
+        }
+        if (inb && a.mask && a.mask[crow] == 0) adm = false;
+        fl_cur = (adm ? 1 : 0) | (has_nan ? 2 : 0) | (inb ? 4 : 0);
+        ktt_cur = LIN ? fma(a.lin_coef, ktl, a.amp) : a.amp;
+    };
+    // B operands of tile (jb, kc) of the current block -> LDS buffer bb (and the parked stream)
+    auto produce_b = [&](int jb, int kc, int bb, int xb, const f64x2 (&bp)[2]) {
+#ifdef S2_X_NOGEN
+        const bool gen = false;
+#else
+        const bool gen = !park || kc >= S2_CPB * jb;
+#endif
+        double bfv[NKK];
+        if (gen) {
+            const double* Xb = Xbuf + xb * SW_KC * XS;
+            double s2[NKK], s3[NKK], al[NKK], lsum[NKK];
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                s2[kk] = 0.0; s3[kk] = 0.0;
+                lsum[kk] = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;
+                al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
+            }
+#pragma unroll
+            for (int d = 0; d < DPAD; d += 2)
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const f64x2 xa = *(const f64x2*)(Xb + (kk * 4 + kq) * XS + d);
+                    const double df0 = tt[d] - xa.x, df1 = tt[d + 1] - xa.y;
+                    s2[kk] = fma(df0, df0, s2[kk]);
+                    s3[kk] = fma(df1, df1, s3[kk]);
+                    if (LIN && a.lin_order > 0) {
+                        const double p0_ = tt[d] * xa.x * Cst[3 * APGP_MAX_DIM + d], p1_ = tt[d + 1] * xa.y * Cst[3 * APGP_MAX_DIM + d + 1];
+                        double q0 = p0_, q1 = p1_;
+                        for (int e = 1; e < a.lin_order; ++e) { q0 *= p0_; q1 *= p1_; }
+                        lsum[kk] += q0 + q1;
+                    }
+                }
+            double ex[NKK];
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) ex[kk] = -(s2[kk] + s3[kk]);
+            apgp_exp4(ex, bfv, Etab);
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) bfv[kk] = LIN ? fma(a.lin_coef, lsum[kk], bfv[kk] * a.amp) : bfv[kk] * a.amp;
+            if (kc >= S2_CPB * jb) {
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) mu_cur = fma(bfv[kk], al[kk], mu_cur);
+                if (park && jb + 1 < nrb2) {
+                    const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
+                    f64x2 q0, q1;
+                    q0.x = bfv[0]; q0.y = bfv[1]; q1.x = bfv[2]; q1.y = bfv[3];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_k, hoff, soff, SW_KAUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_k, hoff, soff + 256 * 16, SW_KAUX);
+                }
+            }
+            f64x2 o0, o1;
+            o0.x = bfv[0]; o0.y = bfv[1]; o1.x = bfv[2]; o1.y = bfv[3];
+            if (bb == 0) { f64x2* Bw = (f64x2*)(Bbuf + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
+            else { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
+        } else {
+            // parked operands go straight from the load registers to LDS
+            if (bb == 0) { f64x2* Bw = (f64x2*)(Bbuf + hw * 256); Bw[lane] = bp[0]; Bw[64 + lane] = bp[1]; }
+            else { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = bp[0]; Bw[64 + lane] = bp[1]; }
+        }
+    };
+    auto epilogue = [&]() {
+        __syncthreads();                          // E1
+        double bu = INFINITY;
+        long long bi = -1;
+        const long long crow = blk_fin * SW_CAND + hw * 16 + cl;
+        if (kq == 0 && (fl_fin & 4)) {
+            double mu = mu_fin + a.mean;
+            double var = ktt_fin - Shq[hw * 16 + cl];
+            if (fl_fin & 2) { mu = NAN; var = NAN; }
+            if (a.mu) a.mu[crow] = mu;
+            if (a.var) a.var[crow] = var;
+            if (a.kind != APGP_UTIL_NONE) {
+                const double uu = (fl_fin & 1) ? util_value(a.kind, mu, var, a.zeta, a.ybest) : INFINITY;
+                if (a.u) a.u[crow] = uu;
+                best_merge(bu, bi, uu, a.idx_offset + crow);
+            }
+        }
+        for (int o = 8; o > 0; o >>= 1) {
+            double ou = __shfl_xor(bu, o);
+            long long oi = __shfl_xor(bi, o);
+            best_merge(bu, bi, ou, oi);
+        }
+        if (lane == 0) { red_u[hw] = bu; red_i[hw] = bi; }
+        __syncthreads();                          // E2
+        if (ht == 0 && a.kind != APGP_UTIL_NONE) {
+            for (int i = 1; i < 4; ++i) best_merge(bu, bi, red_u[i], red_i[i]);
+            a.part_u[blk_fin] = bu;
+            a.part_i[blk_fin] = bi;
+        }
+    };
+
+    // ---- the feeder loop -------------------------------------------------------------------
+    // Next to a saturated MFMA stream every feeder instruction waits for an issue slot (~10
+    // cycles for a scalar one, ~100 for one that reads or writes VGPRs; tools/mfma_pair.hip),
+    // so the per-tile work is a handful of LDS-DMA requests (buffer_load ... lds: no data
+    // VGPRs, no ds_write) and scalar bookkeeping.  Tile i+1's image and parked operands are
+    // requested right after barrier i-1 into slot (i+1) % 3 / buffer (i+1) & 1 -- both free
+    // since barrier i-1 -- and the vmcnt(0) hipcc places in front of barrier i publishes them.
+    struct Pos { int jb, kc; long long bl; };
+    Pos p0 = {0, 0, blk0}, p1, p2, p3;
+    auto next_of = [&](const Pos& p) { Pos q = p; successor(q.jb, q.kc, q.bl); return q; };
+    p1 = next_of(p0); p2 = next_of(p1); p3 = next_of(p2);
+    const int hw_s = __builtin_amdgcn_readfirstlane(hw);
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto dma_tile = [&](int slot, unsigned toffs, int nq) {
+        double* dst = Aring + slot * S2_TILE + hw_s * 128;
+#pragma unroll
+        for (int q = 0; q < nq; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + q * 512), 16, (unsigned)lane * 16u,
+                                                     toffs + (unsigned)(q * 4096) + (unsigned)hw_s * 1024u, 0, 0);
+    };
+    auto dma_parked = [&](int par, int c) {
+        double* dst = Bbuf + par * 1024 + hw_s * 256;
+        const unsigned soff = (unsigned)c * (unsigned)(SW_BCH * 8) + (unsigned)hw_s * 1024u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)dst, 16, (unsigned)lane * 16u, soff, 0, SW_KAUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, SW_KAUX);
+    };
+    auto is_gen = [&](const Pos& p) { return !park || p.kc >= S2_CPB * p.jb; };
+    // ---- prologue: tile 0 and its operands, x chunks of tiles 0 and 1, requests for tile 1 ----
+    f64x2 bdummy[2] = {{0.0, 0.0}, {0.0, 0.0}};
+    __syncthreads();                              // C : constants visible
+    load_candidates(p0.bl);
+    dma_tile(0, tile_off(p0.jb, p0.kc), 8);
+    x_put(0, x_fetch(p0.kc));
+    x_put(1, x_fetch(p1.kc));
+    __syncthreads();                              // P0
+    produce_b(p0.jb, p0.kc, 0, 0, bdummy);
+    f64x2 xq = x_fetch(p2.kc);
+    __syncthreads();                              // P
+    // total tiles of this workgroup
+    long long ntile_blk = 0;
+    for (int jb = 0; jb < nrb2; ++jb) ntile_blk += nkc_of(jb);
+    long long nblk_mine = 0;
+    for (long long b = blk0; b < a.blk_end; b += gridDim.x) ++nblk_mine;
+    const long long ntot = ntile_blk * nblk_mine;
+    bool last_m1 = (ntile_blk == 1), last_m2 = false;
+#ifdef S2_TIMING
+    unsigned long long fw_g = 0, fn_g = 0, fw_p = 0, fn_p = 0, fs_a = 0, fs_b = 0;
+#endif
+    int slot = 1, par = 1;
+    for (long long i = 0;; ++i) {
+        // the matrix wavefronts have just passed barrier i-1: if tile i-1 closed a candidate
+        // block, finish that block
+        if (last_m2) epilogue();
+        if (i == ntot) break;
+#ifdef S2_TIMING
+        const unsigned long long ft0 = __builtin_amdgcn_s_memtime();
+        const bool fgen = is_gen(p1);
+#endif
+        // ---- produce tile i+1 = p1 ----
+#ifndef S2_X_NOFEED
+        dma_tile(slot, tile_off(p1.jb, p1.kc), 8);
+        if (p1.jb == 0 && p1.kc == 0) load_candidates(p1.bl);
+#ifdef S2_TIMING
+        const unsigned long long ft1 = __builtin_amdgcn_s_memtime();
+#endif
+        if (is_gen(p1)) produce_b(p1.jb, p1.kc, par, par, bdummy);
+        else dma_parked(par, p1.kc);
+#ifdef S2_TIMING
+        const unsigned long long ft2 = __builtin_amdgcn_s_memtime();
+        if (!fgen) { fs_a += ft1 - ft0; fs_b += ft2 - ft1; }
+#endif
+        x_put(par ^ 1, xq);                       // x chunk of tile i+2
+        if (is_gen(p3)) xq = x_fetch(p3.kc);
+#endif
+        last_m2 = last_m1;
+        last_m1 = (p1.jb == nrb2 - 1 && p1.kc == nkc_of(p1.jb) - 1);
+        p0 = p1; p1 = p2; p2 = p3; p3 = next_of(p3);
+        slot = slot == 2 ? 0 : slot + 1;
+        par ^= 1;
+#ifdef S2_TIMING
+        { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - ft0; if (fgen) { fw_g += d_; ++fn_g; } else { fw_p += d_; ++fn_p; } }
+#endif
+#ifndef S2_X_NOBAR
+        __syncthreads();                          // barrier i (hipcc drains the LDS-DMA queue first)
+#endif
+    }
+#ifdef S2_TIMING
+    if (a.dbg && blockIdx.x == 0 && ht == 0) { a.dbg[3] = fw_g; a.dbg[4] = fn_g; a.dbg[5] = fw_p; a.dbg[6] = fn_p; a.dbg[7] = fs_a; a.dbg[8] = fs_b; }
+#endif
+}
+
 // The short last round of the persistent grid (and every launch with fewer candidate blocks
 // than CUs) is split by ROW BLOCK: one workgroup per (candidate block, row block) writes its
 // share of sum V^2 and of mu, this kernel adds the shares in row-block order (deterministic)
@@ -739,7 +1185,49 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     const long long full = ncb - rest;
     if (full > 0) {
         a.blk_begin = 0; a.blk_end = full; a.split = 0;
-        launch((unsigned)(full < SW_GRID ? full : SW_GRID));
+        static int two_role = -1;
+        if (two_role < 0) { const char* e = getenv("APGP_SWEEP2"); two_role = (e && e[0] == '1') ? 1 : 0; }
+        if (two_role) {
+            SweepArgs b = a;
+            const int nrb2 = (int)((b.n + S2_ROWS - 1) / S2_ROWS);
+            if (b.ncache > 0 || nrb2 > 1) {
+                // parked stream of the 256-row blocks (same scratch region, a little longer)
+                b.ncache = S2_CPB * (nrb2 - 1);
+                b.kslot_bytes = (unsigned)((b.ncache > 0 ? b.ncache : 1) * SW_BCH * 8);
+                if (a0.ncache == 0) { b.ncache = 0; b.kslot_bytes = SW_BCH * 8; }   // parking disabled
+            }
+            const size_t lds2 = (3 * S2_TILE + 2 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + SW_CAND + 8 +
+                                 4 * APGP_MAX_DIM) * sizeof(double);
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                (void)hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                attr2 = true;
+            }
+            const unsigned g = (unsigned)(full < SW_GRID ? full : SW_GRID);
+#ifdef S2_TIMING
+            static unsigned long long* dbg2 = nullptr;
+            if (!dbg2) (void)hipMalloc(&dbg2, 16 * sizeof(unsigned long long));
+            b.dbg = dbg2;
+#endif
+            if (b.lin_coef != 0.0)
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, true>), dim3(g), dim3(S2_THREADS), lds2, s, b);
+            else
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, false>), dim3(g), dim3(S2_THREADS), lds2, s, b);
+#ifdef S2_TIMING
+            {
+                unsigned long long h[16];
+                (void)hipMemcpyAsync(h, dbg2, sizeof(h), hipMemcpyDeviceToHost, s);
+                (void)hipStreamSynchronize(s);
+                fprintf(stderr, "[sweep2 timing] matrix wave: %llu tiles, barrier wait %.0f cyc/tile, total %.0f cyc/tile | feeder work: gen tiles %.0f cyc (%llu), parked tiles %.0f cyc (%llu)\n",
+                        h[1], (double)h[0] / (h[1] ? h[1] : 1), (double)h[2] / (h[1] ? h[1] : 1), (double)h[3] / (h[4] ? h[4] : 1), h[4],
+                        (double)h[5] / (h[6] ? h[6] : 1), h[6]);
+                fprintf(stderr, "[sweep2 timing] parked feeder iteration: A stage %.0f, B %.0f cyc\n", (double)h[7] / (h[6] ? h[6] : 1), (double)h[8] / (h[6] ? h[6] : 1));
+            }
+#endif
+        } else {
+            launch((unsigned)(full < SW_GRID ? full : SW_GRID));
+        }
     }
     if (rest > 0) {
         a.blk_begin = full; a.blk_end = ncb; a.split = 1;
@@ -761,7 +1249,8 @@ extern "C" int64_t apgp_acquire_work_len(int64_t m, int64_t n) {
     const long long ncb = (m + SW_CAND - 1) / SW_CAND;
     const long long slots = ncb < SW_GRID ? ncb : SW_GRID;
     const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
-    return 2 * ncb + slots * sweep_ncache(n) * SW_BCH + 2 * (long long)SW_SPLIT_MAX * SW_CAND * nrb;
+    // (parked stream sized for the 256-row-block kernel: 32 nrb - 16 chunks per slot)
+    return 2 * ncb + slots * (sweep_ncache(n) + 16) * SW_BCH + 2 * (long long)SW_SPLIT_MAX * SW_CAND * nrb;
 }
 
 extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
@@ -795,7 +1284,7 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     {   // row-block shares of the split last round (after the parked-operand slots)
         const long long slots = nblk < SW_GRID ? nblk : SW_GRID;
         const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
-        a.sp_q = part ? (double*)part + 2 * nblk + slots * sweep_ncache(n) * SW_BCH : NULL;
+        a.sp_q = part ? (double*)part + 2 * nblk + slots * (sweep_ncache(n) + 16) * SW_BCH : NULL;
         a.sp_mu = a.sp_q ? a.sp_q + (long long)SW_SPLIT_MAX * SW_CAND * nrb : NULL;
         a.blk_begin = 0; a.blk_end = nblk; a.split = 0;
     }
