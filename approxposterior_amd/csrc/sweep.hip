@@ -66,7 +66,7 @@ struct SweepArgs {
     double* sp_mu;
     int split;
     long long m, idx_offset;
-    int ndim, nrb, kind, has_box, n, ncache, lin_order;
+    int ndim, nrb, kind, has_box, n, ncache, ncache2, lin_order;
     double mean, amp, zeta, ybest, lin_coef;
     double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
     unsigned long long* dbg;   // phase cycle counters (APGP_SWEEP_TIMING=1 builds only)
@@ -698,12 +698,24 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         return tile * (unsigned)(SW_TILE * 8) + (unsigned)((jb & 1) * S2_TILE * 8);
     };
     // (jb, kc, block) -> successor in the stream: next chunk, next row block, next candidate block
+    // work of this workgroup: row blocks jb_lo .. jb_hi-1 of candidate blocks blk0, blk0 +
+    // blk_step, ...  Persistent mode: every row block of every gridDim-th candidate block.
+    // Split mode (short last round / small launches): ONE (candidate block, row block) item,
+    // heaviest row blocks first; the shares go to sp_q / sp_mu and sweep_finish_kernel.
+    int jb_lo = 0, jb_hi = nrb2;
+    long long blk0 = a.blk_begin + blockIdx.x, blk_step = gridDim.x;
+    if (a.split) {
+        const int nsplit = (int)(a.blk_end - a.blk_begin);
+        blk0 = a.blk_begin + (int)blockIdx.x % nsplit;
+        jb_lo = nrb2 - 1 - (int)blockIdx.x / nsplit;
+        jb_hi = jb_lo + 1;
+        blk_step = a.blk_end;
+    }
     auto successor = [&](int& jb, int& kc, long long& blk) {
         ++kc;
         if (kc >= nkc_of(jb)) { ++jb; kc = 0; }
-        if (jb >= nrb2) { jb = 0; blk += gridDim.x; }
+        if (jb >= jb_hi) { jb = jb_lo; blk += blk_step; }
     };
-    const long long blk0 = a.blk_begin + blockIdx.x;
 
     if (w < 4) {
         // =============================== matrix role ===============================
@@ -728,9 +740,9 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         unsigned long long s2_wait = 0, s2_nt = 0, s2_t0 = __builtin_amdgcn_s_memtime();
 #endif
         load_a(av[0], 0, 0);
-        for (long long blk = blk0; blk < a.blk_end; blk += gridDim.x) {
+        for (long long blk = blk0; blk < a.blk_end; blk += blk_step) {
             double qtot = 0.0;
-            for (int jb = 0; jb < nrb2; ++jb) {
+            for (int jb = jb_lo; jb < jb_hi; ++jb) {
                 const int nkc = nkc_of(jb);
                 const int ndiag0 = S2_CPB * jb;
                 double acc[2 * NP][4];
@@ -770,17 +782,13 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                         const bool act = !PRED || (pr >= p0 && pr < p1);
                         if (act) mfma_pair(pr, 0);
                         __builtin_amdgcn_sched_barrier(0);
-#ifndef S2_X_NOBAR
 #ifdef S2_TIMING
                         if (pr == 4) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); s2_wait += __builtin_amdgcn_s_memtime() - t0_; ++s2_nt; }
 #else
                         if (pr == 4) __syncthreads();          // barrier i: tile i+1 is complete
 #endif
-#endif
-#ifndef S2_X_NOLDS
                         if (pr + 1 < NP) load_a(av[(pr + 1) & 1], slot, pr + 1);
                         else load_a(av[0], nslot, 0);
-#endif
                         if (act) {
                             mfma_pair(pr, 1);
                             mfma_pair(pr, 2);
@@ -827,26 +835,6 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, (int)a.xs_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.kcache + (long long)blockIdx.x * a.ncache * SW_BCH), 0, (int)a.kslot_bytes, 0x00020000);
-    auto gpiece = [&](unsigned toffs, int q) {
-        return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_w, hoff, toffs + (unsigned)(q * 256 * 16), 0));
-    };
-    auto lpiece = [&](int slot, int q) { return (f64x2*)(Aring + slot * S2_TILE) + q * 256 + ht; };
-    // park the eight pieces of a tile image; the slot is a uniform run-time value, but an
-    // address computed from it would be a VALU instruction -- and a feeder VALU instruction
-    // waits ~32 cycles for an issue slot next to the MFMA stream (tools/mfma_pair.hip) --
-    // so there is one copy per slot with immediate offsets
-    auto put_tile = [&](int slot, const f64x2 (&R)[8]) {
-        if (slot == 0) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) *lpiece(0, q) = R[q];
-        } else if (slot == 1) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) *lpiece(1, q) = R[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) *lpiece(2, q) = R[q];
-        }
-    };
     const unsigned xoff = ht < XCHUNK16 ? hoff : 0u;
     auto x_fetch = [&](int kc) {
         return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0));
@@ -857,25 +845,16 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             else *((f64x2*)(Xbuf + SW_KC * XS) + ht) = v;
         }
     };
-    const int cmax = a.ncache > 0 ? a.ncache - 1 : 0;
     const bool park = a.ncache > 0;
-    auto b_fetch = [&](int c, f64x2 (&bp)[2]) {
-        const unsigned soff = (unsigned)(c < cmax ? c : cmax) * (unsigned)(SW_BCH * 8);
-        bp[0] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, hoff, soff, SW_KAUX));
-        bp[1] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, hoff, soff + 256 * 16, SW_KAUX));
-    };
     // per-candidate state of the block being fed (cur) and of the finished one (fin)
     double tt[DPAD];
-    double ktt_cur = a.amp, ktt_fin = a.amp, mu_cur = 0.0, mu_fin = 0.0;
+    double ktt_cur = a.amp, ktt_fin = a.amp, mu_cur = 0.0, mu_tot = 0.0, mu_fin = 0.0;
     int fl_cur = 0, fl_fin = 0;
     long long blk_cur = -1, blk_fin = -1;
     auto load_candidates = [&](long long blk) {
         // snapshot the finished block, then set up the new one
-        double m = mu_cur;
-        m += __shfl_xor(m, 16);
-        m += __shfl_xor(m, 32);
-        mu_fin = m; ktt_fin = ktt_cur; fl_fin = fl_cur; blk_fin = blk_cur;
-        blk_cur = blk; mu_cur = 0.0;
+        mu_fin = mu_tot; ktt_fin = ktt_cur; fl_fin = fl_cur; blk_fin = blk_cur;
+        blk_cur = blk; mu_cur = 0.0; mu_tot = 0.0;
         const long long crow = blk * SW_CAND + hw * 16 + cl;
         const bool inb = blk < a.blk_end && crow < a.m;
         bool adm = inb, has_nan = false;
@@ -900,15 +879,11 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         fl_cur = (adm ? 1 : 0) | (has_nan ? 2 : 0) | (inb ? 4 : 0);
         ktt_cur = LIN ? fma(a.lin_coef, ktl, a.amp) : a.amp;
     };
-    // B operands of tile (jb, kc) of the current block -> LDS buffer bb (and the parked stream)
-    auto produce_b = [&](int jb, int kc, int bb, int xb, const f64x2 (&bp)[2]) {
-#ifdef S2_X_NOGEN
-        const bool gen = false;
-#else
-        const bool gen = !park || kc >= S2_CPB * jb;
-#endif
+    // generate the B operands of tile (jb, kc) of the current block -> LDS buffer bb (and, on
+    // the chunk's first visit, the parked stream and this row block's share of mu)
+    auto produce_b = [&](int jb, int kc, int bb, int xb) {
         double bfv[NKK];
-        if (gen) {
+        {
             const double* Xb = Xbuf + xb * SW_KC * XS;
             double s2[NKK], s3[NKK], al[NKK], lsum[NKK];
 #pragma unroll
@@ -941,6 +916,15 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             if (kc >= S2_CPB * jb) {
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) mu_cur = fma(bfv[kk], al[kk], mu_cur);
+                if (kc == nkc_of(jb) - 1) {
+                    // row block complete: its share of mu, reduced over the 4 k-lanes, joins the
+                    // total in row-block order (the order sweep_finish_kernel adds split shares)
+                    double m = mu_cur;
+                    m += __shfl_xor(m, 16);
+                    m += __shfl_xor(m, 32);
+                    mu_tot += m;
+                    mu_cur = 0.0;
+                }
                 if (park && jb + 1 < nrb2) {
                     const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
                     f64x2 q0, q1;
@@ -953,14 +937,19 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             o0.x = bfv[0]; o0.y = bfv[1]; o1.x = bfv[2]; o1.y = bfv[3];
             if (bb == 0) { f64x2* Bw = (f64x2*)(Bbuf + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
             else { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
-        } else {
-            // parked operands go straight from the load registers to LDS
-            if (bb == 0) { f64x2* Bw = (f64x2*)(Bbuf + hw * 256); Bw[lane] = bp[0]; Bw[64 + lane] = bp[1]; }
-            else { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = bp[0]; Bw[64 + lane] = bp[1]; }
         }
     };
     auto epilogue = [&]() {
         __syncthreads();                          // E1
+        if (a.split) {
+            if (kq == 0) {
+                const long long e = ((blk_fin - a.blk_begin) * SW_CAND + hw * 16 + cl) * nrb2 + jb_lo;
+                a.sp_q[e] = Shq[hw * 16 + cl];
+                a.sp_mu[e] = mu_fin;
+            }
+            __syncthreads();                      // E2
+            return;
+        }
         double bu = INFINITY;
         long long bi = -1;
         const long long crow = blk_fin * SW_CAND + hw * 16 + cl;
@@ -998,7 +987,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     // requested right after barrier i-1 into slot (i+1) % 3 / buffer (i+1) & 1 -- both free
     // since barrier i-1 -- and the vmcnt(0) hipcc places in front of barrier i publishes them.
     struct Pos { int jb, kc; long long bl; };
-    Pos p0 = {0, 0, blk0}, p1, p2, p3;
+    Pos p0 = {jb_lo, 0, blk0}, p1, p2, p3;
     auto next_of = [&](const Pos& p) { Pos q = p; successor(q.jb, q.kc, q.bl); return q; };
     p1 = next_of(p0); p2 = next_of(p1); p3 = next_of(p2);
     const int hw_s = __builtin_amdgcn_readfirstlane(hw);
@@ -1018,21 +1007,20 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     };
     auto is_gen = [&](const Pos& p) { return !park || p.kc >= S2_CPB * p.jb; };
     // ---- prologue: tile 0 and its operands, x chunks of tiles 0 and 1, requests for tile 1 ----
-    f64x2 bdummy[2] = {{0.0, 0.0}, {0.0, 0.0}};
     __syncthreads();                              // C : constants visible
     load_candidates(p0.bl);
     dma_tile(0, tile_off(p0.jb, p0.kc), 8);
     x_put(0, x_fetch(p0.kc));
     x_put(1, x_fetch(p1.kc));
     __syncthreads();                              // P0
-    produce_b(p0.jb, p0.kc, 0, 0, bdummy);
+    produce_b(p0.jb, p0.kc, 0, 0);
     f64x2 xq = x_fetch(p2.kc);
     __syncthreads();                              // P
     // total tiles of this workgroup
     long long ntile_blk = 0;
-    for (int jb = 0; jb < nrb2; ++jb) ntile_blk += nkc_of(jb);
+    for (int jb = jb_lo; jb < jb_hi; ++jb) ntile_blk += nkc_of(jb);
     long long nblk_mine = 0;
-    for (long long b = blk0; b < a.blk_end; b += gridDim.x) ++nblk_mine;
+    for (long long b = blk0; b < a.blk_end; b += blk_step) ++nblk_mine;
     const long long ntot = ntile_blk * nblk_mine;
     bool last_m1 = (ntile_blk == 1), last_m2 = false;
 #ifdef S2_TIMING
@@ -1049,13 +1037,12 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         const bool fgen = is_gen(p1);
 #endif
         // ---- produce tile i+1 = p1 ----
-#ifndef S2_X_NOFEED
         dma_tile(slot, tile_off(p1.jb, p1.kc), 8);
-        if (p1.jb == 0 && p1.kc == 0) load_candidates(p1.bl);
+        if (p1.jb == jb_lo && p1.kc == 0) load_candidates(p1.bl);
 #ifdef S2_TIMING
         const unsigned long long ft1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (is_gen(p1)) produce_b(p1.jb, p1.kc, par, par, bdummy);
+        if (is_gen(p1)) produce_b(p1.jb, p1.kc, par, par);
         else dma_parked(par, p1.kc);
 #ifdef S2_TIMING
         const unsigned long long ft2 = __builtin_amdgcn_s_memtime();
@@ -1063,18 +1050,15 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
 #endif
         x_put(par ^ 1, xq);                       // x chunk of tile i+2
         if (is_gen(p3)) xq = x_fetch(p3.kc);
-#endif
         last_m2 = last_m1;
-        last_m1 = (p1.jb == nrb2 - 1 && p1.kc == nkc_of(p1.jb) - 1);
+        last_m1 = (p1.jb == jb_hi - 1 && p1.kc == nkc_of(p1.jb) - 1);
         p0 = p1; p1 = p2; p2 = p3; p3 = next_of(p3);
         slot = slot == 2 ? 0 : slot + 1;
         par ^= 1;
 #ifdef S2_TIMING
         { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - ft0; if (fgen) { fw_g += d_; ++fn_g; } else { fw_p += d_; ++fn_p; } }
 #endif
-#ifndef S2_X_NOBAR
         __syncthreads();                          // barrier i (hipcc drains the LDS-DMA queue first)
-#endif
     }
 #ifdef S2_TIMING
     if (a.dbg && blockIdx.x == 0 && ht == 0) { a.dbg[3] = fw_g; a.dbg[4] = fn_g; a.dbg[5] = fw_p; a.dbg[6] = fn_p; a.dbg[7] = fs_a; a.dbg[8] = fs_b; }
@@ -1134,6 +1118,8 @@ __global__ __launch_bounds__(64) void sweep_finish_kernel(SweepArgs a) {
 // blocks of the last round that are split by row block (measured break-even at N = 4096:
 // ~230 of 256 -- the split launch regenerates every k* and its largest item is 22 % of a block)
 #define SW_SPLIT_MAX 216
+// the same for the two-role kernel's 256-row items
+#define S2_SPLIT_MAX 216
 
 template <int DPAD>
 static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
@@ -1180,40 +1166,41 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     // full rounds on the persistent grid, then the remainder split by row block
     static int split_on = -1;
     if (split_on < 0) { const char* e = getenv("APGP_SWEEP_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
-    long long rest = ncb % SW_GRID;
-    if (!split_on || a.nrb < 2 || rest > SW_SPLIT_MAX || a.sp_q == NULL) rest = 0;
-    const long long full = ncb - rest;
-    if (full > 0) {
-        a.blk_begin = 0; a.blk_end = full; a.split = 0;
-        static int two_role = -1;
-        if (two_role < 0) { const char* e = getenv("APGP_SWEEP2"); two_role = (e && e[0] == '1') ? 1 : 0; }
-        if (two_role) {
-            SweepArgs b = a;
-            const int nrb2 = (int)((b.n + S2_ROWS - 1) / S2_ROWS);
-            if (b.ncache > 0 || nrb2 > 1) {
-                // parked stream of the 256-row blocks (same scratch region, a little longer)
-                b.ncache = S2_CPB * (nrb2 - 1);
-                b.kslot_bytes = (unsigned)((b.ncache > 0 ? b.ncache : 1) * SW_BCH * 8);
-                if (a0.ncache == 0) { b.ncache = 0; b.kslot_bytes = SW_BCH * 8; }   // parking disabled
-            }
-            const size_t lds2 = (3 * S2_TILE + 2 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + SW_CAND + 8 +
-                                 4 * APGP_MAX_DIM) * sizeof(double);
-            static bool attr2 = false;
-            if (!attr2) {
-                (void)hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                (void)hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                attr2 = true;
-            }
-            const unsigned g = (unsigned)(full < SW_GRID ? full : SW_GRID);
+    static int two_role = -1;
+    if (two_role < 0) { const char* e = getenv("APGP_SWEEP2"); two_role = (e && e[0] == '0') ? 0 : 1; }
+    if (two_role) {
+        // ---- two-role kernel (default) ----
+        const int nrb2 = (int)((a.n + S2_ROWS - 1) / S2_ROWS);
+        const size_t lds2 = (3 * S2_TILE + 2 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + SW_CAND + 8 +
+                             4 * APGP_MAX_DIM) * sizeof(double);
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            (void)hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            attr2 = true;
+        }
+        a.nrb = nrb2;
+        a.ncache = a.ncache2;
+        a.kslot_bytes = (unsigned)((a.ncache > 0 ? a.ncache : 1) * SW_BCH * 8);
 #ifdef S2_TIMING
-            static unsigned long long* dbg2 = nullptr;
-            if (!dbg2) (void)hipMalloc(&dbg2, 16 * sizeof(unsigned long long));
-            b.dbg = dbg2;
+        static unsigned long long* dbg2 = nullptr;
+        if (!dbg2) (void)hipMalloc(&dbg2, 16 * sizeof(unsigned long long));
+        a.dbg = dbg2;
 #endif
-            if (b.lin_coef != 0.0)
-                hipLaunchKernelGGL((sweep2_kernel<DPAD, true>), dim3(g), dim3(S2_THREADS), lds2, s, b);
+        auto launch2 = [&](unsigned grid) {
+            if (a.lin_coef != 0.0)
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, true>), dim3(grid), dim3(S2_THREADS), lds2, s, a);
             else
-                hipLaunchKernelGGL((sweep2_kernel<DPAD, false>), dim3(g), dim3(S2_THREADS), lds2, s, b);
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, false>), dim3(grid), dim3(S2_THREADS), lds2, s, a);
+        };
+        static int split_max = -1;
+        if (split_max < 0) { const char* e = getenv("APGP_SWEEP_SPLIT_MAX"); split_max = e ? atoi(e) : S2_SPLIT_MAX; if (split_max > SW_SPLIT_MAX) split_max = SW_SPLIT_MAX; }
+        long long rest = ncb % SW_GRID;
+        if (!split_on || nrb2 < 2 || rest > split_max || a.sp_q == NULL) rest = 0;
+        const long long full = ncb - rest;
+        if (full > 0) {
+            a.blk_begin = 0; a.blk_end = full; a.split = 0;
+            launch2((unsigned)(full < SW_GRID ? full : SW_GRID));
 #ifdef S2_TIMING
             {
                 unsigned long long h[16];
@@ -1222,12 +1209,25 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
                 fprintf(stderr, "[sweep2 timing] matrix wave: %llu tiles, barrier wait %.0f cyc/tile, total %.0f cyc/tile | feeder work: gen tiles %.0f cyc (%llu), parked tiles %.0f cyc (%llu)\n",
                         h[1], (double)h[0] / (h[1] ? h[1] : 1), (double)h[2] / (h[1] ? h[1] : 1), (double)h[3] / (h[4] ? h[4] : 1), h[4],
                         (double)h[5] / (h[6] ? h[6] : 1), h[6]);
-                fprintf(stderr, "[sweep2 timing] parked feeder iteration: A stage %.0f, B %.0f cyc\n", (double)h[7] / (h[6] ? h[6] : 1), (double)h[8] / (h[6] ? h[6] : 1));
             }
 #endif
-        } else {
-            launch((unsigned)(full < SW_GRID ? full : SW_GRID));
         }
+        if (rest > 0) {
+            a.blk_begin = full; a.blk_end = ncb; a.split = 1;
+            a.ncache = 0;                             // no parking across workgroups
+            a.kslot_bytes = SW_BCH * 8;
+            launch2((unsigned)(rest * nrb2));
+            hipLaunchKernelGGL(sweep_finish_kernel, dim3((unsigned)rest), dim3(64), 0, s, a);
+        }
+        return 0;
+    }
+    // ---- one-role kernel (APGP_SWEEP2=0: the A/B reference of DESIGN.md K5) ----
+    long long rest = ncb % SW_GRID;
+    if (!split_on || a.nrb < 2 || rest > SW_SPLIT_MAX || a.sp_q == NULL) rest = 0;
+    const long long full = ncb - rest;
+    if (full > 0) {
+        a.blk_begin = 0; a.blk_end = full; a.split = 0;
+        launch((unsigned)(full < SW_GRID ? full : SW_GRID));
     }
     if (rest > 0) {
         a.blk_begin = full; a.blk_end = ncb; a.split = 1;
@@ -1250,7 +1250,7 @@ extern "C" int64_t apgp_acquire_work_len(int64_t m, int64_t n) {
     const long long slots = ncb < SW_GRID ? ncb : SW_GRID;
     const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
     // (parked stream sized for the 256-row-block kernel: 32 nrb - 16 chunks per slot)
-    return 2 * ncb + slots * (sweep_ncache(n) + 16) * SW_BCH + 2 * (long long)SW_SPLIT_MAX * SW_CAND * nrb;
+    return 2 * ncb + slots * (sweep_ncache(n) + 16) * SW_BCH + 2 * (long long)SW_SPLIT_MAX * SW_CAND * 2 * nrb;
 }
 
 extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
@@ -1262,7 +1262,7 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     APGP_CHECK_ARG(m >= 1 && n >= 1, "m >= 1 and n >= 1 required");
     APGP_CHECK_ARG(kind >= APGP_UTIL_AGP && kind <= APGP_UTIL_NONE, "unknown utility kind");
     APGP_CHECK_ARG(kind == APGP_UTIL_NONE || best, "best required for an acquisition");
-    APGP_CHECK_ARG(part || (kind == APGP_UTIL_NONE && sweep_ncache(n) == 0),
+    APGP_CHECK_ARG(part || (kind == APGP_UTIL_NONE && n <= S2_ROWS),
                    "part (apgp_acquire_work_len doubles) required");
     APGP_CHECK_ARG((lo == NULL) == (hi == NULL), "lo and hi must be given together");
     KernConst kc;
@@ -1277,15 +1277,16 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     {   // developer A/B switch: APGP_SWEEP_PARK=0 regenerates k* for every row block
         static int park = -1;
         if (park < 0) { const char* e = getenv("APGP_SWEEP_PARK"); park = (e && e[0] == '0') ? 0 : 1; }
-        if (!park) a.ncache = 0;
+        a.ncache2 = S2_CPB * (int)((n + S2_ROWS - 1) / S2_ROWS - 1);
+        if (!park) { a.ncache = 0; a.ncache2 = 0; }
     }
     // N <= 512: nothing is parked; the (unconditional, discarded) prefetch then reads the factor
-    a.kcache = a.ncache > 0 ? (double*)part + 2 * nblk : (double*)packed_linv;
+    a.kcache = (a.ncache > 0 || a.ncache2 > 0) ? (double*)part + 2 * nblk : (double*)packed_linv;
     {   // row-block shares of the split last round (after the parked-operand slots)
         const long long slots = nblk < SW_GRID ? nblk : SW_GRID;
         const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
         a.sp_q = part ? (double*)part + 2 * nblk + slots * (sweep_ncache(n) + 16) * SW_BCH : NULL;
-        a.sp_mu = a.sp_q ? a.sp_q + (long long)SW_SPLIT_MAX * SW_CAND * nrb : NULL;
+        a.sp_mu = a.sp_q ? a.sp_q + (long long)SW_SPLIT_MAX * SW_CAND * 2 * nrb : NULL;
         a.blk_begin = 0; a.blk_end = nblk; a.split = 0;
     }
     {
