@@ -1119,7 +1119,7 @@ __global__ __launch_bounds__(64) void sweep_finish_kernel(SweepArgs a) {
 // ~230 of 256 -- the split launch regenerates every k* and its largest item is 22 % of a block)
 #define SW_SPLIT_MAX 216
 // the same for the two-role kernel's 256-row items
-#define S2_SPLIT_MAX 216
+#define S2_SPLIT_MAX 184
 
 template <int DPAD>
 static int launch_sweep(const SweepArgs& a0, hipStream_t s) {

@@ -45,10 +45,10 @@ def synthetic_c3(n_train, ndim):
 
 def profiled_traffic(n, d, m):
     """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes
-    (profiles/r01d_pmc_sweep.json: FETCH_SIZE x2 for the gfx950 wide-stream
+    (profiles/r01e_pmc_sweep.json: FETCH_SIZE x2 for the gfx950 wide-stream
     correction + WRITE_SIZE, per MI355X_MICROARCH.md), only for the exact workload
     that was profiled; None otherwise (PMC counters are not collected inline)."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_sweep.json")
+    path = os.path.join(ROOT, "profiles", "r01e_pmc_sweep.json")
     if (n, d, m) != (4096, 8, 1000000) or not os.path.exists(path):
         return None
     try:
@@ -211,7 +211,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
                          "traffic": profiled_traffic(N, D, M),
-                         "kernel": "sweep_kernel<%d>" % (2 if D <= 2 else 4 if D <= 4 else 8 if D <= 8 else 16),
+                         "kernel": "sweep2_kernel<%d, false>" % (2 if D <= 2 else 4 if D <= 4 else 8 if D <= 8 else 16),
                          "kernel_ms": k_avg_ms,
                          "algorithmic_flops_per_candidate": f_var(N, D)},
             "best": {"index": int(best[0]), "u": float(best[1])},

@@ -5,7 +5,7 @@ import csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
 root = os.path.join("gpurun_out", "prof_" + tag)
-KERNEL = "sweep_kernel"
+KERNEL = "sweep2_kernel"      # the two-role sweep (APGP_SWEEP2=0 runs: "sweep_kernel")
 
 stats = glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
