@@ -66,7 +66,7 @@ struct SweepArgs {
     double* sp_mu;
     int split;
     long long m, idx_offset;
-    int ndim, nrb, kind, has_box, n, ncache, ncache2, lin_order;
+    int ndim, nrb, kind, has_box, n, ncache, ncache2, lin_order, halves;
     double mean, amp, zeta, ybest, lin_coef;
     double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
     unsigned long long* dbg;   // phase cycle counters (APGP_SWEEP_TIMING=1 builds only)
@@ -654,7 +654,8 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 // written by the feeders between barrier i-1 and barrier i; the matrix wavefronts execute
 // barrier i after the first k-step of pair 4 of tile i and read tile i+1 only after it.
 // ===========================================================================
-#define S2_THREADS 512
+#define S2_THREADS 768
+#define S2_MW 8                          // matrix wavefronts (two per SIMD)
 #define S2_ROWS 256
 #define S2_TILE (S2_ROWS * SW_KC)        // doubles per tile image (32 KiB)
 #define S2_CPB (S2_ROWS / SW_KC)         // chunks per row-block width (16)
@@ -672,13 +673,13 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     double* Xbuf = Bbuf + 2 * 4 * 256;            // 2 x SW_KC x XS
     double* Etab = Xbuf + 2 * SW_KC * XS;
     double* Shq = Etab + APGP_EXP_TAB_N;          // sum V^2 per candidate (matrix -> feeder)
-    double* red_u = Shq + SW_CAND;
+    double* red_u = Shq + 2 * SW_CAND;
     long long* red_i = (long long*)(red_u + 4);
     double* Cst = red_u + 8;                      // sc | lo | hi | lw (4 x APGP_MAX_DIM), feeder only
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cl = lane & 15, kq = lane >> 4;
     apgp_exp_tab_load(Etab);
-    if (t == 256) {
+    if (t == S2_MW * 64) {
 #pragma unroll
         for (int d = 0; d < APGP_MAX_DIM; ++d) {
             Cst[d] = a.sc[d];
@@ -717,8 +718,14 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         if (jb >= jb_hi) { jb = jb_lo; blk += blk_step; }
     };
 
-    if (w < 4) {
+    if (w < S2_MW) {
         // =============================== matrix role ===============================
+        // wavefronts w and w + 4 share a SIMD and a candidate group (cg) and take the two
+        // 128-row halves (rh) of every tile: while one issues its LDS reads the other's MFMAs
+        // keep the pipe busy
+        constexpr int NPW = NP / 2;
+        const int cg = w & 3;
+        const int rh = __builtin_amdgcn_readfirstlane(w) >> 2;
         // lane whose B value this lane multiplies in rotation r (block b meets candidate
         // group b + r): the rotation is an LDS read address, not a register move
         int lr[4];
@@ -726,7 +733,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         for (int r = 0; r < 4; ++r) lr[r] = (lane & 48) | ((lane + 4 * r) & 15);
         f64x2 av[2][2][2];
         auto load_a = [&](f64x2 (&dst)[2][2], int slot, int p) {
-            const f64x2* A2 = (const f64x2*)(Aring + slot * S2_TILE) + lane;
+            const f64x2* A2 = (const f64x2*)(Aring + slot * S2_TILE) + rh * (NPW * 4 * 64) + lane;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -745,9 +752,9 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             for (int jb = jb_lo; jb < jb_hi; ++jb) {
                 const int nkc = nkc_of(jb);
                 const int ndiag0 = S2_CPB * jb;
-                double acc[2 * NP][4];
+                double acc[2 * NPW][4];
 #pragma unroll
-                for (int s_ = 0; s_ < 2 * NP; ++s_)
+                for (int s_ = 0; s_ < 2 * NPW; ++s_)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[s_][r] = 0.0;
                 int kc = 0;
@@ -757,7 +764,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                     // B operands of this tile, all four rotations (published by the last barrier)
                     double brot[4][NKK];
                     {
-                        const f64x2* Bw = (const f64x2*)(Bbuf + bpar * 1024 + w * 256);
+                        const f64x2* Bw = (const f64x2*)(Bbuf + bpar * 1024 + cg * 256);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const f64x2 b0 = Bw[lr[r]], b1 = Bw[64 + lr[r]];
@@ -778,16 +785,17 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                     int p1 = (a.n - S2_ROWS * jb + 31) >> 5;
                     if (p1 > NP) p1 = NP;
 #pragma unroll
-                    for (int pr = 0; pr < NP; ++pr) {
-                        const bool act = !PRED || (pr >= p0 && pr < p1);
+                    for (int pr = 0; pr < NPW; ++pr) {
+                        const int gp = rh * NPW + pr;
+                        const bool act = !PRED || (gp >= p0 && gp < p1);
                         if (act) mfma_pair(pr, 0);
                         __builtin_amdgcn_sched_barrier(0);
 #ifdef S2_TIMING
-                        if (pr == 4) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); s2_wait += __builtin_amdgcn_s_memtime() - t0_; ++s2_nt; }
+                        if (pr == NPW / 2) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); s2_wait += __builtin_amdgcn_s_memtime() - t0_; ++s2_nt; }
 #else
-                        if (pr == 4) __syncthreads();          // barrier i: tile i+1 is complete
+                        if (pr == NPW / 2) __syncthreads();    // barrier i: tile i+1 is complete
 #endif
-                        if (pr + 1 < NP) load_a(av[(pr + 1) & 1], slot, pr + 1);
+                        if (pr + 1 < NPW) load_a(av[(pr + 1) & 1], slot, pr + 1);
                         else load_a(av[0], nslot, 0);
                         if (act) {
                             mfma_pair(pr, 1);
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     qr[r] = 0.0;
 #pragma unroll
-                    for (int s_ = 0; s_ < 2 * NP; ++s_) qr[r] = fma(acc[s_][r], acc[s_][r], qr[r]);
+                    for (int s_ = 0; s_ < 2 * NPW; ++s_) qr[r] = fma(acc[s_][r], acc[s_][r], qr[r]);
                 }
                 double qs = qr[0];
 #pragma unroll
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 qs += __shfl_xor(qs, 32);
                 qtot += qs;
             }
-            if (kq == 0) Shq[w * 16 + cl] = qtot;
+            if (kq == 0) Shq[rh * SW_CAND + cg * 16 + cl] = qtot;
             __syncthreads();                      // E1: sums visible to the feeders
             __syncthreads();                      // E2: block result written
         }
@@ -829,7 +837,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     }
 
     // ================================= feeder role =================================
-    const int hw = w - 4, ht = t - 256;
+    const int hw = w - S2_MW, ht = t - S2_MW * 64;
     const unsigned hoff = (unsigned)ht * 16u;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.linv, 0, (int)a.linv_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, (int)a.xs_bytes, 0x00020000);
@@ -944,7 +952,8 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         if (a.split) {
             if (kq == 0) {
                 const long long e = ((blk_fin - a.blk_begin) * SW_CAND + hw * 16 + cl) * nrb2 + jb_lo;
-                a.sp_q[e] = Shq[hw * 16 + cl];
+                a.sp_q[2 * e] = Shq[hw * 16 + cl];
+                a.sp_q[2 * e + 1] = Shq[SW_CAND + hw * 16 + cl];
                 a.sp_mu[e] = mu_fin;
             }
             __syncthreads();                      // E2
@@ -955,7 +964,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         const long long crow = blk_fin * SW_CAND + hw * 16 + cl;
         if (kq == 0 && (fl_fin & 4)) {
             double mu = mu_fin + a.mean;
-            double var = ktt_fin - Shq[hw * 16 + cl];
+            double var = ktt_fin - (Shq[hw * 16 + cl] + Shq[SW_CAND + hw * 16 + cl]);
             if (fl_fin & 2) { mu = NAN; var = NAN; }
             if (a.mu) a.mu[crow] = mu;
             if (a.var) a.var[crow] = var;
@@ -1094,7 +1103,15 @@ __global__ __launch_bounds__(64) void sweep_finish_kernel(SweepArgs a) {
         if (a.mask && a.mask[crow] == 0) adm = false;
         const long long e0 = ((long long)blockIdx.x * SW_CAND + c) * a.nrb;
         double q = 0.0, mup = 0.0;
-        for (int ib = 0; ib < a.nrb; ++ib) { q += a.sp_q[e0 + ib]; mup += a.sp_mu[e0 + ib]; }
+        if (a.halves == 2) {
+            // two-role kernel: the two row halves of a row block are summed by different
+            // wavefronts, each over the row blocks in order, and added at the end
+            double q1 = 0.0;
+            for (int ib = 0; ib < a.nrb; ++ib) { q += a.sp_q[2 * (e0 + ib)]; q1 += a.sp_q[2 * (e0 + ib) + 1]; mup += a.sp_mu[e0 + ib]; }
+            q += q1;
+        } else {
+            for (int ib = 0; ib < a.nrb; ++ib) { q += a.sp_q[e0 + ib]; mup += a.sp_mu[e0 + ib]; }
+        }
         double mu = mup + a.mean;
         double var = fma(a.lin_coef, ktl, a.amp) - q;
         if (has_nan) { mu = NAN; var = NAN; }
@@ -1134,6 +1151,7 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
         attr_set = true;
     }
     SweepArgs a = a0;
+    a.halves = 1;
     const long long ncb = (a.m + SW_CAND - 1) / SW_CAND;
     static int timing = -1;
     if (timing < 0) { const char* e = getenv("APGP_SWEEP_TIMING"); timing = (e && e[0] == '1') ? 1 : 0; }
@@ -1171,7 +1189,7 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     if (two_role) {
         // ---- two-role kernel (default) ----
         const int nrb2 = (int)((a.n + S2_ROWS - 1) / S2_ROWS);
-        const size_t lds2 = (3 * S2_TILE + 2 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + SW_CAND + 8 +
+        const size_t lds2 = (3 * S2_TILE + 2 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + 2 * SW_CAND + 8 +
                              4 * APGP_MAX_DIM) * sizeof(double);
         static bool attr2 = false;
         if (!attr2) {
@@ -1180,6 +1198,7 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
             attr2 = true;
         }
         a.nrb = nrb2;
+        a.halves = 2;
         a.ncache = a.ncache2;
         a.kslot_bytes = (unsigned)((a.ncache > 0 ? a.ncache : 1) * SW_BCH * 8);
 #ifdef S2_TIMING
@@ -1250,7 +1269,7 @@ extern "C" int64_t apgp_acquire_work_len(int64_t m, int64_t n) {
     const long long slots = ncb < SW_GRID ? ncb : SW_GRID;
     const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
     // (parked stream sized for the 256-row-block kernel: 32 nrb - 16 chunks per slot)
-    return 2 * ncb + slots * (sweep_ncache(n) + 16) * SW_BCH + 2 * (long long)SW_SPLIT_MAX * SW_CAND * 2 * nrb;
+    return 2 * ncb + slots * (sweep_ncache(n) + 16) * SW_BCH + 6 * (long long)SW_SPLIT_MAX * SW_CAND * nrb;
 }
 
 extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
@@ -1286,7 +1305,7 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
         const long long slots = nblk < SW_GRID ? nblk : SW_GRID;
         const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
         a.sp_q = part ? (double*)part + 2 * nblk + slots * (sweep_ncache(n) + 16) * SW_BCH : NULL;
-        a.sp_mu = a.sp_q ? a.sp_q + (long long)SW_SPLIT_MAX * SW_CAND * 2 * nrb : NULL;
+        a.sp_mu = a.sp_q ? a.sp_q + (long long)SW_SPLIT_MAX * SW_CAND * 4 * nrb : NULL;
         a.blk_begin = 0; a.blk_end = nblk; a.split = 0;
     }
     {
