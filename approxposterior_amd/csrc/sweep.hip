@@ -660,6 +660,7 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 #define S2_TILE (S2_ROWS * SW_KC)        // doubles per tile image (32 KiB)
 #define S2_CPB (S2_ROWS / SW_KC)         // chunks per row-block width (16)
 #define S2_NP (S2_ROWS / 32)             // sub-block pairs per tile (8)
+#define S2_NSLOT 4                       // tile images in the LDS ring
 
 template <int DPAD, bool LIN>
 __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
@@ -668,9 +669,9 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     constexpr int NP = S2_NP;
     constexpr int XCHUNK16 = SW_KC * XS / 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Aring = smem;                         // 3 tile images
-    double* Bbuf = Aring + 3 * S2_TILE;           // 2 x 4 wavefronts x [2][64] x 16 B
-    double* Xbuf = Bbuf + 2 * 4 * 256;            // 2 x SW_KC x XS
+    double* Aring = smem;                         // S2_NSLOT tile images
+    double* Bbuf = Aring + S2_NSLOT * S2_TILE;    // 3 x 4 candidate groups x [2][64] x 16 B
+    double* Xbuf = Bbuf + 3 * 4 * 256;            // 2 x SW_KC x XS
     double* Etab = Xbuf + 2 * SW_KC * XS;
     double* Shq = Etab + APGP_EXP_TAB_N;          // sum V^2 per candidate (matrix -> feeder)
     double* red_u = Shq + 2 * SW_CAND;
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 int kc = 0;
                 auto do_tile = [&](auto pred_tag) {
                     constexpr bool PRED = decltype(pred_tag)::value;
-                    const int nslot = slot == 2 ? 0 : slot + 1;
+                    const int nslot = slot == S2_NSLOT - 1 ? 0 : slot + 1;
                     // B operands of this tile, all four rotations (published by the last barrier)
                     double brot[4][NKK];
                     {
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     slot = nslot;
-                    bpar ^= 1;
+                    bpar = bpar == 2 ? 0 : bpar + 1;
                 };
                 const int nstraight = (a.n - S2_ROWS * jb >= S2_ROWS) ? ndiag0 : 0;
                 for (; kc < nstraight; ++kc) do_tile(std::false_type{});
@@ -944,7 +945,8 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             f64x2 o0, o1;
             o0.x = bfv[0]; o0.y = bfv[1]; o1.x = bfv[2]; o1.y = bfv[3];
             if (bb == 0) { f64x2* Bw = (f64x2*)(Bbuf + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
-            else { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
+            else if (bb == 1) { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
+            else { f64x2* Bw = (f64x2*)(Bbuf + 2048 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
         }
     };
     auto epilogue = [&]() {
@@ -996,7 +998,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     // requested right after barrier i-1 into slot (i+1) % 3 / buffer (i+1) & 1 -- both free
     // since barrier i-1 -- and the vmcnt(0) hipcc places in front of barrier i publishes them.
     struct Pos { int jb, kc; long long bl; };
-    Pos p0 = {jb_lo, 0, blk0}, p1, p2, p3;
+    Pos p0 = {jb_lo, 0, blk0}, p1, p2, p3;   // p_k: tile i+k of the loop below
     auto next_of = [&](const Pos& p) { Pos q = p; successor(q.jb, q.kc, q.bl); return q; };
     p1 = next_of(p0); p2 = next_of(p1); p3 = next_of(p2);
     const int hw_s = __builtin_amdgcn_readfirstlane(hw);
@@ -1015,10 +1017,11 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, SW_KAUX);
     };
     auto is_gen = [&](const Pos& p) { return !park || p.kc >= S2_CPB * p.jb; };
-    // ---- prologue: tile 0 and its operands, x chunks of tiles 0 and 1, requests for tile 1 ----
+    // ---- prologue: tiles 0 and 1, the operands of tile 0, x chunks of tiles 0 and 1 ----
     __syncthreads();                              // C : constants visible
     load_candidates(p0.bl);
     dma_tile(0, tile_off(p0.jb, p0.kc), 8);
+    dma_tile(1, tile_off(p1.jb, p1.kc), 8);
     x_put(0, x_fetch(p0.kc));
     x_put(1, x_fetch(p1.kc));
     __syncthreads();                              // P0
@@ -1033,9 +1036,10 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     const long long ntot = ntile_blk * nblk_mine;
     bool last_m1 = (ntile_blk == 1), last_m2 = false;
 #ifdef S2_TIMING
-    unsigned long long fw_g = 0, fn_g = 0, fw_p = 0, fn_p = 0, fs_a = 0, fs_b = 0;
+    unsigned long long fw_g = 0, fn_g = 0, fw_p = 0, fn_p = 0;
 #endif
-    int slot = 1, par = 1;
+    // slot2 / b2: ring slot and B buffer of tile i+2; b1 / x1: B buffer and x buffer of tile i+1
+    int slot2 = 2, b2 = 2, b1 = 1, x1 = 1;
     for (long long i = 0;; ++i) {
         // the matrix wavefronts have just passed barrier i-1: if tile i-1 closed a candidate
         // block, finish that block
@@ -1045,32 +1049,70 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         const unsigned long long ft0 = __builtin_amdgcn_s_memtime();
         const bool fgen = is_gen(p1);
 #endif
-        // ---- produce tile i+1 = p1 ----
-        dma_tile(slot, tile_off(p1.jb, p1.kc), 8);
+        // ---- tile i+1 = p1: generated operands (a parked tile's were requested an iteration ago)
         if (p1.jb == jb_lo && p1.kc == 0) load_candidates(p1.bl);
-#ifdef S2_TIMING
-        const unsigned long long ft1 = __builtin_amdgcn_s_memtime();
-#endif
-        if (is_gen(p1)) produce_b(p1.jb, p1.kc, par, par);
-        else dma_parked(par, p1.kc);
-#ifdef S2_TIMING
-        const unsigned long long ft2 = __builtin_amdgcn_s_memtime();
-        if (!fgen) { fs_a += ft1 - ft0; fs_b += ft2 - ft1; }
-#endif
-        x_put(par ^ 1, xq);                       // x chunk of tile i+2
+        if (is_gen(p1)) produce_b(p1.jb, p1.kc, b1, x1);
+        x_put(x1 ^ 1, xq);                        // x chunk of tile i+2
         if (is_gen(p3)) xq = x_fetch(p3.kc);
+        // ---- tile i+2 = p2: parked operands and the tile image, two tiles ahead.  The eight
+        // image requests come LAST: "at most 8 requests outstanding" in front of barrier i then
+        // means everything older -- tile i+1 completely -- has landed.
+        if (!is_gen(p2)) dma_parked(b2, p2.kc);
+        dma_tile(slot2, tile_off(p2.jb, p2.kc), 8);
         last_m2 = last_m1;
         last_m1 = (p1.jb == jb_hi - 1 && p1.kc == nkc_of(p1.jb) - 1);
-        p0 = p1; p1 = p2; p2 = p3; p3 = next_of(p3);
-        slot = slot == 2 ? 0 : slot + 1;
-        par ^= 1;
+        p1 = p2; p2 = p3; p3 = next_of(p3);
+        slot2 = slot2 == S2_NSLOT - 1 ? 0 : slot2 + 1;
+        b1 = b2;
+        b2 = b2 == 2 ? 0 : b2 + 1;
+        x1 ^= 1;
 #ifdef S2_TIMING
         { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - ft0; if (fgen) { fw_g += d_; ++fn_g; } else { fw_p += d_; ++fn_p; } }
 #endif
-        __syncthreads();                          // barrier i (hipcc drains the LDS-DMA queue first)
+        // barrier i without __syncthreads' full drain: the image requests of tile i+2 stay in flight
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- fast path: inside a row block's run of parked tiles (tiles i+1 .. i+3 parked, no
+        // block boundary near) an iteration is ten LDS-DMA requests, a few scalar adds and the
+        // barrier -- nothing else; a starved wavefront pays per instruction
+        if (park && p1.jb > 0 && p1.kc >= 2) {
+            const int nfast = S2_CPB * p1.jb - 2 - p1.kc;
+            if (nfast > 0) {
+                unsigned toff = tile_off(p2.jb, p2.kc) + (unsigned)hw_s * 1024u;
+                unsigned soff = (unsigned)p2.kc * (unsigned)(SW_BCH * 8) + (unsigned)hw_s * 1024u;
+                for (int n_ = 0; n_ < nfast; ++n_) {
+#ifdef S2_TIMING
+                    const unsigned long long ft0_ = __builtin_amdgcn_s_memtime();
+#endif
+                    {
+                        double* dst = Bbuf + b2 * 1024 + hw_s * 256;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)dst, 16, (unsigned)lane * 16u, soff, 0, SW_KAUX);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, SW_KAUX);
+                    }
+                    {
+                        double* dst = Aring + slot2 * S2_TILE + hw_s * 128;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + q * 512), 16, (unsigned)lane * 16u,
+                                                                     toff + (unsigned)(q * 4096), 0, 0);
+                    }
+                    toff += (unsigned)(SW_TILE * 8);
+                    soff += (unsigned)(SW_BCH * 8);
+                    slot2 = slot2 == S2_NSLOT - 1 ? 0 : slot2 + 1;
+                    b1 = b2;
+                    b2 = b2 == 2 ? 0 : b2 + 1;
+#ifdef S2_TIMING
+                    fw_p += __builtin_amdgcn_s_memtime() - ft0_; ++fn_p;
+#endif
+                    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                p1.kc += nfast; p2.kc += nfast; p3.kc += nfast;
+                x1 ^= nfast & 1;
+                i += nfast;
+            }
+        }
     }
 #ifdef S2_TIMING
-    if (a.dbg && blockIdx.x == 0 && ht == 0) { a.dbg[3] = fw_g; a.dbg[4] = fn_g; a.dbg[5] = fw_p; a.dbg[6] = fn_p; a.dbg[7] = fs_a; a.dbg[8] = fs_b; }
+    if (a.dbg && blockIdx.x == 0 && ht == 0) { a.dbg[3] = fw_g; a.dbg[4] = fn_g; a.dbg[5] = fw_p; a.dbg[6] = fn_p; }
 #endif
 }
 
@@ -1189,7 +1231,7 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     if (two_role) {
         // ---- two-role kernel (default) ----
         const int nrb2 = (int)((a.n + S2_ROWS - 1) / S2_ROWS);
-        const size_t lds2 = (3 * S2_TILE + 2 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + 2 * SW_CAND + 8 +
+        const size_t lds2 = (S2_NSLOT * S2_TILE + 3 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + 2 * SW_CAND + 8 +
                              4 * APGP_MAX_DIM) * sizeof(double);
         static bool attr2 = false;
         if (!attr2) {
