@@ -66,7 +66,7 @@ struct SweepArgs {
     double* sp_mu;
     int split;
     long long m, idx_offset;
-    int ndim, nrb, kind, has_box, n, ncache, ncache2, lin_order, halves;
+    int ndim, nrb, kind, has_box, n, ncache, ncache2, lin_order;
     double mean, amp, zeta, ybest, lin_coef;
     double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
     unsigned long long* dbg;   // phase cycle counters (APGP_SWEEP_TIMING=1 builds only)
@@ -654,13 +654,11 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 // written by the feeders between barrier i-1 and barrier i; the matrix wavefronts execute
 // barrier i after the first k-step of pair 4 of tile i and read tile i+1 only after it.
 // ===========================================================================
-#define S2_THREADS 768
-#define S2_MW 8                          // matrix wavefronts (two per SIMD)
+#define S2_THREADS 512
 #define S2_ROWS 256
 #define S2_TILE (S2_ROWS * SW_KC)        // doubles per tile image (32 KiB)
 #define S2_CPB (S2_ROWS / SW_KC)         // chunks per row-block width (16)
 #define S2_NP (S2_ROWS / 32)             // sub-block pairs per tile (8)
-#define S2_NSLOT 4                       // tile images in the LDS ring
 
 template <int DPAD, bool LIN>
 __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
@@ -669,18 +667,18 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     constexpr int NP = S2_NP;
     constexpr int XCHUNK16 = SW_KC * XS / 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Aring = smem;                         // S2_NSLOT tile images
-    double* Bbuf = Aring + S2_NSLOT * S2_TILE;    // 3 x 4 candidate groups x [2][64] x 16 B
-    double* Xbuf = Bbuf + 3 * 4 * 256;            // 2 x SW_KC x XS
+    double* Aring = smem;                         // 3 tile images
+    double* Bbuf = Aring + 3 * S2_TILE;           // 2 x 4 wavefronts x [2][64] x 16 B
+    double* Xbuf = Bbuf + 2 * 4 * 256;            // 2 x SW_KC x XS
     double* Etab = Xbuf + 2 * SW_KC * XS;
     double* Shq = Etab + APGP_EXP_TAB_N;          // sum V^2 per candidate (matrix -> feeder)
-    double* red_u = Shq + 2 * SW_CAND;
+    double* red_u = Shq + SW_CAND;
     long long* red_i = (long long*)(red_u + 4);
     double* Cst = red_u + 8;                      // sc | lo | hi | lw (4 x APGP_MAX_DIM), feeder only
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cl = lane & 15, kq = lane >> 4;
     apgp_exp_tab_load(Etab);
-    if (t == S2_MW * 64) {
+    if (t == 256) {
 #pragma unroll
         for (int d = 0; d < APGP_MAX_DIM; ++d) {
             Cst[d] = a.sc[d];
@@ -719,14 +717,8 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         if (jb >= jb_hi) { jb = jb_lo; blk += blk_step; }
     };
 
-    if (w < S2_MW) {
+    if (w < 4) {
         // =============================== matrix role ===============================
-        // wavefronts w and w + 4 share a SIMD and a candidate group (cg) and take the two
-        // 128-row halves (rh) of every tile: while one issues its LDS reads the other's MFMAs
-        // keep the pipe busy
-        constexpr int NPW = NP / 2;
-        const int cg = w & 3;
-        const int rh = __builtin_amdgcn_readfirstlane(w) >> 2;
         // lane whose B value this lane multiplies in rotation r (block b meets candidate
         // group b + r): the rotation is an LDS read address, not a register move
         int lr[4];
@@ -734,7 +726,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         for (int r = 0; r < 4; ++r) lr[r] = (lane & 48) | ((lane + 4 * r) & 15);
         f64x2 av[2][2][2];
         auto load_a = [&](f64x2 (&dst)[2][2], int slot, int p) {
-            const f64x2* A2 = (const f64x2*)(Aring + slot * S2_TILE) + rh * (NPW * 4 * 64) + lane;
+            const f64x2* A2 = (const f64x2*)(Aring + slot * S2_TILE) + lane;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -753,19 +745,19 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             for (int jb = jb_lo; jb < jb_hi; ++jb) {
                 const int nkc = nkc_of(jb);
                 const int ndiag0 = S2_CPB * jb;
-                double acc[2 * NPW][4];
+                double acc[2 * NP][4];
 #pragma unroll
-                for (int s_ = 0; s_ < 2 * NPW; ++s_)
+                for (int s_ = 0; s_ < 2 * NP; ++s_)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[s_][r] = 0.0;
                 int kc = 0;
                 auto do_tile = [&](auto pred_tag) {
                     constexpr bool PRED = decltype(pred_tag)::value;
-                    const int nslot = slot == S2_NSLOT - 1 ? 0 : slot + 1;
+                    const int nslot = slot == 2 ? 0 : slot + 1;
                     // B operands of this tile, all four rotations (published by the last barrier)
                     double brot[4][NKK];
                     {
-                        const f64x2* Bw = (const f64x2*)(Bbuf + bpar * 1024 + cg * 256);
+                        const f64x2* Bw = (const f64x2*)(Bbuf + bpar * 1024 + w * 256);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const f64x2 b0 = Bw[lr[r]], b1 = Bw[64 + lr[r]];
@@ -786,17 +778,16 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                     int p1 = (a.n - S2_ROWS * jb + 31) >> 5;
                     if (p1 > NP) p1 = NP;
 #pragma unroll
-                    for (int pr = 0; pr < NPW; ++pr) {
-                        const int gp = rh * NPW + pr;
-                        const bool act = !PRED || (gp >= p0 && gp < p1);
+                    for (int pr = 0; pr < NP; ++pr) {
+                        const bool act = !PRED || (pr >= p0 && pr < p1);
                         if (act) mfma_pair(pr, 0);
                         __builtin_amdgcn_sched_barrier(0);
 #ifdef S2_TIMING
-                        if (pr == NPW / 2) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); s2_wait += __builtin_amdgcn_s_memtime() - t0_; ++s2_nt; }
+                        if (pr == 4) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); s2_wait += __builtin_amdgcn_s_memtime() - t0_; ++s2_nt; }
 #else
-                        if (pr == NPW / 2) __syncthreads();    // barrier i: tile i+1 is complete
+                        if (pr == 4) __syncthreads();          // barrier i: tile i+1 is complete
 #endif
-                        if (pr + 1 < NPW) load_a(av[(pr + 1) & 1], slot, pr + 1);
+                        if (pr + 1 < NP) load_a(av[(pr + 1) & 1], slot, pr + 1);
                         else load_a(av[0], nslot, 0);
                         if (act) {
                             mfma_pair(pr, 1);
@@ -806,7 +797,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     slot = nslot;
-                    bpar = bpar == 2 ? 0 : bpar + 1;
+                    bpar ^= 1;
                 };
                 const int nstraight = (a.n - S2_ROWS * jb >= S2_ROWS) ? ndiag0 : 0;
                 for (; kc < nstraight; ++kc) do_tile(std::false_type{});
@@ -818,7 +809,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     qr[r] = 0.0;
 #pragma unroll
-                    for (int s_ = 0; s_ < 2 * NPW; ++s_) qr[r] = fma(acc[s_][r], acc[s_][r], qr[r]);
+                    for (int s_ = 0; s_ < 2 * NP; ++s_) qr[r] = fma(acc[s_][r], acc[s_][r], qr[r]);
                 }
                 double qs = qr[0];
 #pragma unroll
@@ -827,7 +818,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 qs += __shfl_xor(qs, 32);
                 qtot += qs;
             }
-            if (kq == 0) Shq[rh * SW_CAND + cg * 16 + cl] = qtot;
+            if (kq == 0) Shq[w * 16 + cl] = qtot;
             __syncthreads();                      // E1: sums visible to the feeders
             __syncthreads();                      // E2: block result written
         }
@@ -838,7 +829,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     }
 
     // ================================= feeder role =================================
-    const int hw = w - S2_MW, ht = t - S2_MW * 64;
+    const int hw = w - 4, ht = t - 256;
     const unsigned hoff = (unsigned)ht * 16u;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.linv, 0, (int)a.linv_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, (int)a.xs_bytes, 0x00020000);
@@ -945,8 +936,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             f64x2 o0, o1;
             o0.x = bfv[0]; o0.y = bfv[1]; o1.x = bfv[2]; o1.y = bfv[3];
             if (bb == 0) { f64x2* Bw = (f64x2*)(Bbuf + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
-            else if (bb == 1) { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
-            else { f64x2* Bw = (f64x2*)(Bbuf + 2048 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
+            else { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
         }
     };
     auto epilogue = [&]() {
@@ -954,8 +944,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         if (a.split) {
             if (kq == 0) {
                 const long long e = ((blk_fin - a.blk_begin) * SW_CAND + hw * 16 + cl) * nrb2 + jb_lo;
-                a.sp_q[2 * e] = Shq[hw * 16 + cl];
-                a.sp_q[2 * e + 1] = Shq[SW_CAND + hw * 16 + cl];
+                a.sp_q[e] = Shq[hw * 16 + cl];
                 a.sp_mu[e] = mu_fin;
             }
             __syncthreads();                      // E2
@@ -966,7 +955,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         const long long crow = blk_fin * SW_CAND + hw * 16 + cl;
         if (kq == 0 && (fl_fin & 4)) {
             double mu = mu_fin + a.mean;
-            double var = ktt_fin - (Shq[hw * 16 + cl] + Shq[SW_CAND + hw * 16 + cl]);
+            double var = ktt_fin - Shq[hw * 16 + cl];
             if (fl_fin & 2) { mu = NAN; var = NAN; }
             if (a.mu) a.mu[crow] = mu;
             if (a.var) a.var[crow] = var;
@@ -998,7 +987,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     // requested right after barrier i-1 into slot (i+1) % 3 / buffer (i+1) & 1 -- both free
     // since barrier i-1 -- and the vmcnt(0) hipcc places in front of barrier i publishes them.
     struct Pos { int jb, kc; long long bl; };
-    Pos p0 = {jb_lo, 0, blk0}, p1, p2, p3;   // p_k: tile i+k of the loop below
+    Pos p0 = {jb_lo, 0, blk0}, p1, p2, p3;
     auto next_of = [&](const Pos& p) { Pos q = p; successor(q.jb, q.kc, q.bl); return q; };
     p1 = next_of(p0); p2 = next_of(p1); p3 = next_of(p2);
     const int hw_s = __builtin_amdgcn_readfirstlane(hw);
@@ -1017,11 +1006,10 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, SW_KAUX);
     };
     auto is_gen = [&](const Pos& p) { return !park || p.kc >= S2_CPB * p.jb; };
-    // ---- prologue: tiles 0 and 1, the operands of tile 0, x chunks of tiles 0 and 1 ----
+    // ---- prologue: tile 0 and its operands, x chunks of tiles 0 and 1, requests for tile 1 ----
     __syncthreads();                              // C : constants visible
     load_candidates(p0.bl);
     dma_tile(0, tile_off(p0.jb, p0.kc), 8);
-    dma_tile(1, tile_off(p1.jb, p1.kc), 8);
     x_put(0, x_fetch(p0.kc));
     x_put(1, x_fetch(p1.kc));
     __syncthreads();                              // P0
@@ -1036,10 +1024,9 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     const long long ntot = ntile_blk * nblk_mine;
     bool last_m1 = (ntile_blk == 1), last_m2 = false;
 #ifdef S2_TIMING
-    unsigned long long fw_g = 0, fn_g = 0, fw_p = 0, fn_p = 0;
+    unsigned long long fw_g = 0, fn_g = 0, fw_p = 0, fn_p = 0, fs_a = 0, fs_b = 0;
 #endif
-    // slot2 / b2: ring slot and B buffer of tile i+2; b1 / x1: B buffer and x buffer of tile i+1
-    int slot2 = 2, b2 = 2, b1 = 1, x1 = 1;
+    int slot = 1, par = 1;
     for (long long i = 0;; ++i) {
         // the matrix wavefronts have just passed barrier i-1: if tile i-1 closed a candidate
         // block, finish that block
@@ -1049,70 +1036,32 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         const unsigned long long ft0 = __builtin_amdgcn_s_memtime();
         const bool fgen = is_gen(p1);
 #endif
-        // ---- tile i+1 = p1: generated operands (a parked tile's were requested an iteration ago)
+        // ---- produce tile i+1 = p1 ----
+        dma_tile(slot, tile_off(p1.jb, p1.kc), 8);
         if (p1.jb == jb_lo && p1.kc == 0) load_candidates(p1.bl);
-        if (is_gen(p1)) produce_b(p1.jb, p1.kc, b1, x1);
-        x_put(x1 ^ 1, xq);                        // x chunk of tile i+2
+#ifdef S2_TIMING
+        const unsigned long long ft1 = __builtin_amdgcn_s_memtime();
+#endif
+        if (is_gen(p1)) produce_b(p1.jb, p1.kc, par, par);
+        else dma_parked(par, p1.kc);
+#ifdef S2_TIMING
+        const unsigned long long ft2 = __builtin_amdgcn_s_memtime();
+        if (!fgen) { fs_a += ft1 - ft0; fs_b += ft2 - ft1; }
+#endif
+        x_put(par ^ 1, xq);                       // x chunk of tile i+2
         if (is_gen(p3)) xq = x_fetch(p3.kc);
-        // ---- tile i+2 = p2: parked operands and the tile image, two tiles ahead.  The eight
-        // image requests come LAST: "at most 8 requests outstanding" in front of barrier i then
-        // means everything older -- tile i+1 completely -- has landed.
-        if (!is_gen(p2)) dma_parked(b2, p2.kc);
-        dma_tile(slot2, tile_off(p2.jb, p2.kc), 8);
         last_m2 = last_m1;
         last_m1 = (p1.jb == jb_hi - 1 && p1.kc == nkc_of(p1.jb) - 1);
-        p1 = p2; p2 = p3; p3 = next_of(p3);
-        slot2 = slot2 == S2_NSLOT - 1 ? 0 : slot2 + 1;
-        b1 = b2;
-        b2 = b2 == 2 ? 0 : b2 + 1;
-        x1 ^= 1;
+        p0 = p1; p1 = p2; p2 = p3; p3 = next_of(p3);
+        slot = slot == 2 ? 0 : slot + 1;
+        par ^= 1;
 #ifdef S2_TIMING
         { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - ft0; if (fgen) { fw_g += d_; ++fn_g; } else { fw_p += d_; ++fn_p; } }
 #endif
-        // barrier i without __syncthreads' full drain: the image requests of tile i+2 stay in flight
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // ---- fast path: inside a row block's run of parked tiles (tiles i+1 .. i+3 parked, no
-        // block boundary near) an iteration is ten LDS-DMA requests, a few scalar adds and the
-        // barrier -- nothing else; a starved wavefront pays per instruction
-        if (park && p1.jb > 0 && p1.kc >= 2) {
-            const int nfast = S2_CPB * p1.jb - 2 - p1.kc;
-            if (nfast > 0) {
-                unsigned toff = tile_off(p2.jb, p2.kc) + (unsigned)hw_s * 1024u;
-                unsigned soff = (unsigned)p2.kc * (unsigned)(SW_BCH * 8) + (unsigned)hw_s * 1024u;
-                for (int n_ = 0; n_ < nfast; ++n_) {
-#ifdef S2_TIMING
-                    const unsigned long long ft0_ = __builtin_amdgcn_s_memtime();
-#endif
-                    {
-                        double* dst = Bbuf + b2 * 1024 + hw_s * 256;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)dst, 16, (unsigned)lane * 16u, soff, 0, SW_KAUX);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, SW_KAUX);
-                    }
-                    {
-                        double* dst = Aring + slot2 * S2_TILE + hw_s * 128;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + q * 512), 16, (unsigned)lane * 16u,
-                                                                     toff + (unsigned)(q * 4096), 0, 0);
-                    }
-                    toff += (unsigned)(SW_TILE * 8);
-                    soff += (unsigned)(SW_BCH * 8);
-                    slot2 = slot2 == S2_NSLOT - 1 ? 0 : slot2 + 1;
-                    b1 = b2;
-                    b2 = b2 == 2 ? 0 : b2 + 1;
-#ifdef S2_TIMING
-                    fw_p += __builtin_amdgcn_s_memtime() - ft0_; ++fn_p;
-#endif
-                    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                }
-                p1.kc += nfast; p2.kc += nfast; p3.kc += nfast;
-                x1 ^= nfast & 1;
-                i += nfast;
-            }
-        }
+        __syncthreads();                          // barrier i (hipcc drains the LDS-DMA queue first)
     }
 #ifdef S2_TIMING
-    if (a.dbg && blockIdx.x == 0 && ht == 0) { a.dbg[3] = fw_g; a.dbg[4] = fn_g; a.dbg[5] = fw_p; a.dbg[6] = fn_p; }
+    if (a.dbg && blockIdx.x == 0 && ht == 0) { a.dbg[3] = fw_g; a.dbg[4] = fn_g; a.dbg[5] = fw_p; a.dbg[6] = fn_p; a.dbg[7] = fs_a; a.dbg[8] = fs_b; }
 #endif
 }
 
@@ -1145,15 +1094,7 @@ __global__ __launch_bounds__(64) void sweep_finish_kernel(SweepArgs a) {
         if (a.mask && a.mask[crow] == 0) adm = false;
         const long long e0 = ((long long)blockIdx.x * SW_CAND + c) * a.nrb;
         double q = 0.0, mup = 0.0;
-        if (a.halves == 2) {
-            // two-role kernel: the two row halves of a row block are summed by different
-            // wavefronts, each over the row blocks in order, and added at the end
-            double q1 = 0.0;
-            for (int ib = 0; ib < a.nrb; ++ib) { q += a.sp_q[2 * (e0 + ib)]; q1 += a.sp_q[2 * (e0 + ib) + 1]; mup += a.sp_mu[e0 + ib]; }
-            q += q1;
-        } else {
-            for (int ib = 0; ib < a.nrb; ++ib) { q += a.sp_q[e0 + ib]; mup += a.sp_mu[e0 + ib]; }
-        }
+        for (int ib = 0; ib < a.nrb; ++ib) { q += a.sp_q[e0 + ib]; mup += a.sp_mu[e0 + ib]; }
         double mu = mup + a.mean;
         double var = fma(a.lin_coef, ktl, a.amp) - q;
         if (has_nan) { mu = NAN; var = NAN; }
@@ -1193,7 +1134,6 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
         attr_set = true;
     }
     SweepArgs a = a0;
-    a.halves = 1;
     const long long ncb = (a.m + SW_CAND - 1) / SW_CAND;
     static int timing = -1;
     if (timing < 0) { const char* e = getenv("APGP_SWEEP_TIMING"); timing = (e && e[0] == '1') ? 1 : 0; }
@@ -1231,7 +1171,7 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     if (two_role) {
         // ---- two-role kernel (default) ----
         const int nrb2 = (int)((a.n + S2_ROWS - 1) / S2_ROWS);
-        const size_t lds2 = (S2_NSLOT * S2_TILE + 3 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + 2 * SW_CAND + 8 +
+        const size_t lds2 = (3 * S2_TILE + 2 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + SW_CAND + 8 +
                              4 * APGP_MAX_DIM) * sizeof(double);
         static bool attr2 = false;
         if (!attr2) {
@@ -1240,7 +1180,6 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
             attr2 = true;
         }
         a.nrb = nrb2;
-        a.halves = 2;
         a.ncache = a.ncache2;
         a.kslot_bytes = (unsigned)((a.ncache > 0 ? a.ncache : 1) * SW_BCH * 8);
 #ifdef S2_TIMING
@@ -1311,7 +1250,7 @@ extern "C" int64_t apgp_acquire_work_len(int64_t m, int64_t n) {
     const long long slots = ncb < SW_GRID ? ncb : SW_GRID;
     const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
     // (parked stream sized for the 256-row-block kernel: 32 nrb - 16 chunks per slot)
-    return 2 * ncb + slots * (sweep_ncache(n) + 16) * SW_BCH + 6 * (long long)SW_SPLIT_MAX * SW_CAND * nrb;
+    return 2 * ncb + slots * (sweep_ncache(n) + 16) * SW_BCH + 2 * (long long)SW_SPLIT_MAX * SW_CAND * 2 * nrb;
 }
 
 extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
@@ -1347,7 +1286,7 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
         const long long slots = nblk < SW_GRID ? nblk : SW_GRID;
         const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
         a.sp_q = part ? (double*)part + 2 * nblk + slots * (sweep_ncache(n) + 16) * SW_BCH : NULL;
-        a.sp_mu = a.sp_q ? a.sp_q + (long long)SW_SPLIT_MAX * SW_CAND * 4 * nrb : NULL;
+        a.sp_mu = a.sp_q ? a.sp_q + (long long)SW_SPLIT_MAX * SW_CAND * 2 * nrb : NULL;
         a.blk_begin = 0; a.blk_end = nblk; a.split = 0;
     }
     {
