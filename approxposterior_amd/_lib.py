@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libapgp.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_DIM = 16
 
 UTIL_AGP, UTIL_BAPE, UTIL_JONES, UTIL_NONE = 0, 1, 2, 3
@@ -54,6 +54,7 @@ SIGNATURES = {
     "apgp_logdet": (ctypes.c_int, [_P, _I64, _I64, _P, _P]),
     "apgp_fit_summary": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
     "apgp_nll_eval": (ctypes.c_int, [_P, _I64, _KP, _P, _F64, _P, _P, _P, _P, _P, _P]),
+    "apgp_nll_eval_batch": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "apgp_trsv": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, ctypes.c_int, _P, _P, _P]),
     "apgp_trtri_pack": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
     "apgp_pack_train": (ctypes.c_int, [_P, _P, _I64, _KP, _P, _P]),

@@ -36,7 +36,16 @@ struct PotrfArgs {
     long long j0;        // first column of the current block
     double shift;        // rhs is used as (rhs - shift); applied at block step 0 .. as read
     int* info;
+    // batched factorisation (apgp_nll_eval_batch): blockIdx.y selects the matrix
+    long long batch_A, batch_rhs;   // element strides between consecutive matrices / right-hand sides
 };
+
+// matrix of this workgroup in a batched launch (gridDim.y = batch size; strides 0 otherwise)
+__device__ __forceinline__ void potrf_select(PotrfArgs& a) {
+    a.A += (long long)blockIdx.y * a.batch_A;
+    if (a.rhs) a.rhs += (long long)blockIdx.y * a.batch_rhs;
+    a.info += blockIdx.y;
+}
 
 // Panel step, one wavefront per workgroup: workgroup b owns the 64 panel rows
 // [j0 + 64 + 64 b, +64) and re-factorises the 64x64 diagonal block itself (it is the
@@ -77,6 +86,7 @@ __host__ __device__ constexpr int trsm_gcount(int k, int g) {
 }
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
+    potrf_select(a);
     __shared__ __attribute__((aligned(16))) double col[2][PB];
     __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];   // +2: row-per-lane writes spread over the banks
     __shared__ __attribute__((aligned(16))) double invd[PB];
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
 // trailing update: tile (bi, bk), bi >= bk, of the blocks below/right of column block j:
 // A[ri.., rk..] -= L[ri.., j0..j0+64) * L[rk.., j0..j0+64)^T
 __global__ __launch_bounds__(256) void potrf_update_kernel(PotrfArgs a) {
+    potrf_select(a);
     __shared__ double Ls[PB][PB + 1];   // L[ri + r][j0 + k]
     __shared__ double Rs[PB][PB + 1];   // L[rk + c][j0 + k]
     // linear tile index -> (bi, bk) in the lower triangle
@@ -343,7 +354,41 @@ __global__ __launch_bounds__(256) void potrf_rhs_init_kernel(const double* y, do
 }
 
 __global__ void potrf_finish_kernel(int* info) {
+    info += blockIdx.x;
     if (*(unsigned int*)info == 0xffffffffu) *info = 0;
+}
+
+// `batch` matrices A + b * batch_A (right-hand sides y - shifts[b] -> z + b * n) factorised by
+// the same launches: gridDim.y = batch.  The Cholesky of one small matrix is a chain of
+// latency-bound steps that leaves most of the chip idle, so a batch costs little more than one.
+static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t batch_A, const double* y,
+                     const double* shifts, double* z, int32_t* info_dev, hipStream_t s) {
+    // info = UINT_MAX means "no failure yet"; normalised to 0 by the caller-visible finish kernel
+    if (hipMemsetAsync(info_dev, 0xff, sizeof(int32_t) * batch, s) != hipSuccess) {
+        apgp_set_error("apgp_potrf: memset failed");
+        return -2;
+    }
+    PotrfArgs a;
+    a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = 0.0; a.info = info_dev;
+    a.batch_A = batch_A; a.batch_rhs = n;
+    if (z)
+        for (int64_t b = 0; b < batch; ++b)
+            hipLaunchKernelGGL(potrf_rhs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, shifts[b],
+                               z + b * n, (long long)n);
+    const long long nb = (n + PB - 1) / PB;
+    for (long long jb = 0; jb < nb; ++jb) {
+        a.j0 = jb * PB;
+        const long long below = n - (a.j0 + PB);
+        const unsigned pg = below > 0 ? (unsigned)((below + PB - 1) / PB) : 1u;
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg, (unsigned)batch), dim3(PB), 0, s, a);
+        if (below > 0) {
+            const long long tb = (below + PB - 1) / PB;
+            hipLaunchKernelGGL(potrf_update_kernel, dim3((unsigned)(tb * (tb + 1) / 2), (unsigned)batch), dim3(256), 0, s, a);
+        }
+    }
+    hipLaunchKernelGGL(potrf_finish_kernel, dim3((unsigned)batch), dim3(1), 0, s, info_dev);
+    APGP_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, double shift, double* z,
@@ -351,29 +396,7 @@ extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, do
     APGP_CHECK_ARG(A && info_dev, "null pointer");
     APGP_CHECK_ARG((y == NULL) == (z == NULL), "y and z must be given together");
     APGP_CHECK_ARG(n >= 1 && lda >= n, "n >= 1 and lda >= n required");
-    hipStream_t s = (hipStream_t)stream;
-    // info = UINT_MAX means "no failure yet"; normalised to 0 by the caller-visible finish kernel
-    if (hipMemsetAsync(info_dev, 0xff, sizeof(int32_t), s) != hipSuccess) {
-        apgp_set_error("apgp_potrf: memset failed");
-        return -2;
-    }
-    PotrfArgs a;
-    a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = shift; a.info = info_dev;
-    if (z) hipLaunchKernelGGL(potrf_rhs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, shift, z, (long long)n);
-    const long long nb = (n + PB - 1) / PB;
-    for (long long jb = 0; jb < nb; ++jb) {
-        a.j0 = jb * PB;
-        const long long below = n - (a.j0 + PB);
-        const unsigned pg = below > 0 ? (unsigned)((below + PB - 1) / PB) : 1u;
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg), dim3(PB), 0, s, a);
-        if (below > 0) {
-            const long long tb = (below + PB - 1) / PB;
-            hipLaunchKernelGGL(potrf_update_kernel, dim3((unsigned)(tb * (tb + 1) / 2)), dim3(256), 0, s, a);
-        }
-    }
-    hipLaunchKernelGGL(potrf_finish_kernel, dim3(1), dim3(1), 0, s, info_dev);
-    APGP_CHECK_LAUNCH();
-    return 0;
+    return potrf_run(A, n, lda, 1, 0, y, &shift, z, info_dev, (hipStream_t)stream);
 }
 
 // One gpUtils._nll evaluation (gpUtils.py:46-80) as ONE library call: Gram matrix ->
@@ -398,6 +421,32 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
     if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         apgp_set_error("apgp_nll_eval: D2H copy failed");
+        return -2;
+    }
+    return 0;
+}
+
+// `batch` _nll evaluations at different hyper-parameters of the SAME training set in one call
+// (several hyper-vectors per launch for optimizeGP's restarts):
+// batch Gram launches, ONE batched Cholesky (gridDim.y = batch), batch summary launches, one
+// 40 * batch byte copy, one synchronisation.  Every matrix goes through exactly the code path
+// of apgp_nll_eval, so the values are bit-identical to `batch` single calls.
+extern "C" int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch, const apgp_kernel_t* kerns,
+                                   const double* y, const double* means, double* K, double* z,
+                                   int32_t* info_dev, double* out5_dev, double* out5_host, void* stream) {
+    APGP_CHECK_ARG(X && kerns && y && means && K && z && info_dev && out5_dev && out5_host, "null pointer");
+    APGP_CHECK_ARG(batch >= 1 && batch <= 65535, "1 <= batch <= 65535 required");
+    APGP_CHECK_ARG(n >= 1, "n >= 1 required");
+    int rc;
+    for (int64_t b = 0; b < batch; ++b)
+        if ((rc = apgp_gram(X, n, kerns + b, K + b * n * n, n, stream)) != 0) return rc;
+    if ((rc = potrf_run(K, n, n, batch, n * n, y, means, z, info_dev, (hipStream_t)stream)) != 0) return rc;
+    for (int64_t b = 0; b < batch; ++b)
+        if ((rc = apgp_fit_summary(K + b * n * n, n, n, z + b * n, info_dev + b, out5_dev + 5 * b, stream)) != 0) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double) * batch, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        apgp_set_error("apgp_nll_eval_batch: D2H copy failed");
         return -2;
     }
     return 0;

@@ -611,6 +611,66 @@ class GP(object):
             raise
         return ll if np.isfinite(ll) else -np.inf
 
+    def nll_batch(self, P, y):
+        """Negative marginal log-likelihood at each hyper-parameter vector of ``P`` (B x P),
+        evaluated by ONE batched Gram + Cholesky + solve call (``apgp_nll_eval_batch``;
+        SURVEY.md section 8(f) rank 3).  Entry b is what ``gpUtils._nll(P[b], gp, y, None)``
+        returns -- bit-identical, every matrix takes the code path of the single call --
+        with ``+inf`` for a non-positive-definite Gram matrix.  The GP's own parameter
+        vector is restored; its factorisation is marked stale."""
+        torch, dev, lib = self._rt()
+        if self._x is None:
+            raise RuntimeError("You need to compute the model first")
+        yv = self._check_dimensions(y)
+        P = np.atleast_2d(np.asarray(P, dtype=np.float64))
+        B, n = len(P), len(self._x)
+        out = np.full(B, np.inf)
+        saved = self.get_parameter_vector()
+        structs, means, live = [], [], []
+        try:
+            for b in range(B):
+                try:
+                    self.set_parameter_vector(P[b])
+                    ks = self._kernel_struct()
+                except (LinAlgError, ValueError, OverflowError):
+                    continue
+                structs.append(ks)
+                means.append(float(self.mean.value))
+                live.append(b)
+        finally:
+            self.set_parameter_vector(saved)
+        if not live:
+            return out
+        # chunks bounded by 2 GiB of Gram-matrix work space
+        per = max(1, int((2 << 30) // (8 * n * n)))
+        with torch.cuda.device(dev):
+            st = self._stream(torch)
+            if getattr(self, "_x_d", None) is None:
+                self._x_d = torch.from_numpy(self._x).to(dev)
+            y_d = torch.from_numpy(yv).to(dev)
+            for c0 in range(0, len(live), per):
+                idx = live[c0:c0 + per]
+                nb = len(idx)
+                karr = (_lib.KernelStruct * nb)(*structs[c0:c0 + nb])
+                marr = np.array(means[c0:c0 + nb], dtype=np.float64)
+                K = torch.empty((nb, n, n), dtype=torch.float64, device=dev)
+                z = torch.empty((nb, n), dtype=torch.float64, device=dev)
+                info = torch.empty(nb, dtype=torch.int32, device=dev)
+                o_d = torch.empty((nb, 5), dtype=torch.float64, device=dev)
+                o = np.empty((nb, 5), dtype=np.float64)
+                _lib.check(lib.apgp_nll_eval_batch(self._x_d.data_ptr(), n, nb, ctypes.addressof(karr),
+                                                   y_d.data_ptr(), marr.ctypes.data, K.data_ptr(), z.data_ptr(),
+                                                   info.data_ptr(), o_d.data_ptr(), o.ctypes.data, st),
+                           "apgp_nll_eval_batch")
+                for j, b in enumerate(idx):
+                    if int(o[j, 4]) != 0 or not np.isfinite(o[j, 0]):
+                        continue
+                    const = -0.5 * (n * np.log(2.0 * np.pi) + float(o[j, 0]))
+                    ll = const - 0.5 * float(o[j, 3])
+                    if np.isfinite(ll):
+                        out[b] = -ll
+        return out
+
     # -- packed factor / training stream for the sweep -------------------------------
     def _ensure_linv(self):
         torch, dev, lib = self._rt()

@@ -75,18 +75,118 @@ def defaultGP(theta, y, order=None, white_noise=-12, fitAmp=False):
     return gp
 
 
+class _LockStep(object):
+    """Rendezvous that turns the objective calls of several concurrently running SciPy
+    optimisers into batched device calls: a worker posts its point and blocks; when every
+    still-running worker has posted, the last arrival evaluates the whole batch with
+    ``batchFn`` and wakes the others.  Each optimiser sees exactly the values it would see
+    running alone, so the restarts' trajectories do not depend on the batching."""
+
+    def __init__(self, nWorkers, batchFn):
+        import threading
+        self._cv = threading.Condition()
+        self._active = nWorkers
+        self._batchFn = batchFn
+        self._pending = {}
+        self._results = {}
+
+    def _flush(self):
+        ids = sorted(self._pending)
+        pts = [self._pending[i] for i in ids]
+        self._pending = {}
+        try:
+            vals = self._batchFn(pts)
+        except BaseException as err:          # hand the failure to every waiting worker
+            vals = [err] * len(ids)
+        for i, v in zip(ids, vals):
+            self._results[i] = v
+        self._cv.notify_all()
+
+    def evaluate(self, wid, p):
+        with self._cv:
+            self._pending[wid] = np.array(p, dtype=np.float64, copy=True)
+            if len(self._pending) >= self._active:
+                self._flush()
+            while wid not in self._results:
+                self._cv.wait()
+            v = self._results.pop(wid)
+        if isinstance(v, BaseException):
+            raise v
+        return v
+
+    def retire(self, wid):
+        with self._cv:
+            self._active -= 1
+            if self._pending and len(self._pending) >= self._active:
+                self._flush()
+
+
+def _minimizeLockStep(gp, y, x0s, method, options, priorFn):
+    """The restarts of :func:`optimizeGP` as concurrent SciPy runs (one thread each) whose
+    ``_nll`` evaluations are served in lock-step by ``gp.nll_batch`` -- one batched
+    Gram + Cholesky per round instead of one per restart."""
+    import threading
+    step = _LockStep(len(x0s), lambda pts: gp.nll_batch(np.array(pts), y))
+    sols, errs = [None] * len(x0s), [None] * len(x0s)
+
+    def work(k):
+        def fn(p):
+            # the prior gate of _nll (gpUtils.py:68-70) needs no device work
+            if priorFn is not None and not np.isfinite(priorFn(p)):
+                return np.inf
+            return float(step.evaluate(k, p))
+        try:
+            sols[k] = minimize(fn, x0s[k], method=method, jac=None, bounds=None, options=options)["x"]
+        except BaseException as err:
+            errs[k] = err
+        finally:
+            step.retire(k)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(x0s))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for err in errs:
+        if err is not None:
+            raise err
+    return sols
+
+
 def optimizeGP(gp, theta, y, seed=None, nGPRestarts=1, method="powell",
-               options=None, p0=None, gpHyperPrior=defaultHyperPrior):
+               options=None, p0=None, gpHyperPrior=defaultHyperPrior, batchRestarts=True):
     """Maximise the marginal log-likelihood over the GP hyper-parameters with
     ``nGPRestarts`` SciPy runs and keep the best (gpUtils.py:184-257).  ``seed``
-    and ``theta`` are accepted and unused, as in the reference (quirk Q6)."""
+    and ``theta`` are accepted and unused, as in the reference (quirk Q6).
+
+    With ``batchRestarts`` (default) and a derivative-free ``method`` the restarts run
+    concurrently and their ``_nll`` evaluations are batched on the device; start points,
+    per-restart trajectories and the selected optimum are those of the sequential loop
+    (the optimisers draw no random numbers, and a batched evaluation is bit-identical to a
+    single one).  ``batchRestarts=False`` runs the reference's sequential loop."""
+    derivativeFree = method in ["nelder-mead", "powell", "cg"]
+    if batchRestarts and nGPRestarts > 1 and derivativeFree and hasattr(gp, "nll_batch"):
+        x0s = []
+        for _ in range(nGPRestarts):
+            if p0 is None:
+                x0s.append([np.median(y)] + [np.random.randn() for _ in range(len(gp.get_parameter_vector()) - 1)])
+            else:
+                x0s.append(np.array(p0) + np.min(p0) * 1.0e-3 * np.random.randn(len(p0)))
+        res = _minimizeLockStep(gp, y, x0s, method, options, gpHyperPrior)
+        # marginal likelihood at each solution: one more batch (the sequential loop's
+        # set_parameter_vector + recompute + log_likelihood, gpUtils.py:243-247)
+        mll = -gp.nll_batch(np.array(res), y)
+        best = int(np.argmax(mll))
+        gp.set_parameter_vector(res[best])
+        gp.recompute()
+        return gp
     res, mll = [], []
     for _ in range(nGPRestarts):
         if p0 is None:
             x0 = [np.median(y)] + [np.random.randn() for _ in range(len(gp.get_parameter_vector()) - 1)]
         else:
             x0 = np.array(p0) + np.min(p0) * 1.0e-3 * np.random.randn(len(p0))
-        jac = None if method in ["nelder-mead", "powell", "cg"] else _grad_nll
+        jac = None if derivativeFree else _grad_nll
         sol = minimize(_nll, x0, args=(gp, y, gpHyperPrior), method=method,
                        jac=jac, bounds=None, options=options)["x"]
         res.append(sol)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define APGP_ABI_VERSION 2
+#define APGP_ABI_VERSION 3
 #define APGP_MAX_DIM 16          /* feature dimension D supported by the kernels */
 #define APGP_ROW_BLOCK 512       /* rows per packed L^-1 row block (sweep tile)  */
 #define APGP_K_CHUNK 16          /* contraction depth per packed tile            */
@@ -133,6 +133,18 @@ int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/
                   const double* y, double mean, double* K, double* z,
                   int32_t* info_dev, double* out5_dev, double* out5_host /*host*/,
                   void* stream);
+
+/* ---- `batch` _nll evaluations at different hyper-parameters, one call ----------
+ * (the restarts of gpUtils.optimizeGP, gpUtils.py:223-247,
+ * evaluated in lock-step.)  Same training set X, y; kerns[batch] / means[batch] on the
+ * host; K: batch x n x n work (the factors on return), z: batch x n, info_dev: batch
+ * int32, out5_dev / out5_host: batch x 5 doubles laid out as apgp_fit_summary's record.
+ * One batched Cholesky (gridDim.y = batch): values bit-identical to single calls.    */
+int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch,
+                        const apgp_kernel_t* kerns /*host*/, const double* y,
+                        const double* means /*host*/, double* K, double* z,
+                        int32_t* info_dev, double* out5_dev, double* out5_host /*host*/,
+                        void* stream);
 
 /* ---- K3: triangular solves for z = L^-1 (b - shift), alpha = L^-T z --------
  * Replaces BasicSolver.apply_inverse / dot_solve on a vector (scipy cho_solve;

@@ -189,3 +189,51 @@ def test_default_gp_with_linear_order_end_to_end():
     assert np.all(np.isfinite(tT)) and np.all(np.abs(tT) <= 5) and np.isfinite(yT)
     assert len(ap.gp.get_parameter_vector()) == 6 and ap.gp.computed and len(ap.y) == 41
     assert np.isfinite(ap.gp.log_likelihood(ap.y))
+
+
+@pytest.mark.parametrize("n,d", [(50, 2), (700, 5)])
+def test_nll_batch_is_bit_identical_to_single_evaluations(n, d):
+    """apgp_nll_eval_batch: several hyper-vectors through ONE batched
+    Gram + Cholesky + solve.  Every entry equals gpUtils._nll of that vector exactly --
+    including +inf for a non-positive-definite matrix -- and the GP's own state survives."""
+    import time
+    from approxposterior_amd import gpUtils
+    rs = np.random.RandomState(5)
+    X = rs.uniform(-5, 5, size=(n, d))
+    y = np.sin(X).sum(axis=1) + 0.1 * rs.randn(n)
+    np.random.seed(2)
+    gp = gpUtils.defaultGP(X, y, fitAmp=True)
+    p_own = np.array(gp.get_parameter_vector())
+    P = np.array([p_own + 0.3 * rs.randn(len(p_own)) for _ in range(7)])
+    P[3, 1] = 750.0                 # amplitude overflows: the factorisation must fail
+    t0 = time.time()
+    with np.errstate(all="ignore"):
+        batch = gp.nll_batch(P, y)
+    t_batch = time.time() - t0
+    assert np.array_equal(gp.get_parameter_vector(), p_own)
+    t0 = time.time()
+    with np.errstate(all="ignore"):
+        single = np.array([gpUtils._nll(p, gp, y, None) for p in P])
+    t_single = time.time() - t0
+    assert np.array_equal(batch, single), (batch, single)
+    assert np.isinf(batch[3]) and np.all(np.isfinite(np.delete(batch, 3)))
+    print("nll_batch N=%d: 7 evaluations %.2f ms batched, %.2f ms one by one" % (n, 1e3 * t_batch, 1e3 * t_single))
+
+
+def test_optimizegp_batched_restarts_equal_sequential():
+    """gpUtils.optimizeGP with its restarts evaluated in lock-step on the device returns
+    exactly the hyper-parameters of the reference's sequential loop (gpUtils.py:223-254)."""
+    import time
+    from approxposterior_amd import gpUtils, likelihood as lh
+    out = {}
+    for mode in (False, True):
+        np.random.seed(57)
+        theta = lh.rosenbrockSample(60)
+        y = np.array([lh.rosenbrockLnlike(t) + lh.rosenbrockLnprior(t) for t in theta])
+        gp = gpUtils.defaultGP(theta, y, white_noise=-12)
+        t0 = time.time()
+        with np.errstate(all="ignore"):
+            gp = gpUtils.optimizeGP(gp, theta, y, seed=57, nGPRestarts=4, batchRestarts=mode)
+        out[mode] = (np.array(gp.get_parameter_vector()), time.time() - t0)
+    assert np.array_equal(out[False][0], out[True][0])
+    print("optimizeGP 4 restarts N=60: sequential %.2f s, batched %.2f s" % (out[False][1], out[True][1]))

@@ -197,3 +197,73 @@ def test_linear_kernel_sum_protocol_and_flattening():
         agp.kernels.LinearKernel(log_gamma2=0.0, order=1.5, ndim=2)
     with pytest.raises(NotImplementedError):
         agp._flatten_kernel(agp.kernels.LinearKernel(log_gamma2=0.0, order=1, ndim=2))   # no SE term
+
+
+class _BatchingOracleGP(object):
+    """The oracle GP plus an ``nll_batch`` that loops over ``gpUtils._nll`` (what the device
+    batch computes, one vector at a time) and records the batch sizes it was handed."""
+
+    def __init__(self, gp):
+        self._gp = gp
+        self.batches = []
+
+    def __getattr__(self, name):
+        return getattr(self._gp, name)
+
+    def nll_batch(self, P, y):
+        self.batches.append(len(P))
+        saved = self._gp.get_parameter_vector()
+        out = np.array([gpUtils._nll(np.array(p), self._gp, y, None) for p in P])
+        self._gp.set_parameter_vector(saved)
+        return out
+
+
+def test_lockstep_restarts_follow_the_sequential_trajectories():
+    """optimizeGP's restarts run concurrently with their _nll calls
+    batched.  Start points, every restart's solution and the selected optimum must be those
+    of the reference's sequential loop (gpUtils.py:223-254), bit for bit."""
+    np.random.seed(57)
+    theta, y = rosen_set(30)
+    with np.errstate(all="ignore"):
+        np.random.seed(11)
+        gp_a = oracle_default_gp(theta, y, False)
+        np.random.seed(3)
+        seq = gpUtils.optimizeGP(gp_a, theta, y, nGPRestarts=3, batchRestarts=False)
+        p_seq = np.array(seq.get_parameter_vector())
+        np.random.seed(11)
+        gp_b = _BatchingOracleGP(oracle_default_gp(theta, y, False))
+        np.random.seed(3)
+        bat = gpUtils.optimizeGP(gp_b, theta, y, nGPRestarts=3, batchRestarts=True)
+        p_bat = np.array(bat.get_parameter_vector())
+    assert np.array_equal(p_seq, p_bat)
+    assert max(gp_b.batches) == 3 and min(gp_b.batches) >= 1      # batched while >1 restart is running
+    assert gp_b.batches[-1] == 3                                   # the final mll batch
+
+
+def test_lockstep_evaluator_edge_cases():
+    """Workers with different numbers of evaluations retire without deadlock, the prior gate
+    answers without a device call, and a failing batch raises in the caller."""
+    calls = []
+
+    class Quad(object):
+        def nll_batch(self, P, y):
+            calls.append(len(P))
+            return np.array([float(np.sum((np.asarray(p) - 1.0) ** 2)) for p in P])
+
+    x0s = [np.full(3, 1.0 + 1e-9), np.full(3, 70.0), np.array([2.0, -3.0, 0.5])]
+    sols = gpUtils._minimizeLockStep(Quad(), None, x0s, "nelder-mead", {"xatol": 1e-8, "fatol": 1e-12}, None)
+    for s_, x0 in zip(sols, x0s):
+        assert np.allclose(s_, 1.0, atol=1e-3) and len(s_) == len(x0)
+    assert 3 in calls and min(calls) < 3          # the restarts finish at different times
+    # prior that forbids everything: no batch is ever evaluated
+    calls[:] = []
+    gpUtils._minimizeLockStep(Quad(), None, [np.zeros(2), np.ones(2)], "powell", {"maxiter": 2},
+                              lambda p: -np.inf)
+    assert calls == []
+
+    class Broken(object):
+        def nll_batch(self, P, y):
+            raise RuntimeError("device lost")
+
+    with pytest.raises(RuntimeError):
+        gpUtils._minimizeLockStep(Broken(), None, [np.zeros(2), np.ones(2)], "powell", None, None)

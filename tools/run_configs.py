@@ -74,8 +74,18 @@ def c5_pieces():
         with np.errstate(all="ignore"):
             ap.optGP(nGPRestarts=1)
         print("C5 optGP N=%d: one Powell restart: %.2f s" % (N, time.time() - t0))
+        p_start = np.array(ap.gp.get_parameter_vector())
+        for mode in (False, True):
+            ap.gp.set_parameter_vector(p_start)
+            ap.gp.recompute()
+            np.random.seed(9)
+            t0 = time.time()
+            with np.errstate(all="ignore"):
+                gpUtils.optimizeGP(ap.gp, ap.theta, ap.y, nGPRestarts=4, batchRestarts=mode)
+            print("C5 optGP N=%d: four Powell restarts, %s: %.2f s" % (N, "lock-step batched" if mode else "sequential", time.time() - t0))
 
 
 if __name__ == "__main__":
-    c1()
+    if "--c5" not in sys.argv:
+        c1()
     c5_pieces()
