@@ -2,6 +2,7 @@
 #define APGP_PANEL_TIMING 1
 #include "../approxposterior_amd/csrc/potrf.hip"
 #include "../approxposterior_amd/csrc/gram.hip"
+#include "../approxposterior_amd/csrc/linalg.hip"
 #include <vector>
 int main() {
     const long long n = 4096;
