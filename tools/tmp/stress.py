@@ -1,0 +1,22 @@
+import sys, os, time, numpy as np
+sys.path.insert(0, os.getcwd())
+from approxposterior_amd import gp as agp
+from scipy.optimize import rosen
+rs = np.random.RandomState(1)
+bad = 0
+t00 = time.time()
+for (n, d, m, kind) in [(4096, 8, 70000, "agp"), (1152, 8, 200000, "bape"), (2100, 5, 33000, "jones"), (700, 16, 50000, "agp"),
+                        (300, 2, 100000, "bape"), (4096, 8, 3000, "agp"), (5000, 3, 20000, "bape")]:
+    X = rs.uniform(-5, 5, size=(n, d)); y = np.array([-rosen(x) / 100 for x in X]) if d > 1 else np.sin(X[:, 0])
+    gp = agp.GP(kernel=agp.ExpSquaredKernel(np.full(d, 8.0), ndim=d), fit_mean=True, mean=np.median(y), white_noise=-10, fit_white_noise=False)
+    gp.compute(X)
+    T = rs.uniform(-5, 5, size=(m, d))
+    ref = gp.acquire(y, T, kind, bounds=[(-5, 5)] * d, return_all=True)
+    reps = 60
+    for r in range(reps):
+        out = gp.acquire(y, T, kind, bounds=[(-5, 5)] * d, return_all=True)
+        ok = out[0] == ref[0] and out[1] == ref[1] and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out[2:], ref[2:]))
+        if not ok:
+            bad += 1
+    print("n=%d d=%d m=%d %s: %d launches, mismatches so far %d, %.1f s" % (n, d, m, kind, reps, bad, time.time() - t00), flush=True)
+print("STRESS", "FAILED" if bad else "OK")
