@@ -1,3 +1,5 @@
+"""_nll latency (single and batches of eight) at N = 50 ... 4096 with checksums, for A/B runs of
+the Cholesky (python tools/nll_timing.py on the GPU box)."""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.getcwd())
 import torch

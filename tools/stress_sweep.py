@@ -1,3 +1,5 @@
+"""Repeat-launch stress of the hand-synchronised sweep: seven shapes x 60 launches, every output
+bit-identical to the first launch (python tools/stress_sweep.py on the GPU box)."""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.getcwd())
 from approxposterior_amd import gp as agp
