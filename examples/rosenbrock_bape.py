@@ -4,8 +4,10 @@ only the import line differs (``approxposterior`` -> ``approxposterior_amd``).
     python examples/rosenbrock_bape.py            # host-loop sampler, any lnprior
     python examples/rosenbrock_bape.py --device   # final MCMC inside one persistent kernel (box prior)
 """
+import os
 import sys
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a checkout
 from approxposterior_amd import approx, gpUtils, likelihood as lh
 
 m0, m, nmax = 50, 20, 2                       # initial design, points per iteration, iterations
