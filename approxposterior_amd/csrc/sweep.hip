@@ -5,7 +5,12 @@
 //   utility.AGPUtility / BAPEUtility / JonesUtility (utility.py:99-250)
 //   utility.minimizeObjective's arg-min             (utility.py:369-371)
 //
-// Data flow per workgroup (256 threads = 4 wavefronts, one per SIMD, 64 candidates):
+// Two kernels implement it: sweep2_kernel (the two-role kernel further down: matrix wavefronts
+// + feeder wavefronts, the default) and sweep_kernel (the one-role kernel of rounds 1a-1d,
+// kept behind APGP_SWEEP2=0 as the A/B reference).  They share the packed formats, the
+// candidate -> lane mapping, the row-block split mode and the finishing kernels.
+//
+// Data flow of the one-role kernel per workgroup (256 threads = 4 wavefronts, one per SIMD, 64 candidates):
 //   * wavefront w owns candidates [16 w, 16 w + 16) (one MFMA column block);
 //     the scaled candidate coordinates are parked in LDS (only generating
 //     tiles need them).
