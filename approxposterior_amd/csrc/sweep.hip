@@ -744,7 +744,18 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
 #ifdef S2_TIMING
         unsigned long long s2_wait = 0, s2_nt = 0, s2_t0 = __builtin_amdgcn_s_memtime();
 #endif
+        // B operands of the current tile in all four rotations; half 0 = k-steps 0-1, 1 = 2-3
+        double brot[4][NKK];
+        auto load_b = [&](int buf, int half) {
+            const f64x2* Bw = (const f64x2*)(Bbuf + buf * 1024 + w * 256) + half * 64;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f64x2 bv = Bw[lr[r]];
+                brot[r][2 * half] = bv.x; brot[r][2 * half + 1] = bv.y;
+            }
+        };
         load_a(av[0], 0, 0);
+        load_b(0, 0);
         for (long long blk = blk0; blk < a.blk_end; blk += blk_step) {
             double qtot = 0.0;
             for (int jb = jb_lo; jb < jb_hi; ++jb) {
@@ -759,16 +770,6 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 auto do_tile = [&](auto pred_tag) {
                     constexpr bool PRED = decltype(pred_tag)::value;
                     const int nslot = slot == 2 ? 0 : slot + 1;
-                    // B operands of this tile, all four rotations (published by the last barrier)
-                    double brot[4][NKK];
-                    {
-                        const f64x2* Bw = (const f64x2*)(Bbuf + bpar * 1024 + w * 256);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const f64x2 b0 = Bw[lr[r]], b1 = Bw[64 + lr[r]];
-                            brot[r][0] = b0.x; brot[r][1] = b0.y; brot[r][2] = b1.x; brot[r][3] = b1.y;
-                        }
-                    }
                     auto mfma_pair = [&](int pr, int kk) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -792,12 +793,29 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
 #else
                         if (pr == 4) __syncthreads();          // barrier i: tile i+1 is complete
 #endif
-                        if (pr + 1 < NP) load_a(av[(pr + 1) & 1], slot, pr + 1);
-                        else load_a(av[0], nslot, 0);
-                        if (act) {
-                            mfma_pair(pr, 1);
-                            mfma_pair(pr, 2);
-                            mfma_pair(pr, 3);
+                        if (pr + 1 < NP) {
+                            // (first pair: the k-step 2-3 half of this tile's B operands; its
+                            // registers were still in use when the 0-1 half was prefetched)
+                            if (pr == 0) load_b(bpar, 1);
+                            load_a(av[(pr + 1) & 1], slot, pr + 1);
+                            if (act) {
+                                mfma_pair(pr, 1);
+                                mfma_pair(pr, 2);
+                                mfma_pair(pr, 3);
+                            }
+                        } else {
+                            // last pair: the next tile's first A fragments and, as soon as this
+                            // tile's k-step 0-1 B registers fall free, that half of the next
+                            // tile's B operands (published by this tile's barrier): their LDS
+                            // latency hides behind the 16 MFMAs of k-steps 2-3
+                            load_a(av[0], nslot, 0);
+                            if (act) mfma_pair(pr, 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            load_b(bpar ^ 1, 0);
+                            if (act) {
+                                mfma_pair(pr, 2);
+                                mfma_pair(pr, 3);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
