@@ -45,11 +45,12 @@
 #define SW_GRID 256                  // persistent workgroups = K* scratch slots (one per CU)
 #define SW_BCH (SW_THREADS * 4)      // doubles of parked B operands per chunk per slot
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// cache policy of the parked-operand stream: each workgroup slot is written once and read
-// back once per later row block, 256 slots x 2 MB never fit the L2 -- marked non-temporal
-// (aux bit 1 = nt).  Measured neutral at C3 (L2 hit rate and kernel time unchanged).
+// cache policy of the parked-operand stream (aux bits of its buffer loads / stores): 0 = default.
+// Each workgroup slot is written once and read back once per later row block and 256 slots x
+// 2 MB never fit the L2, so a non-temporal hint (aux 2) looked right -- measured alternating on
+// one box with the two-role kernel it is 0.5 % slower than the default policy (256.5 vs 257.9 ms).
 #ifndef SW_KAUX
-#define SW_KAUX 2
+#define SW_KAUX 0
 #endif
 
 struct SweepArgs {
