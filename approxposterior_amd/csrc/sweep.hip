@@ -1073,7 +1073,13 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         if (!fgen) { fs_a += ft1 - ft0; fs_b += ft2 - ft1; }
 #endif
         x_put(par ^ 1, xq);                       // x chunk of tile i+2
-        if (is_gen(p3)) xq = x_fetch(p3.kc);
+        // VMEM requests of this iteration that barrier i need NOT wait for: the park stores of a
+        // first-visit tile (read back a row block later) and the x chunk fetched for tile i+3 (a
+        // register load hipcc tracks itself).  They are the LAST requests issued, and gfx9 VMEM
+        // completes in issue order, so "at most n outstanding" still means the images and parked
+        // operands of tile i+1 have landed -- without the ~1-2 k cycles of store acknowledgement.
+        int n_pend = (is_gen(p1) && park && p1.kc >= S2_CPB * p1.jb && p1.jb + 1 < nrb2) ? 2 : 0;
+        if (is_gen(p3)) { xq = x_fetch(p3.kc); ++n_pend; }
         last_m2 = last_m1;
         last_m1 = (p1.jb == jb_hi - 1 && p1.kc == nkc_of(p1.jb) - 1);
         p0 = p1; p1 = p2; p2 = p3; p3 = next_of(p3);
@@ -1082,7 +1088,11 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
 #ifdef S2_TIMING
         { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - ft0; if (fgen) { fw_g += d_; ++fn_g; } else { fw_p += d_; ++fn_p; } }
 #endif
-        __syncthreads();                          // barrier i (hipcc drains the LDS-DMA queue first)
+        // barrier i
+        if (n_pend == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (n_pend == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (n_pend == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #ifdef S2_TIMING
     if (a.dbg && blockIdx.x == 0 && ht == 0) { a.dbg[3] = fw_g; a.dbg[4] = fn_g; a.dbg[5] = fw_p; a.dbg[6] = fn_p; a.dbg[7] = fs_a; a.dbg[8] = fs_b; }
