@@ -3,32 +3,45 @@
 :py:mod:`approx.py` - ApproxPosterior: the callers of the GP-surrogate hot path
 -------------------------------------------------------------------------------
 
-Mirror of the hot-path callers of the reference's ``approxposterior/approx.py``:
-``ApproxPosterior.__init__`` (:77-145), ``_gpll`` (:148-189), ``optGP``
-(:192-226) and ``findNextPoint`` (:527-754), with the same signatures, defaults,
-return shapes and error behaviour, running on the HIP-backed GP of
-:py:mod:`approxposterior_amd.gp`.
+The class the reference's users hold (``approxposterior/approx.py``): same public
+method names, argument names, defaults, return shapes, random-number draw order
+and cache files --
 
-Additions the reference does not have (all off by default so reference-style
-scripts behave the same):
+    ApproxPosterior(theta, y, lnprior, lnlike, priorSample, bounds, gp, algorithm)  :77-145
+    _gpll(theta)                          surrogate log-probability        :148-189
+    optGP(...)                            hyper-parameter re-fit           :192-226
+    run(m, nmax, ...)                     BAPE / AGP outer loop            :229-524
+    findNextPoint(...)                    design-point selection           :527-754
+    runMCMC(...)                          surrogate MCMC                   :757-859
+    findMAP(...)                          MAP of the GP mean               :862-926
+    bayesOpt(nmax, ...)                   Bayesian optimisation            :929-1151
 
-* ``findNextPoint(nCandidates=M)`` replaces the restarted Nelder-Mead search by
-  the fused device sweep over ``M`` prior draws (optionally polished by one
-  Nelder-Mead run from the winner);
-* ``_gpllBatch`` evaluates the surrogate log-probability for a whole walker
-  ensemble in one launch (what an ensemble sampler calls with vectorize=True).
+-- organised around the device path instead of the reference's inline loops: a
+design point is found by :meth:`_selectPoint` (restarted Nelder-Mead as in the
+reference, or the fused HIP sweep over ``nCandidates`` prior draws), absorbed by
+:meth:`_absorbPoint` (training set + O(N^2) extension of the device-resident
+Cholesky factor) and the stopping rules live in two small monitor classes.  The
+supported way to run the reference's *own* loop on the MI355X is INTEGRATION.md
+level 1 (hand the reference's ``ApproxPosterior`` a ``gp=`` from this package);
+this class is for scripts that import ``approxposterior_amd`` directly.
 
-The outer-loop glue -- ``run`` (:229-524), ``runMCMC`` (:757-859), ``findMAP``
-(:862-926), ``bayesOpt`` (:929-1151) -- follows the reference's control flow on
-top of the build-side ensemble sampler (:py:mod:`approxposterior_amd.mcmc`,
-emcee is not installable here) and writes the same ``.npz`` caches; the emcee
-HDF5 backend is replaced by a ``<runName>.npz`` chain dump (h5py is absent).
+Additions the reference does not have (all off by default):
+
+* ``nCandidates=M`` (``findNextPoint`` / ``run`` / ``bayesOpt``): point search by the
+  fused sweep over ``M`` ``priorSample`` draws, optionally ``polish``-ed by one
+  Nelder-Mead run from the winner;
+* ``_gpllBatch``: the surrogate log-probability of a whole walker ensemble in one
+  launch (what the ensemble sampler calls with ``vectorize=True``);
+* ``runMCMC(onDevice=True)`` / ``run(onDevice=True)``: the whole chain as one
+  persistent kernel (box prior only).
+
+The emcee HDF5 backend is replaced by a ``<runName>.npz`` chain dump (h5py and emcee
+are not installable here; :py:mod:`approxposterior_amd.mcmc` restates the sampler).
 """
 
-import numpy as np
-from scipy.optimize import minimize
-
 import time
+
+import numpy as np
 
 from . import gp as george
 from . import gpUtils
@@ -38,14 +51,62 @@ from . import utility as ut
 
 __all__ = ["ApproxPosterior"]
 
+_UTILITIES = {"bape": ut.BAPEUtility, "agp": ut.AGPUtility,
+              "alternate": ut.AGPUtility, "jones": ut.JonesUtility}
+
+
+def _cacheName(runName, suffix):
+    return "%s%s.npz" % (runName, suffix)
+
+
+class _MarginalMonitor(object):
+    """Stop rule of ``run`` (approx.py:476-523): the marginal posterior means of
+    successive iterations, in units of the previous iteration's marginal standard
+    deviations, must stay below ``eps`` for ``kmax`` consecutive iterations."""
+
+    def __init__(self, eps, kmax):
+        self.eps, self.kmax = eps, kmax
+        self.means, self.stds, self.zscores = [], [], []
+        self.streak = 0
+
+    def update(self, samples):
+        mean, std = np.mean(samples, axis=0), np.std(samples, axis=0)
+        if self.means:
+            z = np.fabs((mean - self.means[-1]) / self.stds[-1])
+            self.zscores.append(z)
+            self.streak = self.streak + 1 if np.all(z < self.eps) else 0
+        self.means.append(mean)
+        self.stds.append(std)
+        return self.streak >= self.kmax
+
+    def save(self, path):
+        np.savez(path, means=self.means, stds=self.stds, zscores=self.zscores,
+                 eps=self.eps, kmax=self.kmax, finalIteration=self.streak)
+
+
+class _PlateauMonitor(object):
+    """Stop rule of ``bayesOpt`` (approx.py:1118-1128): ``kmax`` consecutive
+    iterations whose best value moved by less than ``tol``."""
+
+    def __init__(self, tol, kmax):
+        self.tol, self.kmax = tol, kmax
+        self.last = None
+        self.streak = 0
+
+    def update(self, value):
+        if self.last is not None:
+            self.streak = self.streak + 1 if np.fabs(value - self.last) < self.tol else 0
+        self.last = value
+        return self.streak >= self.kmax
+
 
 class ApproxPosterior(object):
     """Approximate-posterior driver around a GP surrogate (approx.py:29-145).
 
-    Parameters are those of the reference: the training set ``theta`` (N, D) /
-    ``y`` (N,), the callables ``lnprior``, ``lnlike``, ``priorSample``, the box
-    ``bounds`` (one (lo, hi) per dimension), an optional pre-built ``gp`` and
-    the point-selection ``algorithm`` in {"bape", "agp", "alternate", "jones"}.
+    ``theta`` (N, D) / ``y`` (N,) is the initial training set, ``lnprior``,
+    ``lnlike`` and ``priorSample`` the user's callables, ``bounds`` one (lo, hi)
+    pair per dimension, ``gp`` an optional pre-built GP and ``algorithm`` one of
+    "bape", "agp", "alternate", "jones".
     """
 
     def __init__(self, theta, y, lnprior, lnlike, priorSample, bounds, gp=None,
@@ -54,77 +115,64 @@ class ApproxPosterior(object):
             raise ValueError("Must supply both theta and y for initial GP training set.")
         self.theta = np.array(theta).squeeze()
         self.y = np.array(y).squeeze()
-        self.ndim = 1 if self.theta.ndim <= 1 else theta.shape[-1]
-        if np.any(~np.isfinite(self.theta)) or np.any(~np.isfinite(self.y)):
-            print("theta, y:", theta, y)
+        self.ndim = theta.shape[-1] if self.theta.ndim > 1 else 1
+        if not (np.all(np.isfinite(self.theta)) and np.all(np.isfinite(self.y))):
             raise ValueError("All theta and y values must be finite!")
         if len(bounds) != self.ndim:
             raise ValueError("ERROR: bounds provided but len(bounds) != ndim.\n"
                              "ndim = %d, len(bounds) = %d" % (self.ndim, len(bounds)))
         self.bounds = bounds
-        self._lnprior = lnprior
-        self._lnlike = lnlike
-        self.priorSample = priorSample
+        self._lnprior, self._lnlike, self.priorSample = lnprior, lnlike, priorSample
         self.algorithm = str(algorithm).lower()
-        table = {"bape": ut.BAPEUtility, "agp": ut.AGPUtility,
-                 "alternate": ut.AGPUtility, "jones": ut.JonesUtility}
-        if self.algorithm not in table:
+        if self.algorithm not in _UTILITIES:
             raise ValueError("Unknown algorithm. Valid options: bape, agp, naive, or alternate.")
-        self.utility = table[self.algorithm]
-        self.iburns = list()
-        self.ithins = list()
-        self.backends = list()
+        self.utility = _UTILITIES[self.algorithm]
+        self.iburns, self.ithins, self.backends, self.gpPar = [], [], [], []
         self.sampler = None
-        self.gpPar = list()
         if gp is None:
             print("INFO: No GP specified. Initializing GP using ExpSquaredKernel.")
-            self.gp = gpUtils.defaultGP(self.theta, self.y)
-        else:
-            self.gp = gp
+            gp = gpUtils.defaultGP(self.theta, self.y)
+        self.gp = gp
 
-    # ------------------------------------------------------------------ _gpll
+    # ------------------------------------------------------- surrogate log-probability
     def _gpll(self, theta, *args, **kwargs):
-        """Surrogate log-probability for one point: ``(mu(theta), lnprior)`` or
-        ``(-inf, nan)`` under the reference's three guards (approx.py:148-189):
-        all-non-finite theta, non-finite prior, non-finite / failed prediction."""
+        """``(mu(theta), lnprior(theta))``, or ``(-inf, nan)`` when theta has no finite
+        coordinate, the prior excludes it, or the prediction fails / is not finite
+        (the three guards of approx.py:148-189)."""
+        rejected = (-np.inf, np.nan)
         if not np.any(np.isfinite(theta)):
-            return -np.inf, np.nan
-        lnprior = self._lnprior(theta)
-        if not np.isfinite(lnprior):
-            return -np.inf, np.nan
+            return rejected
+        prior = self._lnprior(theta)
+        if not np.isfinite(prior):
+            return rejected
         try:
-            mu = self.gp.predict(self.y, np.array(theta).reshape(1, -1),
-                                 return_cov=False, return_var=False)
+            mean = self.gp.predict(self.y, np.array(theta).reshape(1, -1),
+                                   return_cov=False, return_var=False)
         except ValueError:
-            return -np.inf, np.nan
-        if not np.isfinite(mu):
-            return -np.inf, np.nan
-        return mu, lnprior
+            return rejected
+        return (mean, prior) if np.isfinite(mean) else rejected
 
     def _gpllBatch(self, thetas):
-        """Vectorised :meth:`_gpll` for a walker ensemble ``thetas`` (W, D): one
-        mean-only device launch.  Returns ``(logp (W,), lnprior (W,))`` with the
-        same guard semantics row by row."""
-        thetas = np.asarray(thetas, dtype=float)
-        if thetas.ndim == 1:
-            thetas = thetas.reshape(-1, self.ndim)
-        W = len(thetas)
-        lp = np.full(W, -np.inf)
-        blob = np.full(W, np.nan)
-        pri = np.array([self._lnprior(t) if np.any(np.isfinite(t)) else -np.inf for t in thetas],
-                       dtype=float)
-        ok = np.isfinite(pri)
-        if ok.any():
-            safe = np.where(np.isfinite(thetas[ok]), thetas[ok], 0.0)
-            mu = self.gp.predict(self.y, safe, return_cov=False, return_var=False)
-            mu = np.where(np.all(np.isfinite(thetas[ok]), axis=1), mu, np.nan)
-            good = np.isfinite(mu)
-            idx = np.flatnonzero(ok)
-            lp[idx[good]] = mu[good]
-            blob[idx[good]] = pri[idx[good]]
-        return lp, blob
+        """:meth:`_gpll` for a whole walker ensemble ``thetas`` (W, D) with one
+        mean-only device launch: ``(logp (W,), lnprior (W,))``, guarded row by row."""
+        pts = np.asarray(thetas, dtype=float)
+        if pts.ndim == 1:
+            pts = pts.reshape(-1, self.ndim)
+        logp = np.full(len(pts), -np.inf)
+        blob = np.full(len(pts), np.nan)
+        prior = np.array([self._lnprior(p) if np.any(np.isfinite(p)) else -np.inf for p in pts],
+                         dtype=float)
+        rows = np.flatnonzero(np.isfinite(prior))
+        if rows.size:
+            finite = np.all(np.isfinite(pts[rows]), axis=1)
+            mean = self.gp.predict(self.y, np.where(np.isfinite(pts[rows]), pts[rows], 0.0),
+                                   return_cov=False, return_var=False)
+            keep = rows[finite & np.isfinite(mean)]
+            logp[keep] = mean[finite & np.isfinite(mean)]
+            blob[keep] = prior[keep]
+        return logp, blob
 
-    # ------------------------------------------------------------------ optGP
+    # ------------------------------------------------------------------ GP re-fit
     def optGP(self, seed=None, method="powell", options=None, p0=None,
               nGPRestarts=1, gpHyperPrior=gpUtils.defaultHyperPrior):
         """Re-fit the GP hyper-parameters in place (approx.py:192-226)."""
@@ -132,7 +180,43 @@ class ApproxPosterior(object):
                                      method=method, options=options, p0=p0,
                                      nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
 
-    # ---------------------------------------------------------- findNextPoint
+    # ------------------------------------------------------- design-point selection
+    def _selectPoint(self, utility, theta0, nRestarts, method, options, nCandidates, polish):
+        """One design point: the minimiser of ``utility`` over the prior."""
+        scalarArgs = (self.y, self.gp, self._lnprior)
+        if nCandidates is None:
+            return ut.minimizeObjective(utility, self.y, self.gp, sampleFn=self.priorSample,
+                                        priorFn=self._lnprior, nRestarts=nRestarts, method=method,
+                                        options=options, bounds=self.bounds, theta0=theta0,
+                                        args=scalarArgs)
+        draws = np.asarray(self.priorSample(int(nCandidates)), dtype=float)
+        point, value = ut.sweepObjective(utility, self.y, self.gp,
+                                         draws.reshape(int(nCandidates), -1), bounds=self.bounds)
+        if polish:
+            point, value = ut.minimizeObjective(utility, self.y, self.gp,
+                                                sampleFn=self.priorSample, priorFn=self._lnprior,
+                                                nRestarts=1, method=method, options=options,
+                                                bounds=self.bounds, theta0=point, args=scalarArgs)
+        return point, value
+
+    def _absorbPoint(self, point, value):
+        """Append (point, value) to the training set and move the GP onto it: same
+        kernel / mean / white-noise objects and hyper-parameters (approx.py:693-717); the
+        device GP extends its factor by one row instead of refactorising."""
+        stack = np.vstack if self.theta.ndim > 1 else np.hstack
+        self.theta = stack([self.theta, np.array(point)])
+        self.y = np.hstack([self.y, value])
+        hyper = self.gp.get_parameter_vector()
+        grown = george.GP(kernel=self.gp.kernel, fit_mean=True, mean=self.gp.mean,
+                          white_noise=self.gp.white_noise, fit_white_noise=False)
+        grown.set_parameter_vector(hyper)
+        if hasattr(grown, "_try_extend"):
+            grown.compute(self.theta, previous=self.gp)
+        else:
+            grown.compute(self.theta)
+        self.gp = grown
+        return hyper
+
     def findNextPoint(self, theta0=None, computeLnLike=True, seed=None,
                       cache=True, gpOptions=None, gpP0=None, verbose=True,
                       nGPRestarts=1, nMinObjRestarts=5, gpMethod="powell",
@@ -140,156 +224,104 @@ class ApproxPosterior(object):
                       runName="apRun", numNewPoints=1, optGPEveryN=1,
                       gpHyperPrior=gpUtils.defaultHyperPrior, args=None,
                       nCandidates=None, polish=False, **kwargs):
-        """Select ``numNewPoints`` design points by minimising the (negative)
-        utility, optionally evaluate the forward model there, append to the
-        training set, re-factorise and periodically re-fit the GP
-        (approx.py:527-754; same return shapes :745-753).
+        """Select ``numNewPoints`` design points by minimising the (negative) utility;
+        with ``computeLnLike`` evaluate the forward model at each, absorb it into the
+        training set / GP and re-fit the hyper-parameters every ``optGPEveryN`` points
+        (approx.py:527-754).  Returns ``theta`` or ``(theta, y)`` -- a single point /
+        value when ``numNewPoints == 1``, arrays otherwise (approx.py:745-753).
 
-        With ``nCandidates`` the point search is the fused device sweep over
-        that many ``priorSample`` draws (box ``bounds`` fused as the prior)
-        instead of ``nMinObjRestarts`` Nelder-Mead runs; ``polish`` then refines
-        the winner with one Nelder-Mead run of the scalar utility.
+        ``nCandidates`` replaces the restarted Nelder-Mead search by the fused device
+        sweep over that many ``priorSample`` draws (box ``bounds`` as the prior);
+        ``polish`` refines the sweep winner with one Nelder-Mead run.
         """
         assert isinstance(numNewPoints, int) and numNewPoints >= 1
         assert isinstance(optGPEveryN, int) and optGPEveryN >= 1
         if verbose and numNewPoints < optGPEveryN:
-            print("WARNING: numNewPoints < optGPEveryN."
-                  "GP hyperparameters will not be re-optimized. Set "
-                  "numNewPoints < optGPEveryN to fix this, if important (it probably is).")
-        if args is None:
-            args = ()
-        newTheta = list()
-        newY = list()
-        for ii in range(numNewPoints):
-            if self.algorithm == "alternate":      # AGP on even, BAPE on odd (approx.py:656-661)
-                self.utility = ut.AGPUtility if ii % 2 == 0 else ut.BAPEUtility
-            if nCandidates is None:
-                thetaT, uT = ut.minimizeObjective(self.utility, self.y, self.gp,
-                                                  sampleFn=self.priorSample,
-                                                  priorFn=self._lnprior,
-                                                  nRestarts=nMinObjRestarts,
-                                                  method=minObjMethod,
-                                                  options=minObjOptions,
-                                                  bounds=self.bounds, theta0=theta0,
-                                                  args=(self.y, self.gp, self._lnprior))
-            else:
-                cands = np.asarray(self.priorSample(int(nCandidates)), dtype=float)
-                cands = cands.reshape(int(nCandidates), -1)
-                thetaT, uT = ut.sweepObjective(self.utility, self.y, self.gp, cands,
-                                               bounds=self.bounds)
-                if polish:
-                    thetaT, uT = ut.minimizeObjective(self.utility, self.y, self.gp,
-                                                      sampleFn=self.priorSample,
-                                                      priorFn=self._lnprior, nRestarts=1,
-                                                      method=minObjMethod, options=minObjOptions,
-                                                      bounds=self.bounds, theta0=thetaT,
-                                                      args=(self.y, self.gp, self._lnprior))
-            newTheta.append(thetaT)
-            if computeLnLike:
-                loglikeT = self._lnlike(thetaT, *args, **kwargs)
-                if hasattr(loglikeT, "__iter__"):
-                    yT = np.array([loglikeT[0] + self._lnprior(thetaT)])
-                else:
-                    yT = np.array([loglikeT + self._lnprior(thetaT)])
-                newY.append(yT)
-                if self.theta.ndim > 1:
-                    self.theta = np.vstack([self.theta, np.array(thetaT)])
-                else:
-                    self.theta = np.hstack([self.theta, thetaT])
-                self.y = np.hstack([self.y, yT])
-                try:
-                    currentHype = self.gp.get_parameter_vector()
-                    if verbose:
-                        print('hyperparameters', currentHype)
-                    if cache:
-                        self.gpPar.append(currentHype)
-                    # same kernel / mean / white-noise objects, new training set
-                    oldGP = self.gp
-                    self.gp = george.GP(kernel=self.gp.kernel, fit_mean=True,
-                                        mean=self.gp.mean,
-                                        white_noise=self.gp.white_noise,
-                                        fit_white_noise=False)
-                    self.gp.set_parameter_vector(currentHype)
-                    if hasattr(self.gp, "_try_extend"):
-                        # same hyper-parameters, one more row: O(N^2) factor extension
-                        self.gp.compute(self.theta, previous=oldGP)
-                    else:
-                        self.gp.compute(self.theta)
-                    if ii % optGPEveryN == 0:
-                        self.optGP(seed=seed, method=gpMethod, options=gpOptions,
-                                   p0=gpP0, nGPRestarts=nGPRestarts,
-                                   gpHyperPrior=gpHyperPrior)
-                except ValueError:
-                    print("theta:", self.theta)
-                    print("y:", self.y)
-                    print("gp parameters names:", self.gp.get_parameter_names())
-                    print("gp parameters:", self.gp.get_parameter_vector())
-                    raise ValueError("GP couldn't optimize!")
+            print("WARNING: numNewPoints < optGPEveryN: the GP hyperparameters will not be "
+                  "re-optimized during this call.")
+        fwdArgs = () if args is None else args
+        points, values = [], []
+        for count in range(numNewPoints):
+            if self.algorithm == "alternate":      # AGP, BAPE, AGP, ... (approx.py:656-661)
+                self.utility = (ut.AGPUtility, ut.BAPEUtility)[count % 2]
+            point, _ = self._selectPoint(self.utility, theta0, nMinObjRestarts, minObjMethod,
+                                         minObjOptions, nCandidates, polish)
+            points.append(point)
+            if not computeLnLike:
+                continue
+            like = self._lnlike(point, *fwdArgs, **kwargs)
+            like = like[0] if hasattr(like, "__iter__") else like      # (lnlike, blobs...) allowed
+            value = np.array([like + self._lnprior(point)])
+            values.append(value)
+            try:
+                hyper = self._absorbPoint(point, value)
+                if verbose:
+                    print("hyperparameters", hyper)
                 if cache:
-                    np.savez(str(runName) + "APFModelCache.npz", theta=self.theta, y=self.y)
+                    self.gpPar.append(hyper)
+                if count % optGPEveryN == 0:
+                    self.optGP(seed=seed, method=gpMethod, options=gpOptions, p0=gpP0,
+                               nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
+            except ValueError:
+                raise ValueError("GP couldn't optimize! names %s, parameters %s, %d training points"
+                                 % (self.gp.get_parameter_names(), self.gp.get_parameter_vector(),
+                                    len(self.y)))
+            if cache:
+                np.savez(_cacheName(runName, "APFModelCache"), theta=self.theta, y=self.y)
         if numNewPoints == 1:
-            newTheta = newTheta[0]
-            if computeLnLike:
-                newY = newY[0]
+            points = points[0]
+            values = values[0] if computeLnLike else values
         if computeLnLike:
-            return np.asarray(newTheta), np.asarray(newY)
-        return np.asarray(newTheta)
+            return np.asarray(points), np.asarray(values)
+        return np.asarray(points)
 
-    # ---------------------------------------------------------------- runMCMC
+    # ------------------------------------------------------------------ surrogate MCMC
+    def _dumpChain(self, runName):
+        path = _cacheName(runName, "")
+        self.backends.append(path)
+        blobs = self.sampler.get_blobs()
+        np.savez(path, chain=self.sampler.get_chain(), log_prob=self.sampler.get_log_prob(),
+                 blobs=np.array([]) if blobs is None else blobs)
+
     def runMCMC(self, samplerKwargs=None, mcmcKwargs=None, runName="apRun",
                 cache=True, estBurnin=True, thinChains=True, verbose=False,
                 args=None, batched=True, onDevice=False, **kwargs):
-        """Sample the GP surrogate posterior with the stretch-move ensemble
-        sampler and estimate burn-in / thinning (approx.py:757-859).  Returns
-        ``(sampler, iburn, ithin)``.
+        """Sample the GP-surrogate posterior with the stretch-move ensemble sampler and
+        estimate burn-in / thinning (approx.py:757-859): ``(sampler, iburn, ithin)``.
 
-        ``batched=True`` (default) evaluates each half-ensemble with ONE
-        mean-only GP launch (``_gpllBatch``); ``batched=False`` calls the scalar
-        ``_gpll`` once per walker exactly as emcee does for the reference;
-        ``onDevice=True`` runs the entire chain as one persistent kernel
-        (``GP.sample_ensemble``) -- only valid when ``lnprior`` is the box prior
-        ``self.bounds`` (constant inside, -inf outside).
-        With ``cache=True`` the finished chain is written to ``<runName>.npz``
-        (keys chain, log_prob, blobs) where the reference writes ``<runName>.h5``.
+        ``batched`` (default) evaluates each half-ensemble with ONE mean-only GP launch
+        (:meth:`_gpllBatch`); ``batched=False`` calls :meth:`_gpll` once per walker as
+        emcee does for the reference; ``onDevice=True`` runs the entire chain as one
+        persistent kernel (``GP.sample_ensemble``) -- valid when ``lnprior`` is the box
+        prior ``self.bounds`` (constant inside, -inf outside), which the caller asserts.
+        With ``cache`` the chain goes to ``<runName>.npz`` (keys chain, log_prob, blobs)
+        where the reference writes ``<runName>.h5``.
         """
         samplerKwargs, mcmcKwargs = mcmcUtils.validateMCMCKwargs(self, samplerKwargs,
                                                                  mcmcKwargs, verbose)
         if onDevice:
-            # the whole loop as one persistent kernel; valid when lnprior is the box
-            # prior self.bounds (constant inside, -inf outside), which the caller asserts
-            res = self.gp.sample_ensemble(self.y, mcmcKwargs["initial_state"],
-                                          mcmcKwargs["iterations"], self.bounds,
-                                          seed=np.random.randint(0, 2 ** 31 - 1))
-            self.sampler = emcee.DeviceChain(res)
-            if cache:
-                bname = str(runName) + ".npz"
-                self.backends.append(bname)
-                np.savez(bname, chain=self.sampler.get_chain(), log_prob=self.sampler.get_log_prob(),
-                         blobs=np.array([]))
-            iburn, ithin = mcmcUtils.estimateBurnin(self.sampler, estBurnin=estBurnin,
-                                                    thinChains=thinChains, verbose=verbose)
-            return self.sampler, iburn, ithin
-        skw = dict(samplerKwargs)
-        if batched:
-            skw["log_prob_fn"] = lambda thetas, *a, **k: self._gpllBatch(thetas)
-            skw["vectorize"] = True
-        self.sampler = emcee.EnsembleSampler(**skw, backend=None, args=args, kwargs=kwargs,
-                                             blobs_dtype=[("lnprior", float)])
-        for _ in self.sampler.sample(**mcmcKwargs):
-            pass
+            result = self.gp.sample_ensemble(self.y, mcmcKwargs["initial_state"],
+                                             mcmcKwargs["iterations"], self.bounds,
+                                             seed=np.random.randint(0, 2 ** 31 - 1))
+            self.sampler = emcee.DeviceChain(result)
+        else:
+            setup = dict(samplerKwargs)
+            if batched:
+                setup["log_prob_fn"] = lambda pts, *a, **k: self._gpllBatch(pts)
+                setup["vectorize"] = True
+            self.sampler = emcee.EnsembleSampler(**setup, backend=None, args=args, kwargs=kwargs,
+                                                 blobs_dtype=[("lnprior", float)])
+            for _ in self.sampler.sample(**mcmcKwargs):
+                pass
         if verbose:
             print("mcmc finished")
         if cache:
-            bname = str(runName) + ".npz"
-            self.backends.append(bname)
-            blobs = self.sampler.get_blobs()
-            np.savez(bname, chain=self.sampler.get_chain(), log_prob=self.sampler.get_log_prob(),
-                     blobs=np.array([]) if blobs is None else blobs)
+            self._dumpChain(runName)
         iburn, ithin = mcmcUtils.estimateBurnin(self.sampler, estBurnin=estBurnin,
                                                 thinChains=thinChains, verbose=verbose)
         return self.sampler, iburn, ithin
 
-    # -------------------------------------------------------------------- run
+    # ---------------------------------------------------------------------- outer loop
     def run(self, m=10, nmax=2, seed=None, timing=False, verbose=True,
             mcmcKwargs=None, samplerKwargs=None, estBurnin=False,
             thinChains=False, runName="apRun", cache=True, gpMethod="powell",
@@ -297,178 +329,153 @@ class ApproxPosterior(object):
             nMinObjRestarts=5, onlyLastMCMC=False, initGPOpt=True, kmax=3,
             gpHyperPrior=gpUtils.defaultHyperPrior, eps=1.0, convergenceCheck=False,
             minObjMethod="nelder-mead", minObjOptions=None, args=None,
-            nCandidates=None, **kwargs):
-        """BAPE / AGP outer loop (approx.py:229-524): for ``nmax`` iterations find
-        ``m`` new design points (re-fitting the GP every ``optGPEveryN``), run the
-        surrogate MCMC, record burn-in / thinning and optionally stop when the
-        marginal posterior means move by less than ``eps`` previous standard
-        deviations for ``kmax`` consecutive iterations.  (The reference only
-        honours that stop rule when ``verbose`` is set -- quirk Q4; here it does
-        not depend on verbosity.)  ``nCandidates`` switches the point search to
-        the fused device sweep."""
-        if cache:
-            np.savez(str(runName) + "APFModelCache.npz", theta=self.theta, y=self.y)
-            self.gpPar = list()
-        if seed is not None:
-            np.random.seed(seed)
-        if timing:
-            self.trainingTime = list()
-            self.mcmcTime = list()
-        if convergenceCheck:
-            self.marginalMeans = list()
-            self.marginalStds = list()
-            self.marginalZScores = list()
-        if initGPOpt:
-            self.optGP(seed=seed, method=gpMethod, options=gpOptions, p0=gpP0,
-                       nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
-        kk = 0
+            nCandidates=None, onDevice=False, batched=True, **kwargs):
+        """BAPE / AGP outer loop (approx.py:229-524): ``nmax`` times, find ``m`` design
+        points (re-fitting the GP every ``optGPEveryN``), sample the surrogate posterior,
+        record burn-in / thinning, and -- with ``convergenceCheck`` -- stop once the
+        marginal means have moved by less than ``eps`` previous standard deviations for
+        ``kmax`` consecutive iterations.  (The reference honours that rule only when
+        ``verbose`` is set, quirk Q4; here it does not depend on verbosity.)
+        ``nCandidates`` switches the point search to the fused device sweep;
+        ``onDevice`` / ``batched`` are passed to :meth:`runMCMC`."""
         if convergenceCheck and onlyLastMCMC:
             raise RuntimeError("If convergenceCheck is True, must run an MCMC each iteration.\n"
                                "convergenceCheck = %d onlyLastMCMC = %d" % (convergenceCheck, onlyLastMCMC))
-        for nn in range(nmax):
+        if cache:
+            np.savez(_cacheName(runName, "APFModelCache"), theta=self.theta, y=self.y)
+            self.gpPar = []
+        if seed is not None:
+            np.random.seed(seed)
+        if timing:
+            self.trainingTime, self.mcmcTime = [], []
+        monitor = _MarginalMonitor(eps, kmax) if convergenceCheck else None
+        if monitor is not None:
+            self.marginalMeans, self.marginalStds = monitor.means, monitor.stds
+            self.marginalZScores = monitor.zscores
+        fit = dict(seed=seed, nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
+        if initGPOpt:
+            self.optGP(method=gpMethod, options=gpOptions, p0=gpP0, **fit)
+        for iteration in range(nmax):
             if verbose:
-                print("Iteration: %d" % nn)
-            start = time.time()
-            _, _ = self.findNextPoint(computeLnLike=True, seed=seed, cache=cache,
-                                      gpMethod=gpMethod, gpOptions=gpOptions,
-                                      nGPRestarts=nGPRestarts, nMinObjRestarts=nMinObjRestarts,
-                                      optGPEveryN=optGPEveryN, numNewPoints=m,
-                                      gpHyperPrior=gpHyperPrior, minObjMethod=minObjMethod,
-                                      minObjOptions=minObjOptions, runName=runName,
-                                      theta0=None, args=args, verbose=verbose,
-                                      nCandidates=nCandidates, **kwargs)
+                print("Iteration: %d" % iteration)
+            clock = time.time()
+            self.findNextPoint(computeLnLike=True, cache=cache, gpMethod=gpMethod,
+                               gpOptions=gpOptions, nMinObjRestarts=nMinObjRestarts,
+                               optGPEveryN=optGPEveryN, numNewPoints=m,
+                               minObjMethod=minObjMethod, minObjOptions=minObjOptions,
+                               runName=runName, theta0=None, args=args, verbose=verbose,
+                               nCandidates=nCandidates, **fit, **kwargs)
             if timing:
-                self.trainingTime.append(time.time() - start)
+                self.trainingTime.append(time.time() - clock)
             if cache:
-                np.savez(str(runName) + "APGP.npz",
-                         gpParamNames=self.gp.get_parameter_names(),
+                np.savez(_cacheName(runName, "APGP"), gpParamNames=self.gp.get_parameter_names(),
                          gpParamValues=self.gpPar)
-            if onlyLastMCMC and nn != (nmax - 1):
+            if onlyLastMCMC and iteration != nmax - 1:
                 self.sampler = None
                 continue
-            start = time.time()
-            self.sampler, iburn, ithin = self.runMCMC(samplerKwargs=samplerKwargs,
-                                                      mcmcKwargs=mcmcKwargs,
-                                                      runName=str(runName) + str(nn),
-                                                      cache=cache, estBurnin=estBurnin,
-                                                      thinChains=thinChains, verbose=verbose,
-                                                      args=args, **kwargs)
+            clock = time.time()
+            _, iburn, ithin = self.runMCMC(samplerKwargs=samplerKwargs, mcmcKwargs=mcmcKwargs,
+                                           runName="%s%d" % (runName, iteration), cache=cache,
+                                           estBurnin=estBurnin, thinChains=thinChains,
+                                           verbose=verbose, args=args, onDevice=onDevice,
+                                           batched=batched, **kwargs)
             self.iburns.append(iburn)
             self.ithins.append(ithin)
             if timing:
-                self.mcmcTime.append(time.time() - start)
+                self.mcmcTime.append(time.time() - clock)
                 if cache:
-                    np.savez(str(runName) + "APTiming.npz", trainingTime=self.trainingTime,
+                    np.savez(_cacheName(runName, "APTiming"), trainingTime=self.trainingTime,
                              mcmcTime=self.mcmcTime)
-            if convergenceCheck:
-                samples = self.sampler.get_chain(discard=self.iburns[-1], flat=True,
-                                                 thin=self.ithins[-1])
-                meanNN = np.mean(samples, axis=0)
-                stdNN = np.std(samples, axis=0)
-                self.marginalMeans.append(meanNN)
-                self.marginalStds.append(stdNN)
-                if nn > 0:
-                    zScore = np.fabs((meanNN - meanPrev) / stdPrev)
-                    self.marginalZScores.append(zScore)
-                    kk = kk + 1 if np.all(zScore < eps) else 0
-                meanPrev, stdPrev = meanNN, stdNN
-                if cache:
-                    np.savez(str(runName) + "ConvergenceCache.npz", means=self.marginalMeans,
-                             stds=self.marginalStds, zscores=self.marginalZScores,
-                             eps=eps, kmax=kmax, finalIteration=kk)
-                if kk >= kmax:
-                    if verbose:
-                        print("Approximate marginal posterior distributions converged.")
-                        print("Delta zScore threshold, eps: %e" % eps)
-                        print("kk, kmax: %d, %d" % (kk, kmax))
-                        print("Final abs(zScore):", zScore)
-                    break
+            if monitor is None:
+                continue
+            converged = monitor.update(self.sampler.get_chain(discard=iburn, flat=True, thin=ithin))
+            if cache:
+                monitor.save(_cacheName(runName, "ConvergenceCache"))
+            if converged:
+                if verbose:
+                    print("Approximate marginal posterior distributions converged: |z| = %s < eps = %e "
+                          "for %d iterations" % (monitor.zscores[-1], eps, kmax))
+                break
 
-    # ---------------------------------------------------------------- findMAP
+    # ----------------------------------------------------------------------------- MAP
     def findMAP(self, theta0=None, method="nelder-mead", options=None, nRestarts=15):
-        """Maximum a posteriori estimate of the function the GP has learned:
-        minimise minus the GP mean from ``nRestarts`` starts around the best
-        training point (approx.py:862-926).  Returns ``(MAP, MAPVal)``."""
-        if theta0 is not None:
-            theta0 = np.array(theta0).reshape(1, self.theta.shape[-1])
+        """Maximum of the function the GP has learned: minimise minus the GP mean from
+        ``nRestarts`` starts around ``theta0`` (default: the best training point)
+        (approx.py:862-926).  Returns ``(MAP, MAPVal)``."""
+        if theta0 is None:
+            start = self.theta[np.argmax(self.y)]
         else:
-            theta0 = self.theta[np.argmax(self.y)]
-        if str(method).lower() == "nelder-mead" and options is None:
+            start = np.array(theta0).reshape(1, self.theta.shape[-1])
+        if options is None and str(method).lower() == "nelder-mead":
             options = {"adaptive": True}
 
-        def fn(x):
-            if not np.isfinite(self._lnprior(x)):
-                return np.inf
-            return -(self._gpll(x)[0])
+        def minusMean(x):
+            return -(self._gpll(x)[0]) if np.isfinite(self._lnprior(x)) else np.inf
 
-        MAP, MAPVal = ut.minimizeObjective(fn, self.y, self.gp, self.priorSample,
+        best, value = ut.minimizeObjective(minusMean, self.y, self.gp, self.priorSample,
                                            self._lnprior, nRestarts=nRestarts, args=None,
-                                           method=method, options=options,
-                                           bounds=self.bounds, theta0=theta0)
-        return MAP, -MAPVal
+                                           method=method, options=options, bounds=self.bounds,
+                                           theta0=start)
+        return best, -value
 
-    # --------------------------------------------------------------- bayesOpt
+    # ---------------------------------------------------------- Bayesian optimisation
     def bayesOpt(self, nmax, theta0=None, tol=1.0e-3, kmax=3, seed=None,
                  verbose=True, runName="apRun", cache=True, gpMethod="powell",
                  gpOptions=None, gpP0=None, optGPEveryN=1, nGPRestarts=1,
                  nMinObjRestarts=5, initGPOpt=True, minObjMethod="nelder-mead",
                  gpHyperPrior=gpUtils.defaultHyperPrior, minObjOptions=None,
                  findMAP=True, args=None, nCandidates=None, **kwargs):
-        """Bayesian optimisation loop (approx.py:929-1151): one new design point
-        per iteration by the object's utility (use algorithm="jones"), optional
-        MAP of the GP mean each iteration, stop after ``kmax`` consecutive
-        iterations whose best value changes by less than ``tol``.  Returns the
-        reference's solution dictionary."""
-        thetas, vals = list(), list()
-        thetasMAP, valsMAP = list(), list()
+        """Bayesian optimisation (approx.py:929-1151): one design point per iteration by
+        the object's utility (use algorithm="jones"), optionally the MAP of the GP mean
+        after each, stop after ``kmax`` consecutive iterations whose best value changed
+        by less than ``tol``.  Returns the reference's solution dictionary (thetaBest,
+        valBest, thetas, vals, nev [, thetasMAP, valsMAP, thetaMAPBest, valMAPBest])."""
         if cache:
-            np.savez(str(runName) + "APFModelCache.npz", theta=self.theta, y=self.y)
+            np.savez(_cacheName(runName, "APFModelCache"), theta=self.theta, y=self.y)
         if seed is not None:
             np.random.seed(seed)
+        fit = dict(seed=seed, nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
         if initGPOpt:
-            self.optGP(seed=seed, method=gpMethod, options=gpOptions, p0=gpP0,
-                       nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
-        kk = 0
-        nn = -1
-        for nn in range(nmax):
+            self.optGP(method=gpMethod, options=gpOptions, p0=gpP0, **fit)
+        plateau = _PlateauMonitor(tol, kmax)
+        history = {"thetas": [], "vals": [], "thetasMAP": [], "valsMAP": []}
+        evaluations = 0
+        for iteration in range(nmax):
             if verbose:
-                print("Iteration: %d" % nn)
-            optN = 1 if nn % optGPEveryN == 0 else 99999999
-            thetaT, yT = self.findNextPoint(computeLnLike=True, seed=seed, cache=cache,
-                                            gpMethod=gpMethod, gpOptions=gpOptions,
-                                            nGPRestarts=nGPRestarts,
-                                            nMinObjRestarts=nMinObjRestarts,
-                                            optGPEveryN=optN, numNewPoints=1,
-                                            gpHyperPrior=gpHyperPrior,
-                                            minObjMethod=minObjMethod,
-                                            minObjOptions=minObjOptions, runName=runName,
-                                            args=args, verbose=verbose,
-                                            nCandidates=nCandidates, **kwargs)
+                print("Iteration: %d" % iteration)
+            # re-fit on every optGPEveryN-th iteration: a period no single call can reach otherwise
+            period = 1 if iteration % optGPEveryN == 0 else 99999999
+            point, value = self.findNextPoint(computeLnLike=True, cache=cache, gpMethod=gpMethod,
+                                              gpOptions=gpOptions, nMinObjRestarts=nMinObjRestarts,
+                                              optGPEveryN=period, numNewPoints=1,
+                                              minObjMethod=minObjMethod, minObjOptions=minObjOptions,
+                                              runName=runName, args=args, verbose=verbose,
+                                              nCandidates=nCandidates, **fit, **kwargs)
+            evaluations = iteration + 1
             if verbose:
-                print("Forward model evaluation at: ", thetaT, ", function value: ", yT)
+                print("Forward model evaluation at: ", point, ", function value: ", value)
             if cache:
-                np.savez(str(runName) + "APGP.npz",
-                         gpParamNames=self.gp.get_parameter_names(),
+                np.savez(_cacheName(runName, "APGP"), gpParamNames=self.gp.get_parameter_names(),
                          gpParamValues=self.gp.get_parameter_vector())
-            thetas.append(self.theta[np.argmax(self.y)])
-            vals.append(self.y[np.argmax(self.y)])
+            top = int(np.argmax(self.y))
+            history["thetas"].append(self.theta[top])
+            history["vals"].append(self.y[top])
             if findMAP:
-                thetaN, valN = self.findMAP(theta0=theta0, method=minObjMethod,
-                                            options=minObjOptions, nRestarts=nMinObjRestarts)
+                mapPoint, mapValue = self.findMAP(theta0=theta0, method=minObjMethod,
+                                                  options=minObjOptions, nRestarts=nMinObjRestarts)
                 if verbose:
-                    print("Current MAP solution: ", thetaN, valN)
-                thetasMAP.append(thetaN)
-                valsMAP.append(valN)
-            if nn > 0:
-                kk = kk + 1 if np.fabs(vals[-1] - vals[-2]) < tol else 0
-                if kk >= kmax:
-                    break
-        soln = {"thetaBest": thetas[-1], "valBest": vals[-1],
-                "thetas": np.asarray(thetas).squeeze(),
-                "vals": np.asarray(vals).squeeze(), "nev": nn + 1}
+                    print("Current MAP solution: ", mapPoint, mapValue)
+                history["thetasMAP"].append(mapPoint)
+                history["valsMAP"].append(mapValue)
+            if plateau.update(history["vals"][-1]):
+                break
+        soln = {"thetaBest": history["thetas"][-1], "valBest": history["vals"][-1],
+                "thetas": np.asarray(history["thetas"]).squeeze(),
+                "vals": np.asarray(history["vals"]).squeeze(), "nev": evaluations}
         if findMAP:
-            soln["thetasMAP"] = np.asarray(thetasMAP).squeeze()
-            soln["valsMAP"] = np.asarray(valsMAP).squeeze()
-            soln["thetaMAPBest"] = soln["thetasMAP"][np.argmax(soln["valsMAP"])]
-            soln["valMAPBest"] = soln["valsMAP"][np.argmax(soln["valsMAP"])]
+            soln["thetasMAP"] = np.asarray(history["thetasMAP"]).squeeze()
+            soln["valsMAP"] = np.asarray(history["valsMAP"]).squeeze()
+            top = int(np.argmax(soln["valsMAP"]))
+            soln["thetaMAPBest"] = soln["thetasMAP"][top]
+            soln["valMAPBest"] = soln["valsMAP"][top]
         return soln

@@ -5,32 +5,27 @@
 //   utility.AGPUtility / BAPEUtility / JonesUtility (utility.py:99-250)
 //   utility.minimizeObjective's arg-min             (utility.py:369-371)
 //
-// Two kernels implement it: sweep2_kernel (the two-role kernel further down: matrix wavefronts
-// + feeder wavefronts, the default) and sweep_kernel (the one-role kernel of rounds 1a-1d,
-// kept behind APGP_SWEEP2=0 as the A/B reference).  They share the packed formats, the
-// candidate -> lane mapping, the row-block split mode and the finishing kernels.
+// One kernel implements it: sweep2_kernel, the two-role kernel further down (matrix wavefronts
+// + feeder wavefronts); a short last round of the persistent grid is split by row block and
+// finished by sweep_finish_kernel.
 //
-// Data flow of the one-role kernel per workgroup (256 threads = 4 wavefronts, one per SIMD, 64 candidates):
-//   * wavefront w owns candidates [16 w, 16 w + 16) (one MFMA column block);
-//     the scaled candidate coordinates are parked in LDS (only generating
-//     tiles need them).
-//   * the packed factor W = L^-1 is streamed tile by tile (512 rows x 16 k,
-//     64 KiB, A-fragment order) L2/MALL -> registers -> LDS (ring of three
-//     half-tile slots, one 16-byte piece per thread per sub-block pair, one
-//     barrier per half tile), shared by the four wavefronts.
-//   * each lane generates the k*(t_m, x_k) value it must feed as the MFMA B
-//     operand (lane -> candidate lane&15, k lane>>4) on the VALU (D sub + D fma
-//     + table-driven exp) the FIRST time chunk k is visited (the diagonal row
-//     block); later row blocks need the same operands again, and because the
-//     fp64 VALU shares the DP pipe with the matrix cores, regenerating them
-//     costs ~12 % of a tile.  They are parked in a per-workgroup-slot scratch
-//     stream instead (32 B per lane per chunk, written once, read back one tile
-//     ahead, <0.5 TB/s chip-wide) -- K* is still never materialised as a matrix
-//     the host sees.  The grid is persistent (one workgroup per CU, candidate
-//     blocks dealt round-robin) so the scratch is SW_GRID slots, not M/64.
-//   * V = W K*^T is accumulated 512 rows x 16 candidates per wavefront in 128
-//     v_mfma_f64_4x4x4_4b_f64 accumulators (AGPRs); at the end of a row block
-//     the squares are folded into a per-candidate sum; V is never stored.
+// Data flow per workgroup (512 threads = 4 matrix + 4 feeder wavefronts, 64 candidates):
+//   * matrix / feeder wavefront w owns candidates [16 w, 16 w + 16) (one MFMA column block).
+//   * the packed factor W = L^-1 is streamed tile by tile (the 256-row halves of the packed
+//     512 rows x 16 k tiles, 32 KiB, A-fragment order) L2/MALL -> LDS by LDS-DMA (ring of
+//     three slots), shared by the four matrix wavefronts.
+//   * the feeder generates the k*(t_m, x_k) values the MFMA B operand needs (lane ->
+//     candidate lane&15, k lane>>4) on the VALU (D sub + D fma + table-driven exp) the
+//     FIRST time chunk k is visited (the diagonal row block); later row blocks need the same
+//     operands again, and because the fp64 VALU shares the DP pipe with the matrix cores,
+//     regenerating them costs ~12 % of a tile.  They are parked in a per-workgroup-slot
+//     scratch stream instead (32 B per lane per chunk, written once, read back by LDS-DMA)
+//     -- K* is still never materialised as a matrix the host sees.  The grid is persistent
+//     (one workgroup per CU, candidate blocks dealt round-robin) so the scratch is SW_GRID
+//     slots, not M/64.
+//   * V = W K*^T is accumulated 256 rows x 16 candidates per matrix wavefront in 64
+//     v_mfma_f64_4x4x4_4b_f64 accumulators; at the end of a row block the squares are folded
+//     into a per-candidate sum; V is never stored.
 //   * mu is a VALU by-product of the generating tiles (every k exactly once).
 #include "apgp_common.h"
 #include <stdlib.h>
@@ -41,9 +36,8 @@
 #define SW_KC APGP_K_CHUNK           // 16 k per tile
 #define SW_TILE (SW_ROWS * SW_KC)    // doubles per tile (64 KiB)
 #define SW_CAND 64                   // candidates per workgroup (16 per wavefront)
-#define SW_THREADS 256
 #define SW_GRID 256                  // persistent workgroups = K* scratch slots (one per CU)
-#define SW_BCH (SW_THREADS * 4)      // doubles of parked B operands per chunk per slot
+#define SW_BCH 1024                  // doubles of parked B operands per chunk per slot (4 wavefronts x 64 lanes x 4 k)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // cache policy of the parked-operand stream (aux bits of its buffer loads / stores): 0 = default.
 // Each workgroup slot is written once and read back once per later row block and 256 slots x
@@ -72,10 +66,10 @@ struct SweepArgs {
     double* sp_mu;
     int split;
     long long m, idx_offset;
-    int ndim, nrb, kind, has_box, n, ncache, ncache2, lin_order;
+    int ndim, nrb, kind, has_box, n, ncache, lin_order;
     double mean, amp, zeta, ybest, lin_coef;
     double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
-    unsigned long long* dbg;   // phase cycle counters (APGP_SWEEP_TIMING=1 builds only)
+    unsigned long long* dbg;   // phase cycle counters (-DS2_TIMING developer builds only)
 };
 
 __device__ __forceinline__ double util_value(int kind, double mu, double var, double zeta,
@@ -123,501 +117,6 @@ __device__ __forceinline__ void best_merge(double& bu, long long& bi, double u, 
 // V^2 per candidate) undoes once per row block with the inverse rotation.
 // (Rotating the A fragment instead keeps lane <-> candidate fixed but needs four
 // times the LDS reads and A registers: it ran the LDS at 73 % of its bandwidth.)
-// Because K* generation costs DP cycles too, each generated value must feed as
-// many rows as possible: a wavefront owns 512 rows x 16 candidates (128 f64
-// accumulators per lane = the whole AGPR file), so one generated B value feeds
-// 128 MFMAs; one wavefront per SIMD, everything latency-critical is prefetched.
-// LIN: the kernel carries a linear-regression term (defaultGP(order=...)).  A template
-// parameter, not a uniform branch: the extra code in the generating path costs the
-// LIN-free kernel 3 % through register allocation alone.
-template <int DPAD, bool TIMING = false, bool LIN = false>
-__global__ __launch_bounds__(SW_THREADS, 1) void sweep_kernel(SweepArgs a) {
-    // (compile-time indices only: a runtime-indexed array would live in scratch and drain vmcnt)
-    unsigned long long tp[3] = {0, 0, 0}, tg[3] = {0, 0, 0}, tq = 0, ntp = 0, ntg = 0;
-#define SW_TICK(i) do { if (TIMING) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); tg[i] += gen ? n_ - tq : 0ull; tp[i] += gen ? 0ull : n_ - tq; tq = n_; } } while (0)
-    constexpr int XS = DPAD + 2;
-    constexpr int RS = SW_ROWS / 16;           // 16-row sub-blocks per tile (32)
-    constexpr int NP = RS / 2;                 // sub-block pairs per tile (16)
-    constexpr int NKK = SW_KC / 4;             // k-steps per tile (4)
-    constexpr int HT = SW_TILE / 2;            // doubles per half tile (32 KiB)
-    static_assert(NKK == 4 && NP == 16, "tile layout");
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Aring = smem;                      // 3 half tiles
-    double* Xbuf = smem + 3 * HT;              // 2 x SW_KC x XS
-    double* Etab = Xbuf + 2 * SW_KC * XS;      // exp table
-    double* red_u = Etab + APGP_EXP_TAB_N;     // workgroup arg-min exchange (4 + 4 slots)
-    long long* red_i = (long long*)(red_u + 4);
-    double* Tc = red_u + 8;                    // scaled candidate coordinates [DPAD/2][256] x 16 B
-    // long-lived, rarely-touched per-lane values live in LDS, not in VGPRs: anything
-    // hipcc spills to scratch instead shares vmcnt with the factor stream and makes
-    // every wait on that stream a full drain
-    double* Qp = Tc + DPAD * SW_THREADS;       // ||V||^2 partial sums, one per B rotation
-    double* Mp = Qp + 4 * SW_THREADS;          // mu partial sums
-    int* Fl = (int*)(Mp + SW_THREADS);         // bit 0: admissible, bit 1: NaN coordinate
-    double* Cst = (double*)(Fl + SW_THREADS);  // sc | lo | hi | lw (4 x APGP_MAX_DIM)
-    double* Ktt = Cst + 4 * APGP_MAX_DIM;      // k(t,t) per lane (amp + linear term)
-
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int cl = lane & 15, kq = lane >> 4;
-    apgp_exp_tab_load(Etab);
-    if (t == 0) {
-#pragma unroll
-        for (int d = 0; d < APGP_MAX_DIM; ++d) {
-            Cst[d] = a.sc[d];
-            Cst[APGP_MAX_DIM + d] = a.lo[d];
-            Cst[2 * APGP_MAX_DIM + d] = a.hi[d];
-            Cst[3 * APGP_MAX_DIM + d] = a.lw[d];
-        }
-    }
-
-    constexpr int CPB = SW_ROWS / SW_KC;       // k-chunks per row-block width (32)
-    const int kc_lim = (a.n + SW_KC - 1) / SW_KC;     // chunks that hold real columns
-
-    // ---- the packed factor streams L2/MALL -> registers -> LDS ---------------------
-    // A half tile (256 rows x 16 k, 32 KiB) is eight 16-byte "pieces" per thread;
-    // piece q holds exactly the sub-block pair q of that half.  The stream is
-    // software-pipelined at the granularity of one piece per sub-block pair:
-    // at pair g a thread parks (ds_write_b128) the piece it requested 16 pairs
-    // -- one whole tile, whatever that tile's length -- earlier and re-uses the
-    // register for the piece that will be consumed 25 pairs later.  The half
-    // tiles live in a ring of three LDS slots; a piece is written >= 8 pairs
-    // before it is read and >= 15 pairs after the previous occupant's last
-    // read, so ONE barrier every 8 pairs (placed in the middle of the MFMA
-    // stream, where no LDS read waits on it) covers both hazards and there is
-    // no pipeline restart at tile boundaries.
-    // (global_load_lds was measured at ~55 issue cycles per KiB on the issuing
-    // wavefront; with one wavefront per SIMD nothing hides that.)
-    constexpr int HALF16 = HT / 2;                   // 16-byte pieces per half tile (2048)
-    constexpr int NST = HALF16 / SW_THREADS;         // pieces per thread per half (8)
-    constexpr int XCHUNK16 = SW_KC * XS / 2;         // 16-byte pieces of the x chunk
-    static_assert(NST == 8 && XCHUNK16 <= SW_THREADS, "staging layout");
-    f64x2 R[2 * NST];
-    f64x2 xpend;
-    f64x2 bpend[2];
-    // All streams go through buffer descriptors (scalar base + scalar offset + one
-    // 32-bit lane offset): no 64-bit per-lane addresses, VGPRs are the scarce resource.
-    const unsigned toff = (unsigned)t * 16u;         // lane part of every 16-byte piece address
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.linv, 0, (int)a.linv_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.xs, 0, (int)a.xs_bytes, 0x00020000);
-    // parked B operands of this workgroup slot: chunk c -> [2][SW_THREADS] x 16 B
-    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.kcache + (long long)blockIdx.x * a.ncache * SW_BCH), 0, (int)a.kslot_bytes, 0x00020000);
-    auto gpiece = [&](long long tile, int half, int q) {
-        const unsigned soff = (unsigned)tile * (unsigned)(SW_TILE * 8) + (unsigned)(half * HT * 8 + q * SW_THREADS * 16);
-        return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_w, toff, soff, 0));
-    };
-    auto lpiece = [&](int slot, int q) {
-        return (f64x2*)(Aring + slot * HT) + q * SW_THREADS + t;
-    };
-    // NOTE: every load below is UNCONDITIONAL (indices are clamped instead): a load
-    // under an `if` makes hipcc merge "loaded or old" values and drain vmcnt(0) at
-    // the join, exposing the full memory latency (cdna guide, .s-level trap (c)).
-    const unsigned xoff = t < XCHUNK16 ? toff : 0u;
-    auto x_load = [&](int kc) {
-        xpend = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(
-            rs_x, xoff, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0));
-    };
-    auto x_store = [&](int xb) {
-        if (t < XCHUNK16) *((f64x2*)(Xbuf + xb * SW_KC * XS) + t) = xpend;
-    };
-    const int cmax = a.ncache > 0 ? a.ncache - 1 : 0;
-    const bool park = a.ncache > 0;
-    auto b_load = [&](int c) {
-        const unsigned soff = (unsigned)(c < cmax ? c : cmax) * (unsigned)(SW_BCH * 8);
-        bpend[0] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, toff, soff, SW_KAUX));
-        bpend[1] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_k, toff, soff + SW_THREADS * 16, SW_KAUX));
-    };
-
-    // tile sequence: row block ib, chunks kc = 0 .. min((ib+1)*CPB, kc_lim) - 1, then
-    // the next row block, then tile (0,0) again for the next candidate block;
-    // packed tile index = CPB*ib*(ib+1)/2 + kc
-    auto tile_index = [&](int ib, int kc) { return (long long)CPB * ib * (ib + 1) / 2 + kc; };
-    auto nkc_of = [&](int ib) { const int v = CPB * (ib + 1); return v < kc_lim ? v : kc_lim; };
-    auto successor = [&](int& ib, int& kc) {
-        ++kc;
-        if (kc >= nkc_of(ib)) { ib = a.split ? ib : ib + 1; kc = 0; }
-        if (ib >= a.nrb) { ib = 0; kc = 0; }
-    };
-    // split launch: workgroups are dealt heaviest row block first (row block ib costs ib + 1
-    // units): blockIdx = (nrb - 1 - ib) * nblocks + block
-    const unsigned sp_nb = (unsigned)(a.blk_end - a.blk_begin);
-    const int ib_first = a.split ? a.nrb - 1 - (int)(blockIdx.x / sp_nb) : 0;
-    // A fragments of one sub-block pair: per 16-row sub-block two ds_read_b128 fetch
-    // the four k-steps of the lane's row (half-tile layout [s][kp][lane][q]).
-    f64x2 av[2][2][2];
-    auto load_a = [&](f64x2 (&dst)[2][2], int slot, int q) {
-        const f64x2* A2 = (const f64x2*)(Aring + slot * HT) + lane;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) dst[h][kp] = A2[((q * 2 + h) * 2 + kp) * 64];
-    };
-    // rotate a per-lane double by 4*r lanes inside each row of 16 lanes (DPP row_ror)
-    auto rot16 = [&](double v, int r) {
-        if (r == 0) return v;
-        const int lo = __double2loint(v), hi = __double2hiint(v);
-        int rl, rh;
-        if (r == 1) { rl = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xf, false); }
-        else if (r == 2) { rl = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false); }
-        else { rl = __builtin_amdgcn_update_dpp(0, lo, 0x12c, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x12c, 0xf, 0xf, false); }
-        return __hiloint2double(rh, rl);
-    };
-
-    // ---- pipeline prologue: tile (0,0) ------------------------------------------
-    {
-        int ib1 = ib_first, kc1 = 0;
-        successor(ib1, kc1);
-        const long long t0 = tile_index(ib_first, 0), t1 = tile_index(ib1, kc1);
-#pragma unroll
-        for (int q = 0; q < NST; ++q) R[q] = gpiece(t0, 0, q);
-#pragma unroll
-        for (int q = 0; q < NST; ++q) *lpiece(0, q) = R[q];
-        *lpiece(1, 0) = gpiece(t0, 1, 0);
-        // what the (virtual) tile before would have requested, see stage()
-#pragma unroll
-        for (int pr = 0; pr < 7; ++pr) R[pr] = gpiece(t0, 1, pr + 1);
-#pragma unroll
-        for (int pr = 7; pr < 15; ++pr) R[pr] = gpiece(t1, 0, pr - 7);
-        R[15] = gpiece(t1, 1, 0);
-        x_load(0); x_store(0);
-        bpend[0] = R[0]; bpend[1] = R[0];
-        __syncthreads();
-        load_a(av[0], 0, 0);
-    }
-    int h0 = 0;          // ring slot of the current tile's first half
-    int xb = 0;          // x-chunk buffer of the current tile
-
-    const long long blk_first = a.blk_begin + (a.split ? (long long)(blockIdx.x % sp_nb) : (long long)blockIdx.x);
-    const long long blk_step = a.split ? (a.blk_end - a.blk_begin + 1) : (long long)gridDim.x;
-    const int ib_lo = ib_first, ib_hi = a.split ? ib_first + 1 : a.nrb;
-    for (long long blk = blk_first; blk < a.blk_end; blk += blk_step) {
-    // ---- candidate of this lane (scaled coordinates parked in LDS: only the
-    //      generating tiles need them, and VGPRs are the scarce resource) --------
-    {
-        const long long crow = blk * SW_CAND + w * 16 + cl;
-        const bool inb = crow < a.m;
-        bool adm = inb, has_nan = false;
-        double ktl = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;     // sum_d (t_d^2)^P
-#pragma unroll
-        for (int d = 0; d < DPAD; ++d) {
-            double v = 0.0;
-            if (inb && d < a.ndim) {
-                v = a.T[crow * a.ndim + d];
-                if (a.has_box && !(v >= Cst[APGP_MAX_DIM + d] && v <= Cst[2 * APGP_MAX_DIM + d])) adm = false;
-                if (v != v) has_nan = true;
-            }
-            Tc[((d >> 1) * SW_THREADS + t) * 2 + (d & 1)] = v * Cst[d];
-            if (LIN && a.lin_order > 0) {
-                const double p = v * v;
-                double q = p;
-                for (int e = 1; e < a.lin_order; ++e) q *= p;
-                ktl += q;
-            }
-        }
-        if (LIN) Ktt[t] = fma(a.lin_coef, ktl, a.amp);     // k(t,t): no white noise (george predict)
-        if (inb && a.mask && a.mask[crow] == 0) adm = false;
-        Fl[t] = (adm ? 1 : 0) | (has_nan ? 2 : 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Qp[r * SW_THREADS + t] = 0.0;
-        Mp[t] = 0.0;
-    }
-
-    for (int ib = ib_lo; ib < ib_hi; ++ib) {
-        const int nkc = nkc_of(ib);
-        const int nparked = CPB * ib;          // chunks generated by an earlier row block
-        // drain the vector-memory counter once per row block (s_waitcnt vmcnt(0)): whatever
-        // spill traffic hipcc placed between candidate blocks must not be pending at the
-        // tile loop's entry, or every wait inside the loop degrades to a full drain
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        double acc[RS][4];
-#pragma unroll
-        for (int s = 0; s < RS; ++s)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
-        int kc = 0;
-        // One tile body for every case (a second unrolled body makes hipcc shuffle the
-        // 128 accumulators through scratch at the loop joins); what varies is uniform:
-        //  * pairs [p0, p1) hold non-zero rows (diagonal block: W is lower triangular;
-        //    last row block: rows >= N are padding) -- the others skip reads and MFMAs;
-        //  * gen: the B operands are generated (first visit of chunk kc, or parking
-        //    disabled), otherwise they were prefetched from the slot's scratch stream.
-        auto do_tile = [&](auto pred_tag) {
-            constexpr bool PRED = decltype(pred_tag)::value;
-            // (SW_X_NOGEN / NOSTAGE / NOBAR / NOLDS: developer builds for the elimination runs
-            // quoted in DESIGN.md -- results are wrong, the timing tells what a phase costs)
-#ifdef SW_X_NOGEN
-            const bool gen = false;
-#else
-            const bool gen = !park || kc >= nparked;
-#endif
-            if (TIMING) { tq = __builtin_amdgcn_s_memtime(); ntg += gen ? 1 : 0; ntp += gen ? 0 : 1; }
-            int nib = ib, nk = kc;
-            successor(nib, nk);
-            const long long ntile = tile_index(nib, nk);
-            int pib = nib, pk = nk;
-            successor(pib, pk);
-            const long long nntile = tile_index(pib, pk);
-            const int h1 = h0 == 2 ? 0 : h0 + 1;
-            const int h2 = h1 == 2 ? 0 : h1 + 1;
-            x_load(nk);
-            const double* Xb = Xbuf + xb * SW_KC * XS;
-            SW_TICK(0);
-            double bfv[NKK];
-            if (gen) {
-                // ---- generate the B operands of the tile's four k-steps:
-                //      k*(candidate cl, x_k), k = kc*16 + 4 kk + kq
-                // written across the four k-steps so the four dependent fp64 chains
-                // interleave; two partial sums per chain halve its length
-                // (all LDS operands of a group of four dimensions are requested before any
-                // is used: left to itself hipcc serialises a dozen read->wait->use trips)
-                double s2[NKK], s3[NKK], al[NKK], lsum[NKK];
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) {
-                    s2[kk] = 0.0; s3[kk] = 0.0;
-                    lsum[kk] = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;
-                    al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
-                }
-                constexpr int DG = DPAD < 4 ? DPAD : 4;       // dimensions per group
-#pragma unroll
-                for (int d0 = 0; d0 < DPAD; d0 += DG) {
-                    f64x2 xa[NKK][DG / 2], tc[DG / 2];
-#pragma unroll
-                    for (int h = 0; h < DG / 2; ++h) {
-                        tc[h] = *((const f64x2*)Tc + ((d0 >> 1) + h) * SW_THREADS + t);
-#pragma unroll
-                        for (int kk = 0; kk < NKK; ++kk)
-                            xa[kk][h] = *(const f64x2*)(Xb + (kk * 4 + kq) * XS + d0 + 2 * h);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int h = 0; h < DG / 2; ++h)
-#pragma unroll
-                        for (int kk = 0; kk < NKK; ++kk) {
-                            const double df0 = tc[h].x - xa[kk][h].x;
-                            const double df1 = tc[h].y - xa[kk][h].y;
-                            s2[kk] = fma(df0, df0, s2[kk]);
-                            s3[kk] = fma(df1, df1, s3[kk]);
-                        }
-                    if (LIN && a.lin_order > 0) {
-                        // linear-regression term: sum_d (t_d x_d)^P in the scaled coordinates
-#pragma unroll
-                        for (int h = 0; h < DG / 2; ++h)
-#pragma unroll
-                            for (int kk = 0; kk < NKK; ++kk) {
-                                const double p0 = tc[h].x * xa[kk][h].x * Cst[3 * APGP_MAX_DIM + d0 + 2 * h];
-                                const double p1 = tc[h].y * xa[kk][h].y * Cst[3 * APGP_MAX_DIM + d0 + 2 * h + 1];
-                                double q0 = p0, q1 = p1;
-                                for (int e = 1; e < a.lin_order; ++e) { q0 *= p0; q1 *= p1; }
-                                lsum[kk] += q0 + q1;
-                            }
-                    }
-                }
-                double ex[NKK];
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) ex[kk] = -(s2[kk] + s3[kk]);
-                apgp_exp4(ex, bfv, Etab);
-                // the amplitude multiplies the exponential (folding log(amp) into the
-                // exponent would perturb every entry by ~|log amp| ulps, which matters
-                // once cond(K) approaches 1/eps)
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) bfv[kk] = LIN ? fma(a.lin_coef, lsum[kk], bfv[kk] * a.amp) : bfv[kk] * a.amp;
-                if (kc >= nparked) {
-                    // first visit of this chunk: mu = k* . alpha picks it up exactly once
-                    double mupart = Mp[t];
-#pragma unroll
-                    for (int kk = 0; kk < NKK; ++kk) mupart = fma(bfv[kk], al[kk], mupart);
-                    Mp[t] = mupart;
-                    if (park && ib + 1 < a.nrb) {      // later row blocks revisit this chunk
-                        const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
-                        f64x2 q0, q1;
-                        q0.x = bfv[0]; q0.y = bfv[1]; q1.x = bfv[2]; q1.y = bfv[3];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_k, toff, soff, SW_KAUX);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_k, toff,
-                                                               soff + SW_THREADS * 16, SW_KAUX);
-                    }
-                }
-            } else {
-                bfv[0] = bpend[0].x; bfv[1] = bpend[0].y;
-                bfv[2] = bpend[1].x; bfv[3] = bpend[1].y;
-            }
-            // the four block-rotations of the B operand (see the instruction note above);
-            // (moving these DPP moves under the previous tile's MFMAs was measured: zero-sum)
-            double brot[4][NKK];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) brot[r][kk] = rot16(bfv[kk], r);
-            __builtin_amdgcn_sched_barrier(0);
-            if (TIMING) { asm volatile("" :: "v"(brot[0][0]), "v"(brot[0][1]), "v"(brot[0][2]), "v"(brot[0][3])); SW_TICK(1); }
-            // pair pr of this tile: park the piece requested one tile ago, request the
-            // one consumed 25 pairs from now (same register), see the ring comment
-            auto stage = [&](int pr) {
-#ifdef SW_X_NOSTAGE
-                return;
-#endif
-                // park: pairs 9..15 of this tile, then 0..8 of the next one;
-                // request: the same pairs one tile further on
-                if (pr < 7) {
-                    *lpiece(h1, pr + 1) = R[pr];
-                    R[pr] = gpiece(ntile, 1, pr + 1);
-                } else if (pr < 15) {
-                    *lpiece(h2, pr - 7) = R[pr];
-                    R[pr] = gpiece(nntile, 0, pr - 7);
-                } else {
-                    *lpiece(h0, 0) = R[15];
-                    R[15] = gpiece(nntile, 1, 0);
-                }
-                if (pr == 5) b_load(nk);
-
-                if (pr == 9) x_store(xb ^ 1);
-            };
-            // the one barrier per half tile sits after the first k-step of pairs 4 and 12:
-            // no LDS operation of this wavefront is in flight there (the barrier's
-            // lgkmcnt(0) is free) and the matrix pipe still has that k-step queued
-            auto ring_barrier = [&](int pr) {
-#ifdef SW_X_NOBAR
-                return;
-#endif
-                if (pr == 4 || pr == 12) __syncthreads();
-            };
-            auto mfma_pair = [&](int pr, int kk) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[2 * pr][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
-                        av[pr & 1][0][kk >> 1][kk & 1], brot[r][kk], acc[2 * pr][r], 0, 0, 0);
-                    acc[2 * pr + 1][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
-                        av[pr & 1][1][kk >> 1][kk & 1], brot[r][kk], acc[2 * pr + 1][r], 0, 0, 0);
-                }
-            };
-            // LDS slot / pair index inside the half of pair pr (pr == NP: next tile's first)
-            auto prefetch_a = [&](int pr) {
-#ifdef SW_X_NOLDS
-                return;
-#endif
-                if (pr < 8) load_a(av[pr & 1], h0, pr);
-                else if (pr < NP) load_a(av[pr & 1], h1, pr - 8);
-                else load_a(av[0], h2, 0);
-            };
-            // sub-blocks in pairs: 8 independent accumulators per (kk, r) sweep keep the
-            // dependent-accumulate distance at 8 MFMAs; the four ds_read_b128 of the next
-            // pair are requested after the first k-step (one pair ahead, across tile
-            // boundaries too).
-            // W is lower triangular: in the diagonal block, chunk kc only reaches rows
-            // >= 16 (kc - nparked), i.e. sub-block pairs >= p0.  The structurally-zero
-            // pairs skip their 32 MFMAs (uniform branch) but nothing else: every LDS read,
-            // staging step and barrier stays unconditional, so no memory operation sits
-            // under a branch and hipcc's wait counters stay exact.
-            int p0 = (kc - nparked) >> 1;
-            if (p0 < 0) p0 = 0;
-            // ... and in the last row block rows >= N are padding: pairs >= p1 are zero too
-            int p1 = (a.n - SW_ROWS * ib + 31) >> 5;
-            if (p1 > NP) p1 = NP;
-#pragma unroll
-            for (int pr = 0; pr < NP; ++pr) {
-                const bool act = !PRED || (pr >= p0 && pr < p1);
-                if (act) mfma_pair(pr, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                ring_barrier(pr);
-                prefetch_a(pr + 1);
-                if (act) {
-                    mfma_pair(pr, 1);
-                    mfma_pair(pr, 2);
-                    mfma_pair(pr, 3);
-                }
-                stage(pr);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            SW_TICK(2);
-            h0 = h2;
-            xb ^= 1;
-        };
-        // two copies of the body: the one for the diagonal block (and for a last row block
-        // with padded rows) skips its structurally-zero pairs
-        // (two uniform branches per pair, ~18 cycles each in an MFMA stream), the other
-        // one is branch-free
-        const int nstraight = (a.n - SW_ROWS * ib >= SW_ROWS) ? nparked : 0;
-        for (; kc < nstraight; ++kc) do_tile(std::false_type{});
-        for (; kc < nkc; ++kc) do_tile(std::true_type{});
-        // row block finished: this row block's SHARE of sum V^2 and of mu, reduced over the
-        // lanes of a candidate, then added to the running totals in row-block order.  (The
-        // split last round stores the shares instead and sweep_finish_kernel adds them in the
-        // same order: a candidate's result does not depend on how it was scheduled.)
-        // The accumulators of rotation r belong to the candidate of the lane 4r further along
-        // the 16-lane row: rotate back (inverse rotation: 16 - 4r).
-        double qr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            qr[r] = 0.0;
-#pragma unroll
-            for (int s = 0; s < RS; ++s) qr[r] = fma(acc[s][r], acc[s][r], qr[r]);
-        }
-        double qs = qr[0] + rot16(qr[1], 3) + rot16(qr[2], 2) + rot16(qr[3], 1);
-        qs += __shfl_xor(qs, 16);
-        qs += __shfl_xor(qs, 32);
-        double ms = Mp[t];
-        ms += __shfl_xor(ms, 16);
-        ms += __shfl_xor(ms, 32);
-        Mp[t] = 0.0;
-        if (a.split) {
-            if (kq == 0) {
-                const long long e = ((blk - a.blk_begin) * SW_CAND + w * 16 + cl) * a.nrb + ib;
-                a.sp_q[e] = qs;
-                a.sp_mu[e] = ms;
-            }
-        } else {
-            Qp[t] += qs;
-            Qp[SW_THREADS + t] += ms;
-        }
-    }
-    if (a.split) continue;
-    double qpart = Qp[t];
-    double mupart = Qp[SW_THREADS + t];
-    // recomputed behind an opaque barrier: CSE with the copy above would keep a 64-bit
-    // VGPR alive (= spilled) across the whole tile stream
-    int lane2 = t;
-    asm volatile("" : "+v"(lane2));
-    const long long crow = blk * SW_CAND + (lane2 >> 6) * 16 + (lane2 & 15);
-    const bool adm = (Fl[t] & 1) != 0, has_nan = (Fl[t] & 2) != 0;
-
-    double bu = INFINITY;
-    long long bi = -1;
-    if (kq == 0 && crow < a.m) {
-        double mu = mupart + a.mean;
-        double var = (LIN ? Ktt[t] : a.amp) - qpart;
-        if (has_nan) { mu = NAN; var = NAN; }     // george propagates NaN coordinates
-        if (a.mu) a.mu[crow] = mu;
-        if (a.var) a.var[crow] = var;
-        if (a.kind != APGP_UTIL_NONE) {
-            double uu = adm ? util_value(a.kind, mu, var, a.zeta, a.ybest) : INFINITY;
-            if (a.u) a.u[crow] = uu;
-            best_merge(bu, bi, uu, a.idx_offset + crow);
-        }
-    }
-    if (a.kind == APGP_UTIL_NONE) continue;
-    // wavefront arg-min, then workgroup arg-min through LDS (the slots are not
-    // rewritten before the next candidate block's tile barriers have passed)
-    for (int o = 8; o > 0; o >>= 1) {
-        double ou = __shfl_xor(bu, o);
-        long long oi = __shfl_xor(bi, o);
-        best_merge(bu, bi, ou, oi);
-    }
-    if (lane == 0) { red_u[w] = bu; red_i[w] = bi; }
-    __syncthreads();
-    if (t == 0) {
-        for (int i = 1; i < SW_THREADS / 64; ++i) best_merge(bu, bi, red_u[i], red_i[i]);
-        a.part_u[blk] = bu;
-        a.part_i[blk] = bi;
-    }
-    }   // candidate blocks
-
-    if (TIMING && a.dbg && blockIdx.x == 0 && t == 0) {
-        for (int i = 0; i < 3; ++i) { a.dbg[i] = tp[i]; a.dbg[3 + i] = tg[i]; }
-        a.dbg[6] = ntp;
-        a.dbg[7] = ntg;
-    }
-}
 
 // K6: final arg-min over the per-workgroup partials (one workgroup).
 __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u, const long long* part_i,
@@ -1150,141 +649,102 @@ __global__ __launch_bounds__(64) void sweep_finish_kernel(SweepArgs a) {
 }
 
 // blocks of the last round that are split by row block (measured break-even at N = 4096:
-// ~230 of 256 -- the split launch regenerates every k* and its largest item is 22 % of a block)
-#define SW_SPLIT_MAX 216
-// the same for the two-role kernel's 256-row items
+// ~190 of 256 -- the split launch regenerates every k* and its largest item is 1/nrb of a block)
 #define S2_SPLIT_MAX 184
+
+static inline int s2_nrb(int64_t n) { return (int)((n + S2_ROWS - 1) / S2_ROWS); }
+// chunks per workgroup slot whose B operands are revisited by a later 256-row block
+static inline long long s2_ncache(int64_t n) { return (long long)S2_CPB * (s2_nrb(n) - 1); }
+
+// dynamic LDS of sweep2_kernel<DPAD, *>
+template <int DPAD>
+static constexpr size_t s2_lds_bytes() {
+    return (3 * S2_TILE + 2 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + SW_CAND + 8 +
+            4 * APGP_MAX_DIM) * sizeof(double);
+}
+
+// The kernel needs > 64 KiB of dynamic LDS: the attribute is per device (and per kernel
+// instantiation), so it is set -- and its result checked -- once for each device this process
+// launches on.
+template <int DPAD>
+static int s2_prepare_device() {
+    static bool done[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        apgp_set_error("apgp_acquire: hipGetDevice failed");
+        return -2;
+    }
+    if (done[dev]) return 0;
+    const int lds = (int)s2_lds_bytes<DPAD>();
+    hipError_t e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+        apgp_set_error("apgp_acquire: hipFuncSetAttribute(%d B of LDS) failed on device %d: %s", lds, dev,
+                       hipGetErrorString(e));
+        return -2;
+    }
+    done[dev] = true;
+    return 0;
+}
 
 template <int DPAD>
 static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
-    const size_t lds = (3 * (SW_TILE / 2) + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + 8 + DPAD * SW_THREADS +
-                        6 * SW_THREADS + SW_THREADS / 2 + 4 * APGP_MAX_DIM) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)sweep_kernel<DPAD, false, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    const int rc = s2_prepare_device<DPAD>();
+    if (rc != 0) return rc;
     SweepArgs a = a0;
+    const size_t lds = s2_lds_bytes<DPAD>();
     const long long ncb = (a.m + SW_CAND - 1) / SW_CAND;
-    static int timing = -1;
-    if (timing < 0) { const char* e = getenv("APGP_SWEEP_TIMING"); timing = (e && e[0] == '1') ? 1 : 0; }
-    if (timing && DPAD == 8) {
-        // developer instrumentation: per-phase s_memtime cycles of block 0 / wave 0
-        static unsigned long long* dbg = nullptr;
-        if (!dbg) (void)hipMalloc(&dbg, 16 * sizeof(unsigned long long));
-        a.dbg = dbg;
-        a.blk_begin = 0; a.blk_end = ncb; a.split = 0;
-        (void)hipFuncSetAttribute((const void*)sweep_kernel<8, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((sweep_kernel<8, true>), dim3((unsigned)(ncb < SW_GRID ? ncb : SW_GRID)),
-                           dim3(SW_THREADS), lds, s, a);
-        unsigned long long h[8];
-        (void)hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, s);
-        (void)hipStreamSynchronize(s);
-        for (int g = 0; g < 2; ++g) {
-            const double nt = (double)(h[6 + g] ? h[6 + g] : 1);
-            fprintf(stderr, "[apgp sweep timing] %s tiles %llu | per tile cycles: head %.0f gen/fetch %.0f mfma+stage %.0f\n",
-                    g ? "generating" : "parked", h[6 + g], h[3 * g] / nt, h[3 * g + 1] / nt, h[3 * g + 2] / nt);
-        }
-        return 0;
-    }
+    const int nrb2 = s2_nrb(a.n);
+    a.nrb = nrb2;
+#ifdef S2_TIMING
+    static unsigned long long* dbg2 = nullptr;
+    if (!dbg2) (void)hipMalloc(&dbg2, 16 * sizeof(unsigned long long));
+    a.dbg = dbg2;
+#endif
     auto launch = [&](unsigned grid) {
         if (a.lin_coef != 0.0)
-            hipLaunchKernelGGL((sweep_kernel<DPAD, false, true>), dim3(grid), dim3(SW_THREADS), lds, s, a);
+            hipLaunchKernelGGL((sweep2_kernel<DPAD, true>), dim3(grid), dim3(S2_THREADS), lds, s, a);
         else
-            hipLaunchKernelGGL((sweep_kernel<DPAD, false>), dim3(grid), dim3(SW_THREADS), lds, s, a);
+            hipLaunchKernelGGL((sweep2_kernel<DPAD, false>), dim3(grid), dim3(S2_THREADS), lds, s, a);
     };
     // full rounds on the persistent grid, then the remainder split by row block
-    static int split_on = -1;
-    if (split_on < 0) { const char* e = getenv("APGP_SWEEP_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
-    static int two_role = -1;
-    if (two_role < 0) { const char* e = getenv("APGP_SWEEP2"); two_role = (e && e[0] == '0') ? 0 : 1; }
-    if (two_role) {
-        // ---- two-role kernel (default) ----
-        const int nrb2 = (int)((a.n + S2_ROWS - 1) / S2_ROWS);
-        const size_t lds2 = (3 * S2_TILE + 2 * 4 * 256 + 2 * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + SW_CAND + 8 +
-                             4 * APGP_MAX_DIM) * sizeof(double);
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            (void)hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            attr2 = true;
-        }
-        a.nrb = nrb2;
-        a.ncache = a.ncache2;
-        a.kslot_bytes = (unsigned)((a.ncache > 0 ? a.ncache : 1) * SW_BCH * 8);
-#ifdef S2_TIMING
-        static unsigned long long* dbg2 = nullptr;
-        if (!dbg2) (void)hipMalloc(&dbg2, 16 * sizeof(unsigned long long));
-        a.dbg = dbg2;
-#endif
-        auto launch2 = [&](unsigned grid) {
-            if (a.lin_coef != 0.0)
-                hipLaunchKernelGGL((sweep2_kernel<DPAD, true>), dim3(grid), dim3(S2_THREADS), lds2, s, a);
-            else
-                hipLaunchKernelGGL((sweep2_kernel<DPAD, false>), dim3(grid), dim3(S2_THREADS), lds2, s, a);
-        };
-        static int split_max = -1;
-        if (split_max < 0) { const char* e = getenv("APGP_SWEEP_SPLIT_MAX"); split_max = e ? atoi(e) : S2_SPLIT_MAX; if (split_max > SW_SPLIT_MAX) split_max = SW_SPLIT_MAX; }
-        long long rest = ncb % SW_GRID;
-        if (!split_on || nrb2 < 2 || rest > split_max || a.sp_q == NULL) rest = 0;
-        const long long full = ncb - rest;
-        if (full > 0) {
-            a.blk_begin = 0; a.blk_end = full; a.split = 0;
-            launch2((unsigned)(full < SW_GRID ? full : SW_GRID));
-#ifdef S2_TIMING
-            {
-                unsigned long long h[16];
-                (void)hipMemcpyAsync(h, dbg2, sizeof(h), hipMemcpyDeviceToHost, s);
-                (void)hipStreamSynchronize(s);
-                fprintf(stderr, "[sweep2 timing] matrix wave: %llu tiles, barrier wait %.0f cyc/tile, total %.0f cyc/tile | feeder work: gen tiles %.0f cyc (%llu), parked tiles %.0f cyc (%llu)\n",
-                        h[1], (double)h[0] / (h[1] ? h[1] : 1), (double)h[2] / (h[1] ? h[1] : 1), (double)h[3] / (h[4] ? h[4] : 1), h[4],
-                        (double)h[5] / (h[6] ? h[6] : 1), h[6]);
-            }
-#endif
-        }
-        if (rest > 0) {
-            a.blk_begin = full; a.blk_end = ncb; a.split = 1;
-            a.ncache = 0;                             // no parking across workgroups
-            a.kslot_bytes = SW_BCH * 8;
-            launch2((unsigned)(rest * nrb2));
-            hipLaunchKernelGGL(sweep_finish_kernel, dim3((unsigned)rest), dim3(64), 0, s, a);
-        }
-        return 0;
-    }
-    // ---- one-role kernel (APGP_SWEEP2=0: the A/B reference of DESIGN.md K5) ----
     long long rest = ncb % SW_GRID;
-    if (!split_on || a.nrb < 2 || rest > SW_SPLIT_MAX || a.sp_q == NULL) rest = 0;
+    if (nrb2 < 2 || rest > S2_SPLIT_MAX || a.sp_q == NULL) rest = 0;
     const long long full = ncb - rest;
     if (full > 0) {
         a.blk_begin = 0; a.blk_end = full; a.split = 0;
         launch((unsigned)(full < SW_GRID ? full : SW_GRID));
+#ifdef S2_TIMING
+        {
+            unsigned long long h[16];
+            (void)hipMemcpyAsync(h, dbg2, sizeof(h), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "[sweep2 timing] matrix wave: %llu tiles, barrier wait %.0f cyc/tile, total %.0f cyc/tile | feeder work: gen tiles %.0f cyc (%llu), parked tiles %.0f cyc (%llu)\n",
+                    h[1], (double)h[0] / (h[1] ? h[1] : 1), (double)h[2] / (h[1] ? h[1] : 1), (double)h[3] / (h[4] ? h[4] : 1), h[4],
+                    (double)h[5] / (h[6] ? h[6] : 1), h[6]);
+        }
+#endif
     }
     if (rest > 0) {
         a.blk_begin = full; a.blk_end = ncb; a.split = 1;
-        a.ncache = 0;                                 // no parking across workgroups
-        a.kcache = (double*)a.linv; a.kslot_bytes = SW_BCH * 8;
-        launch((unsigned)(rest * a.nrb));
+        a.ncache = 0;                             // no parking across workgroups
+        a.kslot_bytes = SW_BCH * 8;
+        launch((unsigned)(rest * nrb2));
         hipLaunchKernelGGL(sweep_finish_kernel, dim3((unsigned)rest), dim3(64), 0, s, a);
     }
     return 0;
 }
 
-// chunks whose B operands are revisited by a later row block
-static inline long long sweep_ncache(int64_t n) {
-    return (long long)(SW_ROWS / SW_KC) * (apgp_npad(n) / APGP_ROW_BLOCK - 1);
-}
-
+// Layout of the caller's scratch (doubles): [2 ncb arg-min partials | slots x ncache x SW_BCH
+// parked operands | 2 x S2_SPLIT_MAX x SW_CAND x nrb row-block shares of the split last round]
 extern "C" int64_t apgp_acquire_work_len(int64_t m, int64_t n) {
     if (m < 1 || n < 1) return 0;
     const long long ncb = (m + SW_CAND - 1) / SW_CAND;
     const long long slots = ncb < SW_GRID ? ncb : SW_GRID;
-    const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
-    // (parked stream sized for the 256-row-block kernel: 32 nrb - 16 chunks per slot)
-    return 2 * ncb + slots * (sweep_ncache(n) + 16) * SW_BCH + 2 * (long long)SW_SPLIT_MAX * SW_CAND * 2 * nrb;
+    return 2 * ncb + slots * s2_ncache(n) * SW_BCH + 2 * (long long)S2_SPLIT_MAX * SW_CAND * s2_nrb(n);
 }
 
 extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
@@ -1305,32 +765,24 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     a.T = T; a.linv = packed_linv; a.xs = xs; a.mask = mask; a.dbg = NULL;
     a.mu = mu; a.var = var; a.u = u;
     const long long nblk = (m + SW_CAND - 1) / SW_CAND;
+    const long long slots = nblk < SW_GRID ? nblk : SW_GRID;
     a.part_u = (double*)part;
     a.part_i = part ? (long long*)((double*)part + nblk) : NULL;
-    a.ncache = (int)sweep_ncache(n);
-    {   // developer A/B switch: APGP_SWEEP_PARK=0 regenerates k* for every row block
-        static int park = -1;
-        if (park < 0) { const char* e = getenv("APGP_SWEEP_PARK"); park = (e && e[0] == '0') ? 0 : 1; }
-        a.ncache2 = S2_CPB * (int)((n + S2_ROWS - 1) / S2_ROWS - 1);
-        if (!park) { a.ncache = 0; a.ncache2 = 0; }
-    }
-    // N <= 512: nothing is parked; the (unconditional, discarded) prefetch then reads the factor
-    a.kcache = (a.ncache > 0 || a.ncache2 > 0) ? (double*)part + 2 * nblk : (double*)packed_linv;
-    {   // row-block shares of the split last round (after the parked-operand slots)
-        const long long slots = nblk < SW_GRID ? nblk : SW_GRID;
-        const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
-        a.sp_q = part ? (double*)part + 2 * nblk + slots * (sweep_ncache(n) + 16) * SW_BCH : NULL;
-        a.sp_mu = a.sp_q ? a.sp_q + (long long)SW_SPLIT_MAX * SW_CAND * 2 * nrb : NULL;
-        a.blk_begin = 0; a.blk_end = nblk; a.split = 0;
-    }
+    a.ncache = (int)s2_ncache(n);
+    // N <= 256: nothing is parked; the descriptor then points at the factor (never dereferenced)
+    a.kcache = a.ncache > 0 ? (double*)part + 2 * nblk : (double*)packed_linv;
+    // row-block shares of the split last round (after the parked-operand slots)
+    a.sp_q = part ? (double*)part + 2 * nblk + slots * s2_ncache(n) * SW_BCH : NULL;
+    a.sp_mu = a.sp_q ? a.sp_q + (long long)S2_SPLIT_MAX * SW_CAND * s2_nrb(n) : NULL;
+    a.blk_begin = 0; a.blk_end = nblk; a.split = 0;
     {
         const long long wb = apgp_packed_linv_len(n) * 8, xb = apgp_packed_train_len(n, kc.ndim) * 8;
-        const long long kb = a.ncache > 0 ? (long long)a.ncache * SW_BCH * 8 : SW_BCH * 8;
+        const long long kb = (long long)(a.ncache > 0 ? a.ncache : 1) * SW_BCH * 8;
         APGP_CHECK_ARG(wb < (1ll << 31) && kb < (1ll << 31), "n too large for the sweep's 32-bit stream offsets");
         a.linv_bytes = (unsigned)wb; a.xs_bytes = (unsigned)xb; a.kslot_bytes = (unsigned)kb;
     }
     a.m = m; a.idx_offset = idx_offset;
-    a.ndim = kc.ndim; a.nrb = (int)(apgp_npad(n) / APGP_ROW_BLOCK); a.kind = kind; a.n = (int)n;
+    a.ndim = kc.ndim; a.nrb = s2_nrb(n); a.kind = kind; a.n = (int)n;
     a.has_box = lo != NULL;
     a.mean = mean; a.amp = kc.amp; a.zeta = zeta; a.ybest = ybest;
     a.lin_coef = kc.lin_coef; a.lin_order = kc.lin_order;
@@ -1341,12 +793,14 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
         a.hi[d] = (hi && d < kc.ndim) ? hi[d] : 0.0;
     }
     hipStream_t s = (hipStream_t)stream;
+    int rc;
     switch (kc.dpad) {
-        case 2: launch_sweep<2>(a, s); break;
-        case 4: launch_sweep<4>(a, s); break;
-        case 8: launch_sweep<8>(a, s); break;
-        default: launch_sweep<16>(a, s); break;
+        case 2: rc = launch_sweep<2>(a, s); break;
+        case 4: rc = launch_sweep<4>(a, s); break;
+        case 8: rc = launch_sweep<8>(a, s); break;
+        default: rc = launch_sweep<16>(a, s); break;
     }
+    if (rc != 0) return rc;
     if (kind != APGP_UTIL_NONE)
         hipLaunchKernelGGL(argmin_final_kernel, dim3(1), dim3(1024), 0, s, a.part_u, a.part_i, nblk, best);
     APGP_CHECK_LAUNCH();

@@ -18,11 +18,11 @@ exactly the members the reference calls:
   ``gp.predict(y, t, return_var=True)`` / mean only                utility.py:131; approx.py:178
   ``gp.computed``, ``gp.kernel``, ``gp.mean``, ``gp.white_noise``  utility.py:130; approx.py:712-714
 
-All arithmetic runs in the hand-written HIP kernels of ``libapgp.so``
-(include/apgp.h) on one MI355X; the Cholesky factorisation is rocSOLVER's
-dpotrf through ``torch.linalg.cholesky_ex``.  PyTorch is otherwise only the
-device allocator / stream provider.  There is no CPU fallback: without a GPU or
-without the built extension every compute entry point raises.
+All arithmetic -- including the blocked Cholesky factorisation (csrc/potrf.hip)
+-- runs in the hand-written HIP kernels of ``libapgp.so`` (include/apgp.h) on one
+MI355X.  PyTorch is only the device allocator / stream provider.  There is no
+CPU fallback: without a GPU or without the built extension every compute entry
+point raises.
 
 Beyond george's API the GP also offers the batched counterparts the reference
 lacks: ``acquire`` (fused predict + utility + arg-min over a candidate matrix)
@@ -44,13 +44,9 @@ UTILITY_KINDS = {"agp": _lib.UTIL_AGP, "bape": _lib.UTIL_BAPE, "jones": _lib.UTI
 # Above this condition estimate ((max L_ii / min L_ii)^2) the explicit L^-1
 # contraction is no longer trusted for the predictive variance (SURVEY.md
 # section 7, "Conditioning vs. formulation") and the solve-based sweep
-# (apgp_acquire_solve) is used instead.  APGP_VARIANCE=solve|inverse overrides.
+# (apgp_acquire_solve) is used instead.  ``GP.variance_mode`` = "solve" | "inverse"
+# overrides the choice for one object (tests); no environment variable is read.
 COND_SOLVE = 1.0e10
-
-# APGP_CHOLESKY=rocsolver routes the factorisation through torch.linalg.cholesky_ex
-# (rocSOLVER dpotrf) instead of the in-tree blocked Cholesky -- for A/B checks only.
-import os as _os
-_USE_ROCSOLVER = _os.environ.get("APGP_CHOLESKY", "").lower() == "rocsolver"
 
 
 # ---------------------------------------------------------------------------
@@ -297,6 +293,7 @@ class GP(object):
         self.fit_mean = bool(fit_mean)
         self.fit_white_noise = bool(fit_white_noise)
         self._device_arg = device
+        self.variance_mode = None     # None: by condition estimate; "solve" / "inverse": forced
         self._computed = False
         self._x = None
         self._yerr2 = 0.0
@@ -435,7 +432,7 @@ class GP(object):
     def _try_extend(self, prev):
         """Extend ``prev``'s Cholesky factor by the rows of self._x it does not cover:
         l = L^-1 k(x_new, X_old), d = sqrt(k(x_new,x_new) + diag_add - l.l)."""
-        if _USE_ROCSOLVER or getattr(prev, "_L", None) is None or getattr(prev, "_x", None) is None:
+        if getattr(prev, "_L", None) is None or getattr(prev, "_x", None) is None:
             return False
         if getattr(prev, "_factored_key", None) != self._factor_key():
             return False
@@ -498,7 +495,7 @@ class GP(object):
             self._x_d = keep_x if keep_x is not None else torch.from_numpy(x).to(dev)
             K = torch.empty((n, n), dtype=torch.float64, device=dev)
             z = None
-            if yv is not None and not _USE_ROCSOLVER:
+            if yv is not None:
                 # the whole _nll evaluation as one library call and one synchronisation
                 y_d = keep_y if keep_y is not None else torch.from_numpy(yv).to(dev)
                 z = torch.empty(n, dtype=torch.float64, device=dev)
@@ -516,20 +513,11 @@ class GP(object):
                 _lib.check(lib.apgp_gram(self._x_d.data_ptr(), n, ctypes.byref(ks), K.data_ptr(), n, st),
                            "apgp_gram")
                 out5 = torch.empty(5, dtype=torch.float64, device=dev)
-                if _USE_ROCSOLVER:
-                    # rocSOLVER potrf works column-major: asking for the UPPER factor makes
-                    # its memory image the row-major LOWER factor the kernels stream.
-                    U, info = torch.linalg.cholesky_ex(K, upper=True, check_errors=False)
-                    L = U.mT
-                    if not L.is_contiguous():
-                        L = L.contiguous()
-                    info = info.to(torch.int32).reshape(1)
-                else:
-                    # own blocked Cholesky (csrc/potrf.hip), in place on the Gram matrix
-                    info = torch.empty(1, dtype=torch.int32, device=dev)
-                    _lib.check(lib.apgp_potrf(K.data_ptr(), n, n, None, 0.0, None, info.data_ptr(), st),
-                               "apgp_potrf")
-                    L = K
+                # blocked Cholesky (csrc/potrf.hip), in place on the Gram matrix
+                info = torch.empty(1, dtype=torch.int32, device=dev)
+                _lib.check(lib.apgp_potrf(K.data_ptr(), n, n, None, 0.0, None, info.data_ptr(), st),
+                           "apgp_potrf")
+                L = K
                 _lib.check(lib.apgp_fit_summary(L.data_ptr(), n, n, None, info.data_ptr(), out5.data_ptr(), st),
                            "apgp_fit_summary")
                 o = out5.cpu().numpy()          # the only synchronisation of the evaluation
@@ -776,7 +764,7 @@ class GP(object):
                                                  ctypes.byref(ks), float(self.mean.value),
                                                  mu.data_ptr(), st), "apgp_predict_mean")
                 return (mu.cpu().numpy(),)
-            mode = _os.environ.get("APGP_VARIANCE", "").lower()
+            mode = (self.variance_mode or "").lower()
             use_solve = (mode == "solve") or (mode != "inverse" and self.cond_estimate is not None
                                               and self.cond_estimate > COND_SOLVE and n <= 4096)
             if not use_solve:

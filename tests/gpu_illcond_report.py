@@ -6,8 +6,8 @@ from approxposterior_amd import gp as agp
 from test_gpu_parity import build
 g = np.load(os.path.join(ROOT, "tests/golden/rosen2d_n50_amp_opt_illcond.npz"))
 for mode in ("solve", "inverse", ""):
-    os.environ["APGP_VARIANCE"] = mode
     gp = build(agp, g)
+    gp.variance_mode = mode or None
     mu, var = gp.predict(g["y"], g["cands"], return_var=True)
     vt, mt = g["var_truth"], g["mu_truth"]
     print("mode=%-8s cond_est %.3g | var rel err vs truth: mine median %.3g max %.3g | oracle median %.3g max %.3g | mu rel err mine max %.3g oracle max %.3g" % (
