@@ -303,6 +303,16 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                                 mfma_pair(pr, 2);
                                 mfma_pair(pr, 3);
                             }
+#ifdef S2_SPREAD
+                            // developer variant: one LDS read per S2_SPREAD MFMAs instead of a cluster
+                            if (!PRED) {
+#pragma unroll
+                                for (int q_ = 0; q_ < (pr == 0 ? 8 : 4); ++q_) {
+                                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x008, S2_SPREAD, 0);
+                                }
+                            }
+#endif
                         } else {
                             // last pair: the next tile's first A fragments and, as soon as this
                             // tile's k-step 0-1 B registers fall free, that half of the next
@@ -316,6 +326,15 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                                 mfma_pair(pr, 2);
                                 mfma_pair(pr, 3);
                             }
+#ifdef S2_SPREAD
+                            if (!PRED) {
+#pragma unroll
+                                for (int q_ = 0; q_ < 4; ++q_) {
+                                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x008, S2_SPREAD, 0);
+                                }
+                            }
+#endif
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }

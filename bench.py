@@ -7,12 +7,18 @@ A "step" is one pass of the hot path over one batch of synthetic candidates:
 the fused sweep (k* generation -> mu -> L^-1 k* contraction on the f64 matrix
 cores -> variance -> AGP utility -> arg-min), the final arg-min reduction, and
 (N > 1) the all-gather of the per-rank winners -- from "candidates resident in
-HBM" to "(best_idx, best_u) on the host".  The fit (Gram + Cholesky + L^-1) is
-outside the timed region and reported separately.
+HBM" to "(best_idx, best_u) on the host".  The fit (Gram + Cholesky + L^-1) and
+the H2D copy of the candidates are outside the timed region and reported
+separately (``config.fit_ms_warm``, ``config.h2d_candidates_ms``).
 
 Workload at N=1: BASELINE.json configs[2] ("C3"): synthetic D=8 log-likelihood,
-N_train=4096, 1e6 candidates, AGP utility, box prior [-5,5]^8, fp64.  For N>1
-each rank sweeps its own 1e6-candidate shard (weak scaling, configs[3] shape).
+N_train=4096, 1e6 candidates, AGP utility, box prior [-5,5]^8, fp64.  The candidate
+matrix is ONE NumPy ``RandomState(1)`` draw of (total candidates) x D (SURVEY.md
+section 8d); rank r owns its rows [r M/world, (r+1) M/world), so the printed ``best`` can be
+re-derived by anybody.  For N>1:
+  default                      weak scaling: 1e6 candidates per rank (total = N x 1e6);
+  --total-candidates 10000000  configs[3] ("C4") as written: 1e7 candidates split over the
+                               ranks (1.25e6 per rank at N=8), reported as "scaling": "strong".
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 bench.py --gpus 8 ...
@@ -21,6 +27,7 @@ Rank 0 prints ONE JSON line.
 """
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F64_TFLOPS = 78.6   # AMD public MI355X FP64 matrix = FP64 vector peak
+CSRC = os.path.join(ROOT, "approxposterior_amd", "csrc")
 
 
 def synthetic_c3(n_train, ndim):
@@ -43,18 +51,34 @@ def synthetic_c3(n_train, ndim):
     return X, y
 
 
+def sweep_source_hash():
+    """Identity of the kernel a profile was taken of: sha256 over the sweep's sources."""
+    h = hashlib.sha256()
+    for name in ("sweep.hip", "apgp_common.h"):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def profiled_traffic(n, d, m):
-    """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes
-    (profiles/r01f_pmc_sweep.json: FETCH_SIZE x2 for the gfx950 wide-stream
-    correction + WRITE_SIZE, per MI355X_MICROARCH.md), only for the exact workload
-    that was profiled; None otherwise (PMC counters are not collected inline)."""
-    path = os.path.join(ROOT, "profiles", "r01f_pmc_sweep.json")
-    if (n, d, m) != (4096, 8, 1000000) or not os.path.exists(path):
-        return None
-    try:
-        return float(json.load(open(path))["derived"]["hbm_traffic_bytes_per_launch"])
-    except Exception:
-        return None
+    """HBM-side bytes per sweep call from the newest committed rocprofv3 PMC summary
+    (profiles/r*_pmc_sweep.json: FETCH_SIZE x2 for the gfx950 wide-stream correction +
+    WRITE_SIZE, per MI355X_MICROARCH.md).  PMC counters cannot be collected inside this
+    process, so the figure is only reported when it was measured on THIS kernel (the
+    summary's ``sweep_source_sha`` equals the hash of the sources that are compiled now) and
+    on this workload; otherwise None -- a stale number is never printed."""
+    if (n, d, m) != (4096, 8, 1000000):
+        return None, None
+    import glob
+    here = sweep_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sweep.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+            if rec.get("sweep_source_sha") == here:
+                return float(rec["derived"]["hbm_traffic_bytes_per_launch"]), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def f_var(n, d):
@@ -62,12 +86,7 @@ def f_var(n, d):
     return float(n) * n + float(n) * (3 * d + 4)
 
 
-def cpu_baseline(X, y, metric, ndim, seconds=12.0):
-    """Reference-library batched path (BASELINE.md section 3 (ii)) on the oracle:
-    predict(y, T_chunk, return_var=True) on 4096-candidate chunks + vectorised
-    AGP utility + arg-min, all host cores for BLAS.  george itself is not
-    installable here, so this runs the NumPy/SciPy restatement (same LAPACK
-    calls george's BasicSolver makes): kind = "port"."""
+def oracle_gp(X, y, metric, ndim):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import george_oracle as go
     k = go.ExpSquaredKernel(np.full(ndim, metric), ndim=ndim)
@@ -75,38 +94,64 @@ def cpu_baseline(X, y, metric, ndim, seconds=12.0):
     t0 = time.time()
     gp.compute(X)
     gp._compute_alpha(y, True)
-    fit_s = time.time() - t0
+    return gp, time.time() - t0
+
+
+def agp_utility(mu, var, inside):
+    with np.errstate(all="ignore"):
+        u = -(mu + 0.5 * np.log(2.0 * np.pi * np.e * var))
+    return np.where(inside, u, np.inf)
+
+
+def check_best(gpo, y, cands, best, lo=-5.0, hi=5.0):
+    """The winner against the oracle (the checker, never the thing measured): the oracle's
+    utility over the 4,096-candidate chunk that contains the winning row must have its
+    minimum at that row, with the same value (1e-9 relative)."""
+    bi, bu = int(best[0]), float(best[1])
+    if bi < 0:
+        return False
+    c0 = (bi // 4096) * 4096
+    chunk = cands[c0:c0 + 4096]
+    mu, var = gpo.predict(y, chunk, return_var=True)
+    u = agp_utility(mu, var, np.all((chunk >= lo) & (chunk <= hi), axis=1))
+    j = bi - c0
+    return bool(abs(u[j] - bu) <= 1e-9 * max(1.0, abs(bu)) and
+                u[j] <= np.nanmin(u) + 1e-9 * max(1.0, abs(bu)))
+
+
+def cpu_baseline(gpo, fit_s, y, ndim, seconds=12.0, scalar_calls=2000):
+    """Reference-library batched path (BASELINE.md section 3 (ii)) on the oracle:
+    predict(y, T_chunk, return_var=True) on 4096-candidate chunks + vectorised
+    AGP utility + arg-min, all host cores for BLAS.  george itself is not
+    installable here, so this runs the NumPy/SciPy restatement (same LAPACK
+    calls george's BasicSolver makes): kind = "port"."""
     rs = np.random.RandomState(1)
     done = 0
     best = (np.inf, -1)
     t0 = time.time()
     while time.time() - t0 < seconds:
         T = rs.uniform(-5.0, 5.0, size=(4096, ndim))
-        mu, var = gp.predict(y, T, return_var=True)
-        with np.errstate(all="ignore"):
-            u = -(mu + 0.5 * np.log(2.0 * np.pi * np.e * var))
+        mu, var = gpo.predict(y, T, return_var=True)
+        u = agp_utility(mu, var, True)
         i = int(np.nanargmin(u))
         if u[i] < best[0]:
             best = (float(u[i]), done + i)
         done += len(T)
     dt = time.time() - t0
     # (i) reference-faithful scalar path: one candidate per predict call, as
-    # utility.minimizeObjective drives it (utility.py:131) -- small subsample
+    # utility.minimizeObjective drives it (utility.py:131) -- SURVEY.md 8(d)(i): >= 2,000 calls
     t1 = time.time()
-    ns = 0
-    while time.time() - t1 < max(2.0, seconds / 4.0):
+    for _ in range(int(scalar_calls)):
         t = rs.uniform(-5.0, 5.0, size=(1, ndim))
-        mu, var = gp.predict(y, t, return_var=True)
-        with np.errstate(all="ignore"):
-            _ = -(mu + 0.5 * np.log(2.0 * np.pi * np.e * var))
-        ns += 1
+        mu, var = gpo.predict(y, t, return_var=True)
+        _ = agp_utility(mu, var, True)
     ds = time.time() - t1
     return {"value": done / dt, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "port",
             "sample": "%d candidates in %.1f s (4096-candidate chunks, N_train=%d, D=%d, "
                       "oracle predict+utility+argmin; fit %.2f s excluded)" % (done, dt, len(y), ndim, fit_s),
-            "scalar_path_value": ns / ds,
+            "scalar_path_value": scalar_calls / ds,
             "scalar_path_sample": "%d single-candidate predict+utility calls in %.1f s "
-                                  "(what the reference's Nelder-Mead search evaluates)" % (ns, ds)}
+                                  "(what the reference's Nelder-Mead search evaluates)" % (scalar_calls, ds)}
 
 
 def main():
@@ -116,11 +161,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-train", type=int, default=4096)
     ap.add_argument("--ndim", type=int, default=8)
-    ap.add_argument("--candidates", type=int, default=1000000, help="candidates per GPU per step")
+    ap.add_argument("--candidates", type=int, default=1000000, help="candidates per GPU per step (weak scaling)")
+    ap.add_argument("--total-candidates", type=int, default=0,
+                    help="total candidates per step, split over the ranks (strong scaling; 10000000 = C4)")
     ap.add_argument("--metric", type=float, default=8.0)
     ap.add_argument("--utility", default="agp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the winner")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-scalar-calls", type=int, default=2000)
     args = ap.parse_args()
 
     import torch
@@ -143,30 +192,53 @@ def main():
     from approxposterior_amd import gp as agp
     from approxposterior_amd import dist as adist
 
-    N, D, M = args.n_train, args.ndim, args.candidates
+    N, D = args.n_train, args.ndim
+    strong = args.total_candidates > 0
+    M_total = args.total_candidates if strong else args.candidates * world
+    lo_row, hi_row = adist.shard_bounds(M_total, world, rank)
+    M = hi_row - lo_row
     X, y = synthetic_c3(N, D)
-    kernel = agp.ExpSquaredKernel(np.full(D, args.metric), ndim=D)
-    gp = agp.GP(kernel=kernel, fit_mean=True, mean=np.median(y), white_noise=-12,
-                fit_white_noise=False, device=dev)
+
+    def fit():
+        kernel = agp.ExpSquaredKernel(np.full(D, args.metric), ndim=D)
+        g = agp.GP(kernel=kernel, fit_mean=True, mean=np.median(y), white_noise=-12,
+                   fit_white_noise=False, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        g.compute(X)
+        g._ensure_xs(y)
+        g._ensure_linv()
+        torch.cuda.synchronize()
+        return g, (time.time() - t0) * 1e3
+    _, fit_ms_cold = fit()      # includes module load, first allocations, attribute set-up
+    gp, fit_ms = fit()          # what a refit costs: Gram + Cholesky + solves + L^-1 + packing
+
+    # candidates: ONE global NumPy seed-1 draw; this rank's rows; resident in HBM before the
+    # timed region (the H2D copy is reported separately)
+    rs = np.random.RandomState(1)
+    if rank == 0 and not args.no_check:
+        cands_all = rs.uniform(-5.0, 5.0, size=(M_total, D))
+        mine = cands_all[lo_row:hi_row]
+    else:
+        # skip the rows of lower ranks without holding them (same stream positions)
+        left = lo_row
+        while left > 0:
+            n = min(left, 1 << 20)
+            rs.uniform(-5.0, 5.0, size=(n, D))
+            left -= n
+        mine = rs.uniform(-5.0, 5.0, size=(M, D))
+        cands_all = None
+    mine = np.ascontiguousarray(mine)
     torch.cuda.synchronize()
     t0 = time.time()
-    gp.compute(X)
-    gp._ensure_xs(y)
-    gp._ensure_linv()
+    T = torch.from_numpy(mine).to(dev)
     torch.cuda.synchronize()
-    fit_ms = (time.time() - t0) * 1e3
-
-    # candidates: resident in HBM before the timed region; rank r owns global rows
-    # [r*M, (r+1)*M) (seed 1 + rank so shards differ)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1 + rank)
-    T = (torch.rand((M, D), dtype=torch.float64, device=dev, generator=gen) * 10.0 - 5.0).contiguous()
+    h2d_ms = (time.time() - t0) * 1e3
     bounds = [(-5.0, 5.0)] * D
-    offset = rank * M
 
     def step():
         return adist.sharded_acquire(
-            lambda off: gp.acquire(y, T, args.utility, bounds=bounds, idx_offset=off), offset)
+            lambda off: gp.acquire(y, T, args.utility, bounds=bounds, idx_offset=off), lo_row)
 
     def barrier():
         if launched:
@@ -191,33 +263,45 @@ def main():
     kms = [a.elapsed_time(b) for a, b in kernel_ms]
 
     if rank == 0:
-        total = float(M) * world * args.steps
+        total = float(M_total) * args.steps
         value = total / elapsed
         k_avg_ms = float(np.mean(kms))
         achieved = f_var(N, D) * M / (k_avg_ms * 1e-3) / 1e12
+        traffic, traffic_src = profiled_traffic(N, D, M)
+        name = "C3" if (N, D, M_total, world) == (4096, 8, 1000000, 1) else \
+               "C4" if (N, D, M_total) == (4096, 8, 10000000) else "C3-shaped"
         out = {
             "metric": "GP-predict+acquisition candidates/sec (N_train, D fixed)",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3: synthetic D=%d log-likelihood (-rosen/100), N_train=%d, "
-                                   "%d candidates per GPU, %s utility, box prior [-5,5]^D, "
+            "config": {"workload": "%s: synthetic D=%d log-likelihood (-rosen/100), N_train=%d, "
+                                   "%d candidates in total (%d on rank 0), %s utility, box prior [-5,5]^D, "
                                    "ExpSquaredKernel metric %.1f, white_noise -12"
-                                   % (D, N, M, args.utility.upper(), args.metric),
-                       "n_train": N, "ndim": D, "candidates_per_gpu": M,
+                                   % (name, D, N, M_total, M, args.utility.upper(), args.metric),
+                       "n_train": N, "ndim": D, "candidates_total": M_total, "candidates_per_gpu": M,
+                       "candidate_draw": "numpy RandomState(1).uniform(-5, 5, (candidates_total, D)); "
+                                         "rank r owns rows [r M/world, (r+1) M/world)",
                        "sharding": "candidates split by rank, one 16 B/rank all-gather",
-                       "fit_ms_excluded": fit_ms},
+                       "fit_ms_warm": fit_ms, "fit_ms_cold_first_call": fit_ms_cold,
+                       "h2d_candidates_ms": h2d_ms,
+                       "h2d_candidates_GBps": mine.nbytes / (h2d_ms * 1e-3) / 1e9},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
-                         "traffic": profiled_traffic(N, D, M),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "sweep2_kernel<%d, false>" % (2 if D <= 2 else 4 if D <= 4 else 8 if D <= 8 else 16),
                          "kernel_ms": k_avg_ms,
                          "algorithmic_flops_per_candidate": f_var(N, D)},
             "best": {"index": int(best[0]), "u": float(best[1])},
         }
+        need_oracle = (not args.no_check) or (world == 1 and not args.no_cpu_baseline)
+        if need_oracle:
+            gpo, fit_s = oracle_gp(X, y, args.metric, D)
+        if not args.no_check:
+            out["best_checked"] = check_best(gpo, y, cands_all, best)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, y, args.metric, D, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(gpo, fit_s, y, D, args.cpu_seconds, args.cpu_scalar_calls)
         print(json.dumps(out))
     if launched:
         dist.destroy_process_group()

@@ -4,7 +4,7 @@
 # Kernel trace and every PMC group are SEPARATE runs of the same command (the counters do
 # not fit one pass, and --pmc must not be combined with other trace domains).
 tag=${1:-r01x}
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check"
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp

@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Condense the rocprofv3 output of tools/profile_round.sh into
 gpurun_out/prof_<tag>/{kernel_stats.csv, pmc_sweep.json} (copy into profiles/)."""
-import csv, glob, json, os, shutil, sys
+import csv, glob, hashlib, json, os, shutil, sys
 
 tag = sys.argv[1]
 root = os.path.join("gpurun_out", "prof_" + tag)
-KERNEL = "sweep2_kernel"      # the two-role sweep (APGP_SWEEP2=0 runs: "sweep_kernel")
+KERNEL = "sweep2_kernel"      # the two-role sweep
 
 stats = glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
@@ -55,7 +55,12 @@ if c("SQ_VALU_MFMA_BUSY_CYCLES") is not None and c("GRBM_GUI_ACTIVE") is not Non
     # busy cycles summed over 1024 SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs
     derived["shader_cycles_per_launch"] = c("GRBM_GUI_ACTIVE") / 8.0
     derived["mfma_busy_fraction"] = c("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * c("GRBM_GUI_ACTIVE") / 8.0)
-out = {"kernel": KERNEL, "workload": "bench.py default: N_train=4096, D=8, 1e6 candidates, AGP",
+# identity of the profiled kernel: bench.py only reports `traffic` from a summary whose hash
+# matches the sources it runs (same function as bench.sweep_source_hash)
+sha = hashlib.sha256()
+for name in ("sweep.hip", "apgp_common.h"):
+    sha.update(open(os.path.join("approxposterior_amd", "csrc", name), "rb").read())
+out = {"kernel": KERNEL, "sweep_source_sha": sha.hexdigest()[:16], "workload": "bench.py default: N_train=4096, D=8, 1e6 candidates, AGP",
        "how": "tools/profile_round.sh %s (separate rocprofv3 --pmc passes, 1 warm-up + 3 timed launches each)" % tag,
        "counters": counters, "derived": derived}
 json.dump(out, open(os.path.join(root, "pmc_sweep.json"), "w"), indent=1)
