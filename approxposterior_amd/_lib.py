@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libapgp.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_DIM = 16
 
 UTIL_AGP, UTIL_BAPE, UTIL_JONES, UTIL_NONE = 0, 1, 2, 3
@@ -56,6 +56,9 @@ SIGNATURES = {
     "apgp_nll_eval": (ctypes.c_int, [_P, _I64, _KP, _P, _F64, _P, _P, _P, _P, _P, _P]),
     "apgp_nll_eval_batch": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "apgp_trsv": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, ctypes.c_int, _P, _P, _P]),
+    "apgp_append_diag": (ctypes.c_int, [_P, _P, _F64, _P, _I64, _P]),
+    "apgp_winv_apply_work_len": (_I64, [_I64]),
+    "apgp_winv_apply": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, ctypes.c_int, _P, _P, _P, _P]),
     "apgp_trtri_pack": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
     "apgp_pack_train": (ctypes.c_int, [_P, _P, _I64, _KP, _P, _P]),
     "apgp_acquire": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _I64, _KP, _F64, _I32,

@@ -1,5 +1,7 @@
-// K1 "gram": N x N Gram matrix  K_ij = amp * exp(-|xs_i - xs_j|^2) [+ lin_coef * sum_d (x_id x_jd)^P], LDS-tiled, coalesced row
-// writes.  HBM-write-bound (8 N^2 bytes out, 8 N D bytes in).
+// K1 "gram": lower triangle of the N x N Gram matrix  K_ij = amp * exp(-|xs_i - xs_j|^2)
+// [+ lin_coef * sum_d (x_id x_jd)^P], LDS-tiled, coalesced row writes.  HBM-write-bound
+// (4 N^2 bytes out -- only the 64 x 64 tiles on and below the diagonal, which is all the
+// Cholesky reads --, 8 N D bytes in).
 // Reference semantics: george ExpSquaredKernel.get_value + the diagonal update
 // of GP.compute (called from gpUtils.py:178,244,254; approx.py:717).
 #include "apgp_common.h"
@@ -35,7 +37,12 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     __shared__ double etab[APGP_EXP_TAB_N];
     apgp_exp_tab_load(etab);
     const int t = threadIdx.x;
-    const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
+    // lower triangle only: linear tile index -> (row block bi, column block bj <= bi)
+    const long long tix = blockIdx.x;
+    long long bi = (long long)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= tix) ++bi;
+    while (bi * (bi + 1) / 2 > tix) --bi;
+    const long long i0 = bi * 64, j0 = (tix - bi * (bi + 1) / 2) * 64;
     for (int e = t; e < 64 * DPAD; e += 256) {
         int r = e / DPAD, d = e % DPAD;
         long long gi = i0 + r, gj = j0 + r;
@@ -84,7 +91,8 @@ extern "C" int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern, 
     GramArgs a;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &a.kc) == 0, "kernel parameters");
     a.X = X; a.K = K; a.n = n; a.ldk = ldk;
-    dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64)), block(256);
+    const long long nb = (n + 63) / 64;
+    dim3 grid((unsigned)(nb * (nb + 1) / 2)), block(256);
     hipStream_t s = (hipStream_t)stream;
     switch (a.kc.dpad) {
         case 2: hipLaunchKernelGGL(gram_kernel<2>, grid, block, 0, s, a); break;

@@ -223,6 +223,128 @@ extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* 
 }
 
 // ---------------------------------------------------------------------------
+// Diagonal entry of an appended factor row (incremental fit, approx.py:693-717): after
+// l = L^-1 k(x_new, X_old) (apgp_kernel_cross + apgp_trsv, *ss = l.l) the new pivot is
+// d = sqrt(kdiag - l.l); a non-positive pivot is reported LAPACK-style through *info_dev
+// (0 = none; the first failing leading-minor order is kept) and d = 1 keeps later rows finite.
+// No host round trip per appended row.
+// ---------------------------------------------------------------------------
+__global__ void append_diag_kernel(double* ljj, const double* ss, double kdiag, int* info, int order) {
+    const double d2 = kdiag - *ss;
+    if (d2 > 0.0 && d2 < INFINITY) *ljj = sqrt(d2);
+    else { *ljj = 1.0; atomicCAS(info, 0, order); }
+}
+
+extern "C" int apgp_append_diag(double* ljj, const double* ss, double kdiag, int32_t* info_dev, int64_t order,
+                                void* stream) {
+    APGP_CHECK_ARG(ljj && ss && info_dev, "null pointer");
+    APGP_CHECK_ARG(order >= 1 && order < (1ll << 31), "order out of range");
+    hipLaunchKernelGGL(append_diag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ljj, ss, kdiag, (int*)info_dev, (int)order);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// K3 with the explicit inverse: z = W (b - shift) or x = W^T b for the dense lower-triangular
+// W = L^-1 that apgp_trtri_pack leaves resident for every sweep set-up.  Two HBM-rate GEMVs
+// (the 67 MB triangle at N = 4096 in ~20 us each) replace the two single-workgroup triangular
+// solves (1.6 ms each) of GP._compute_alpha (george; utility.py:131 via GP.predict).  Same
+// accuracy class as the sweep's own use of W: the caller keeps the solve form above cond 1e10.
+// Both kernels reduce in a fixed order (bit-reproducible).
+// ---------------------------------------------------------------------------
+#define WA_RCH 128     // rows per partial-sum chunk of the transposed product
+__global__ __launch_bounds__(256) void winv_gemv_kernel(const double* W, long long ldw, long long n,
+                                                        const double* b, double shift, double* x) {
+    // one wavefront per row i: x_i = sum_{k <= i} W_ik (b_k - shift)
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const double* wr = W + i * ldw;
+    double s0 = 0.0, s1 = 0.0;
+    for (long long k = 2 * lane; k <= i; k += 128) {
+        const f64x2 w2 = *(const f64x2*)(wr + k);          // W is zero above the diagonal
+        s0 = fma(w2.x, b[k] - shift, s0);
+        if (k + 1 <= i) s1 = fma(w2.y, b[k + 1] - shift, s1);
+    }
+    double s = s0 + s1;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) x[i] = s;
+}
+
+__global__ __launch_bounds__(256) void winv_gemvt_partial_kernel(const double* W, long long ldw, long long n,
+                                                                 const double* z, double* part) {
+    // thread per column k, rows [r0, r0 + WA_RCH): part[chunk][k] = sum_i W_ik z_i (i >= k)
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r0 = (long long)blockIdx.y * WA_RCH;
+    if (r0 + WA_RCH <= (long long)blockIdx.x * 256) {          // chunk entirely above the diagonal
+        if (k < n) part[(long long)blockIdx.y * n + k] = 0.0;
+        return;
+    }
+    __shared__ double zs[WA_RCH];
+    if (threadIdx.x < WA_RCH) zs[threadIdx.x] = (r0 + threadIdx.x < n) ? z[r0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    if (k >= n) return;
+    const long long r1 = r0 + WA_RCH < n ? r0 + WA_RCH : n;
+    double s0 = 0.0, s1 = 0.0;
+    long long i = r0 > k ? r0 : k;
+    for (; i + 1 < r1; i += 2) {
+        s0 = fma(W[i * ldw + k], zs[i - r0], s0);
+        s1 = fma(W[(i + 1) * ldw + k], zs[i + 1 - r0], s1);
+    }
+    if (i < r1) s0 = fma(W[i * ldw + k], zs[i - r0], s0);
+    part[(long long)blockIdx.y * n + k] = s0 + s1;
+}
+
+__global__ __launch_bounds__(256) void winv_gemvt_reduce_kernel(const double* part, long long n, int nchunk, double* x) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += part[(long long)c * n + k];
+    x[k] = s;
+}
+
+__global__ __launch_bounds__(1024) void sumsq_kernel(const double* x, long long n, double* out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) s = fma(x[i], x[i], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        *out = t;
+    }
+}
+
+extern "C" int64_t apgp_winv_apply_work_len(int64_t n) {
+    return n < 1 ? 0 : ((n + WA_RCH - 1) / WA_RCH) * n;
+}
+
+extern "C" int apgp_winv_apply(const double* winv, int64_t ldw, int64_t n, const double* b, double shift,
+                               int trans, double* x, double* sumsq, double* work, void* stream) {
+    APGP_CHECK_ARG(winv && b && x, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && ldw >= n, "n >= 1 and ldw >= n required");
+    APGP_CHECK_ARG(!trans || work, "work (apgp_winv_apply_work_len doubles) required for the transposed product");
+    APGP_CHECK_ARG(!trans || shift == 0.0, "shift applies to the forward product only");
+    APGP_CHECK_ARG(x != b, "x must not alias b");
+    hipStream_t s = (hipStream_t)stream;
+    if (!trans) {
+        hipLaunchKernelGGL(winv_gemv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, winv, (long long)ldw,
+                           (long long)n, b, shift, x);
+    } else {
+        const int nchunk = (int)((n + WA_RCH - 1) / WA_RCH);
+        hipLaunchKernelGGL(winv_gemvt_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nchunk), dim3(256), 0, s,
+                           winv, (long long)ldw, (long long)n, b, work);
+        hipLaunchKernelGGL(winv_gemvt_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                           (const double*)work, (long long)n, nchunk, x);
+    }
+    if (sumsq) hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, s, (const double*)x, (long long)n, sumsq);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // Triangular inversion W = L^-1.
 //   (1) invert every 64x64 diagonal block (one wavefront per block, LDS);
 //   (2) log2 merge levels: for adjacent blocks A (first) and B (second) with

@@ -160,6 +160,12 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 // barrier i after the first k-step of pair 4 of tile i and read tile i+1 only after it.
 // ===========================================================================
 #define S2_THREADS 512
+// LDS reads of the matrix role are issued one per S2_SPREAD MFMAs instead of in clusters of four
+// (sched_group_barrier): clustered, the reads' issue time exceeds one MFMA's 16-cycle shadow and
+// the matrix pipe idles (same box, alternating: 249.5 vs 255.0 ms at C3).  0 = compiler's order.
+#ifndef S2_SPREAD
+#define S2_SPREAD 1
+#endif
 #define S2_ROWS 256
 #define S2_TILE (S2_ROWS * SW_KC)        // doubles per tile image (32 KiB)
 #define S2_CPB (S2_ROWS / SW_KC)         // chunks per row-block width (16)
@@ -231,6 +237,9 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         for (int r = 0; r < 4; ++r) lr[r] = (lane & 48) | ((lane + 4 * r) & 15);
         f64x2 av[2][2][2];
         auto load_a = [&](f64x2 (&dst)[2][2], int slot, int p) {
+#ifdef S2_X_NOA            // elimination build (results wrong): the A fragments are never re-read
+            if (p >= 0) return;
+#endif
             const f64x2* A2 = (const f64x2*)(Aring + slot * S2_TILE) + lane;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -247,6 +256,9 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         // B operands of the current tile in all four rotations; half 0 = k-steps 0-1, 1 = 2-3
         double brot[4][NKK];
         auto load_b = [&](int buf, int half) {
+#ifdef S2_X_NOB            // elimination build (results wrong): the B operands are never re-read
+            if (half >= 0) return;
+#endif
             const f64x2* Bw = (const f64x2*)(Bbuf + buf * 1024 + w * 256) + half * 64;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -256,8 +268,14 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         };
         load_a(av[0], 0, 0);
         load_b(0, 0);
+#ifdef S2_PROFILE
+        int s2_blkno = 0;      // row-block time stamps of the third candidate block of workgroup 0
+#endif
         for (long long blk = blk0; blk < a.blk_end; blk += blk_step) {
             double qtot = 0.0;
+#ifdef S2_PROFILE
+            if (a.dbg && blockIdx.x == 0 && t == 0 && s2_blkno == 2) a.dbg[40] = __builtin_amdgcn_s_memtime();
+#endif
             for (int jb = jb_lo; jb < jb_hi; ++jb) {
                 const int nkc = nkc_of(jb);
                 const int ndiag0 = S2_CPB * jb;
@@ -303,8 +321,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                                 mfma_pair(pr, 2);
                                 mfma_pair(pr, 3);
                             }
-#ifdef S2_SPREAD
-                            // developer variant: one LDS read per S2_SPREAD MFMAs instead of a cluster
+#if S2_SPREAD > 0
                             if (!PRED) {
 #pragma unroll
                                 for (int q_ = 0; q_ < (pr == 0 ? 8 : 4); ++q_) {
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                                 mfma_pair(pr, 2);
                                 mfma_pair(pr, 3);
                             }
-#ifdef S2_SPREAD
+#if S2_SPREAD > 0
                             if (!PRED) {
 #pragma unroll
                                 for (int q_ = 0; q_ < 4; ++q_) {
@@ -359,7 +376,13 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 qs += __shfl_xor(qs, 16);
                 qs += __shfl_xor(qs, 32);
                 qtot += qs;
+#ifdef S2_PROFILE
+                if (a.dbg && blockIdx.x == 0 && t == 0 && s2_blkno == 2 && jb < 40) a.dbg[jb] = __builtin_amdgcn_s_memtime();
+#endif
             }
+#ifdef S2_PROFILE
+            ++s2_blkno;
+#endif
             if (kq == 0) Shq[w * 16 + cl] = qtot;
             __syncthreads();                      // E1: sums visible to the feeders
             __syncthreads();                      // E2: block result written
@@ -434,6 +457,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 lsum[kk] = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;
                 al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
             }
+#ifndef S2_X_NOGEN         // (elimination build, results wrong: no distance sums, no exponential)
 #pragma unroll
             for (int d = 0; d < DPAD; d += 2)
 #pragma unroll
@@ -449,10 +473,16 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                         lsum[kk] += q0 + q1;
                     }
                 }
+#endif
             double ex[NKK];
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) ex[kk] = -(s2[kk] + s3[kk]);
+#if defined(S2_X_NOEXP) || defined(S2_X_NOGEN)          // elimination build (results wrong): no exponential
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) bfv[kk] = ex[kk];
+#else
             apgp_exp4(ex, bfv, Etab);
+#endif
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) bfv[kk] = LIN ? fma(a.lin_coef, lsum[kk], bfv[kk] * a.amp) : bfv[kk] * a.amp;
             if (kc >= S2_CPB * jb) {
@@ -718,9 +748,9 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     const long long ncb = (a.m + SW_CAND - 1) / SW_CAND;
     const int nrb2 = s2_nrb(a.n);
     a.nrb = nrb2;
-#ifdef S2_TIMING
+#if defined(S2_TIMING) || defined(S2_PROFILE)
     static unsigned long long* dbg2 = nullptr;
-    if (!dbg2) (void)hipMalloc(&dbg2, 16 * sizeof(unsigned long long));
+    if (!dbg2) (void)hipMalloc(&dbg2, 64 * sizeof(unsigned long long));
     a.dbg = dbg2;
 #endif
     auto launch = [&](unsigned grid) {
@@ -747,6 +777,18 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
         }
 #endif
     }
+#ifdef S2_PROFILE
+    if (full > 0) {
+        // cycles per row block of one steady-state candidate block: T(jb) = a + b jb with
+        // b = 16 x (cycles per straight tile), a = the 16 diagonal (generating) tiles + fold
+        unsigned long long h[64];
+        (void)hipMemcpyAsync(h, dbg2, sizeof(h), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "[sweep2 profile] row-block cycles:");
+        for (int jb = 0; jb < nrb2 && jb < 40; ++jb) fprintf(stderr, " %llu", h[jb] - (jb ? h[jb - 1] : h[40]));
+        fprintf(stderr, "\n");
+    }
+#endif
     if (rest > 0) {
         a.blk_begin = full; a.blk_end = ncb; a.split = 1;
         a.ncache = 0;                             // no parking across workgroups

@@ -451,7 +451,10 @@ class GP(object):
             L[:n0, :n0].copy_(prev._L[:n0, :n0])
             row = torch.empty(n1, dtype=torch.float64, device=dev)
             ss = torch.empty(1, dtype=torch.float64, device=dev)
+            info = torch.zeros(1, dtype=torch.int32, device=dev)
             for j in range(n0, n1):
+                # row j: l = L^-1 k(x_j, X[:j]), pivot sqrt(k(x_j,x_j) + diag_add - l.l) -- all enqueued,
+                # no host round trip per row (a failed pivot is reported through `info`)
                 _lib.check(lib.apgp_kernel_cross(self._x_d[j:].data_ptr(), 1, self._x_d.data_ptr(), j,
                                                  ctypes.byref(ks), row.data_ptr(), n1, st), "apgp_kernel_cross")
                 _lib.check(lib.apgp_trsv(L.data_ptr(), j, n1, row.data_ptr(), 0.0, 0, L[j].data_ptr(),
@@ -459,14 +462,15 @@ class GP(object):
                 kxx = ks.amp            # k(x_new, x_new): amplitude + the linear term's sum_d (x_d^2)^P
                 if ks.lin_coef != 0.0:
                     kxx += ks.lin_coef * float(np.sum((self._x[j] * self._x[j]) ** ks.lin_order))
-                d2 = kxx + ks.diag_add - float(ss.item())
-                if not (d2 > 0.0 and np.isfinite(d2)):
-                    self._reset_device_state()
-                    raise LinAlgError("%d-th leading minor of the array is not positive definite" % (j + 1))
-                L[j, j] = float(np.sqrt(d2))
+                _lib.check(lib.apgp_append_diag(L[j, j:].data_ptr(), ss.data_ptr(), kxx + ks.diag_add,
+                                                info.data_ptr(), j + 1, st), "apgp_append_diag")
             out5 = torch.empty(5, dtype=torch.float64, device=dev)
-            _lib.check(lib.apgp_logdet(L.data_ptr(), n1, n1, out5.data_ptr(), st), "apgp_logdet")
-            o = out5.cpu().numpy()
+            _lib.check(lib.apgp_fit_summary(L.data_ptr(), n1, n1, None, info.data_ptr(), out5.data_ptr(), st),
+                       "apgp_fit_summary")
+            o = out5.cpu().numpy()          # the only synchronisation of the extension
+        if int(o[4]) != 0 or not np.isfinite(o[0]):
+            self._reset_device_state()
+            raise LinAlgError("%d-th leading minor of the array is not positive definite" % int(o[4]))
         self._L = L
         self.log_determinant = float(o[0])
         self.cond_estimate = float((o[2] / o[1]) ** 2)
@@ -554,21 +558,32 @@ class GP(object):
 
     # -- K3: z = L^-1 (y - mean), alpha = L^-T z -----------------------------------
     def _solve(self, y, need_alpha):
-        """Ensures z (and alpha) for this y; returns z.z as a float."""
+        """Ensures z (and alpha) for this y; returns z.z as a float.  With the dense
+        W = L^-1 resident (every sweep set-up) and a trusted condition estimate, both are
+        HBM-rate matrix-vector products (``apgp_winv_apply``); otherwise the triangular
+        solves (``apgp_trsv``), which also serve ill-conditioned factors."""
         torch, dev, lib = self._rt()
         y = self._check_dimensions(y)
         n = len(y)
         same = (self._alpha_y is not None and self._alpha_mean == self.mean.value
                 and np.array_equal(self._alpha_y, y))
+        via_w = (self._work is not None and (self.variance_mode or "") != "solve"
+                 and self.cond_estimate is not None and self.cond_estimate <= COND_SOLVE)
+        np64 = (n + 63) // 64 * 64
         with torch.cuda.device(dev):
             st = self._stream(torch)
             if not same or self._z is None:
                 self._y_d = torch.from_numpy(y).to(dev)
                 self._z = torch.empty(n, dtype=torch.float64, device=dev)
                 ztz = torch.empty(1, dtype=torch.float64, device=dev)
-                _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, self._y_d.data_ptr(),
-                                         float(self.mean.value), 0, self._z.data_ptr(),
-                                         ztz.data_ptr(), st), "apgp_trsv(forward)")
+                if via_w:
+                    _lib.check(lib.apgp_winv_apply(self._work.data_ptr(), np64, n, self._y_d.data_ptr(),
+                                                   float(self.mean.value), 0, self._z.data_ptr(),
+                                                   ztz.data_ptr(), None, st), "apgp_winv_apply(forward)")
+                else:
+                    _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, self._y_d.data_ptr(),
+                                             float(self.mean.value), 0, self._z.data_ptr(),
+                                             ztz.data_ptr(), st), "apgp_trsv(forward)")
                 self._ztz_host = float(ztz.item())
                 self._alpha = None
                 self._xs = None
@@ -576,8 +591,14 @@ class GP(object):
                 self._alpha_mean = self.mean.value
             if need_alpha and self._alpha is None:
                 self._alpha = torch.empty(n, dtype=torch.float64, device=dev)
-                _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, self._z.data_ptr(), 0.0, 1,
-                                         self._alpha.data_ptr(), None, st), "apgp_trsv(backward)")
+                if via_w:
+                    wk = torch.empty(int(lib.apgp_winv_apply_work_len(n)), dtype=torch.float64, device=dev)
+                    _lib.check(lib.apgp_winv_apply(self._work.data_ptr(), np64, n, self._z.data_ptr(), 0.0, 1,
+                                                   self._alpha.data_ptr(), None, wk.data_ptr(), st),
+                               "apgp_winv_apply(backward)")
+                else:
+                    _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, self._z.data_ptr(), 0.0, 1,
+                                             self._alpha.data_ptr(), None, st), "apgp_trsv(backward)")
                 self._xs = None
         return self._ztz_host
 
@@ -735,8 +756,13 @@ class GP(object):
         n = len(self._x)
         need_var = kind is not None or "var" in want
         ks = self._kernel_struct()
+        mode = (self.variance_mode or "").lower()
+        use_solve = need_var and ((mode == "solve") or (mode != "inverse" and self.cond_estimate is not None
+                                                        and self.cond_estimate > COND_SOLVE and n <= 4096))
         with torch.cuda.device(dev):
             st = self._stream(torch)
+            if need_var and not use_solve:
+                self._ensure_linv()     # first: with W resident alpha is two matrix-vector products
             self._ensure_xs(y)
             if not need_var and cand_device is None and 0 < len(cand) <= 4096:
                 # latency-bound mean-only call (the sampler's _gpll batches): host buffers
@@ -764,11 +790,6 @@ class GP(object):
                                                  ctypes.byref(ks), float(self.mean.value),
                                                  mu.data_ptr(), st), "apgp_predict_mean")
                 return (mu.cpu().numpy(),)
-            mode = (self.variance_mode or "").lower()
-            use_solve = (mode == "solve") or (mode != "inverse" and self.cond_estimate is not None
-                                              and self.cond_estimate > COND_SOLVE and n <= 4096)
-            if not use_solve:
-                self._ensure_linv()
             mu = torch.empty(m, dtype=torch.float64, device=dev) if "mu" in want else None
             var = torch.empty(m, dtype=torch.float64, device=dev) if "var" in want else None
             u = torch.empty(m, dtype=torch.float64, device=dev) if "u" in want else None

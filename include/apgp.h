@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define APGP_ABI_VERSION 3
+#define APGP_ABI_VERSION 4
 #define APGP_MAX_DIM 16          /* feature dimension D supported by the kernels */
 #define APGP_ROW_BLOCK 512       /* rows per packed L^-1 row block (sweep tile)  */
 #define APGP_K_CHUNK 16          /* contraction depth per packed tile            */
@@ -87,8 +87,10 @@ int64_t apgp_trtri_work_len(int64_t n);
 /* ---- K1: Gram matrix ------------------------------------------------------
  * Replaces george ``kernel.get_value(X)`` + the diagonal update inside
  * ``GP.compute`` (called from gpUtils.py:178,244,254; approx.py:717 and every
- * _nll evaluation, gpUtils.py:74-78).  Writes the full symmetric N x N matrix
- * K (leading dimension ldk >= N).                                            */
+ * _nll evaluation, gpUtils.py:74-78).  Writes the LOWER triangle of the symmetric
+ * N x N matrix K (leading dimension ldk >= N) -- whole 64 x 64 tiles on and below the
+ * diagonal; tiles strictly above it are left untouched: apgp_potrf, the only consumer,
+ * reads the lower triangle only, and half the HBM writes is half the kernel's time.   */
 int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
               double* K, int64_t ldk, void* stream);
 
@@ -153,6 +155,29 @@ int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch,
  * If sumsq != NULL, *sumsq = x.x (device scalar).  x may alias b.  n <= 16384. */
 int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
               int trans, double* x, double* sumsq, void* stream);
+
+/* ---- pivot of an appended factor row -----------------------------------------
+ * Incremental fit when ApproxPosterior.findNextPoint appends a design point
+ * (approx.py:693-717): with l = L^-1 k(x_new, X_old) already in the new row (apgp_kernel_cross
+ * + apgp_trsv, *ss = l.l on the device), writes *ljj = sqrt(kdiag - *ss), kdiag = k(x_new,
+ * x_new) + diag_add.  *info_dev (device int32, caller-initialised to 0) keeps the FIRST
+ * non-positive pivot's 1-based leading-minor order (LAPACK convention; rows are appended in
+ * stream order) and 1.0 is stored so that later rows stay finite.                        */
+int apgp_append_diag(double* ljj, const double* ss, double kdiag, int32_t* info_dev, int64_t order,
+                     void* stream);
+
+/* ---- K3 through the resident explicit inverse -------------------------------
+ * x = W (b - shift) (trans = 0) or x = W^T b (trans = 1, shift must be 0) for the dense
+ * lower-triangular W = L^-1 that apgp_trtri_pack leaves in the first panel of its work
+ * buffer (winv, leading dimension ldw = n rounded up to 64): z and alpha of george's
+ * GP._compute_alpha (behind every GP.predict, utility.py:131,178,224; approx.py:178) as two
+ * HBM-rate matrix-vector products once the sweep's W exists, instead of two triangular
+ * solves.  If sumsq != NULL, *sumsq = x.x (device scalar).  x must not alias b.
+ * work: apgp_winv_apply_work_len(n) doubles (trans = 1 only).  Use apgp_trsv instead when the
+ * condition estimate exceeds ~1e10 (same rule as apgp_acquire vs apgp_acquire_solve).     */
+int64_t apgp_winv_apply_work_len(int64_t n);
+int apgp_winv_apply(const double* winv, int64_t ldw, int64_t n, const double* b, double shift,
+                    int trans, double* x, double* sumsq, double* work, void* stream);
 
 /* ---- L^-1 in the sweep's packed tile layout --------------------------------
  * Computes W = L^-1 (blocked recursive triangular inversion, MFMA-f64 GEMM

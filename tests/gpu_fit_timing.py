@@ -30,7 +30,8 @@ for N, D in ((50, 2), (512, 8), (1152, 8), (4096, 8)):
         for _ in range(R): f()
         sync(); return (time.time() - t0) / R
     t_gram = timeit(lambda: lib.apgp_gram(gp._x_d.data_ptr(), N, ctypes.byref(ks), K.data_ptr(), N, st))
-    t_chol = timeit(lambda: torch.linalg.cholesky_ex(K, upper=True))
+    Ks = torch.tril(K) + torch.tril(K, -1).T          # apgp_gram writes the lower triangle only
+    t_chol = timeit(lambda: torch.linalg.cholesky_ex(Ks, upper=True))
     info = torch.empty(1, dtype=torch.int32, device='cuda'); K2 = K.clone()
     def own():
         K2.copy_(K); lib.apgp_potrf(K2.data_ptr(), N, N, None, 0.0, None, info.data_ptr(), st)
@@ -43,6 +44,15 @@ for N, D in ((50, 2), (512, 8), (1152, 8), (4096, 8)):
     packed = torch.empty(lib.apgp_packed_linv_len(N), dtype=torch.float64, device="cuda")
     t_tri = timeit(lambda: lib.apgp_trtri_pack(gp._L.data_ptr(), N, N, work.data_ptr(), packed.data_ptr(), None, st), R=5)
     t_grad = timeit(lambda: gp.grad_log_likelihood(y), R=3)
+    wk = torch.empty(int(lib.apgp_winv_apply_work_len(N)), dtype=torch.float64, device="cuda")
+    NP = (N + 63) // 64 * 64
+    t_wf = timeit(lambda: lib.apgp_winv_apply(work.data_ptr(), NP, N, yd.data_ptr(), 0.0, 0, z.data_ptr(), s.data_ptr(), None, st))
+    t_wb = timeit(lambda: lib.apgp_winv_apply(work.data_ptr(), NP, N, yd.data_ptr(), 0.0, 1, z.data_ptr(), None, wk.data_ptr(), st))
+    def setup():
+        g2 = agp.GP(kernel=k, fit_mean=True, mean=np.median(y), white_noise=-12, fit_white_noise=False)
+        g2.compute(X); g2._ensure_linv(); g2._ensure_xs(y)
+    t_setup = timeit(setup, R=5)
+    print("N=%5d  winv_apply fwd %.3f ms, bwd %.3f ms | sweep set-up (compute + L^-1 + pack + alpha + xs) %.3f ms" % (N, t_wf*1e3, t_wb*1e3, t_setup*1e3))
     T = torch.rand((64, D), dtype=torch.float64, device="cuda") * 10 - 5
     gp.recompute(); gp._ensure_xs(y)
     mu = torch.empty(64, dtype=torch.float64, device="cuda")

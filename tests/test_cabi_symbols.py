@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_abi_version_and_sizes():
     lib = _lib.load()
-    assert lib.apgp_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.apgp_abi_version() == _lib.ABI_VERSION == 4
     assert lib.apgp_npad(1) == 512 and lib.apgp_npad(512) == 512 and lib.apgp_npad(513) == 1024
     # packed L^-1: row block ib holds (ib+1)*32 tiles of 512 x 16 doubles
     for n, nrb in ((100, 1), (4096, 8), (4097, 9)):
@@ -38,6 +38,7 @@ def test_abi_version_and_sizes():
     assert lib.apgp_packed_train_len(100, 3) == 512 * 6
     assert lib.apgp_trtri_work_len(100) == 2 * 128 * 128
     assert lib.apgp_grad_work_len(64) == 64 * 64 + 18
+    assert lib.apgp_winv_apply_work_len(4096) == 32 * 4096 and lib.apgp_winv_apply_work_len(129) == 2 * 129
     assert ctypes.sizeof(_lib.KernelStruct) == 8 + 16 + 16 * 8 + 8
     assert ctypes.sizeof(_lib.BestStruct) == 16
 
@@ -52,6 +53,7 @@ def test_bad_arguments_are_refused_without_a_gpu():
     assert lib.apgp_logdet(None, 4, 4, None, None) == -1
     assert lib.apgp_trsv(None, 4, 4, None, 0.0, 0, None, None, None) == -1
     assert lib.apgp_trtri_pack(None, 4, 4, None, None, None, None) == -1
+    assert lib.apgp_winv_apply(None, 64, 4, None, 0.0, 0, None, None, None, None) == -1
     assert lib.apgp_pack_train(None, None, 4, ctypes.byref(ks), None, None) == -1
     assert lib.apgp_predict_mean(None, 1, None, 4, ctypes.byref(ks), 0.0, None, None) == -1
     assert lib.apgp_grad_loglik(None, None, None, 64, 4, ctypes.byref(ks), None, None, None) == -1

@@ -328,6 +328,41 @@ def test_oracle_parity_seeded(n, d, m, metric, lib_loaded):
         assert bi == -1
 
 
+@pytest.mark.parametrize("n,d", [(700, 8), (1100, 3), (50, 2), (129, 5)])
+def test_alpha_through_resident_inverse(n, d, lib_loaded):
+    """K3 both ways: z = L^-1 r, alpha = L^-T z by the triangular solves (apgp_trsv) and, once
+    the sweep's dense W = L^-1 is resident, by the two matrix-vector products of
+    apgp_winv_apply -- both against the oracle's cho_solve (george GP._compute_alpha), and
+    z.z (the quadratic form of GP.log_likelihood) against r^T K^-1 r."""
+    go, agp = _mods()
+    X, y = _synthetic(n, d)
+    ko = go.ExpSquaredKernel(np.full(d, float(d)), ndim=d)
+    gpo = go.GP(kernel=ko, fit_mean=True, mean=np.median(y), white_noise=-12, fit_white_noise=False)
+    gpo.compute(X)
+    gp = agp.GP(kernel=agp.ExpSquaredKernel(np.full(d, float(d)), ndim=d), fit_mean=True, mean=np.median(y),
+                white_noise=-12, fit_white_noise=False)
+    gp.compute(X)
+    K = gpo.kernel.get_value(gpo._x)
+    K[np.diag_indices_from(K)] += np.exp(-12.0)
+    tol = max(1e-12, 200 * np.linalg.cond(K) * EPS)
+    want = gpo._compute_alpha(y, False)
+    quad = float((y - np.median(y)) @ want)
+    ztz_t = gp._solve(y, need_alpha=True)                  # nothing resident yet: triangular solves
+    a_t = gp._alpha.cpu().numpy()
+    gp._ensure_linv()
+    gp._z = gp._alpha = gp._alpha_y = None
+    ztz_w = gp._solve(y, need_alpha=True)                  # W resident: matrix-vector products
+    a_w = gp._alpha.cpu().numpy()
+    for a_, q_ in ((a_t, ztz_t), (a_w, ztz_w)):
+        assert np.abs(a_ - want).max() <= tol * np.abs(want).max()
+        assert abs(q_ - quad) <= tol * abs(quad)
+    # the sweep set-up takes the second path and predicts the same mean
+    T = np.random.RandomState(4).uniform(-5, 5, size=(300, d))
+    mu, var = gp.predict(y, T, return_var=True)
+    mo, vo = gpo.predict(y, T, return_var=True)
+    assert np.abs(mu - mo).max() <= tol * np.abs(want).sum() and np.abs(var - vo).max() <= tol
+
+
 @pytest.mark.parametrize("m", [5000, 40000])
 def test_multi_row_block_utilities_mask_nan(m, lib_loaded):
     """N > 512 (several row blocks: parked operands, persistent + split launches) with everything
