@@ -69,7 +69,7 @@ struct SweepArgs {
     int ndim, nrb, kind, has_box, n, ncache, lin_order;
     double mean, amp, zeta, ybest, lin_coef;
     double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
-    unsigned long long* dbg;   // phase cycle counters (-DS2_TIMING developer builds only)
+    unsigned long long* dbg;   // row-block time stamps (-DS2_PROFILE developer builds only)
 };
 
 __device__ __forceinline__ double util_value(int kind, double mu, double var, double zeta,
@@ -166,6 +166,9 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 #ifndef S2_SPREAD
 #define S2_SPREAD 1
 #endif
+#ifndef S2_X_IMGPIECES
+#define S2_X_IMGPIECES 8
+#endif
 #define S2_ROWS 256
 #define S2_TILE (S2_ROWS * SW_KC)        // doubles per tile image (32 KiB)
 #define S2_CPB (S2_ROWS / SW_KC)         // chunks per row-block width (16)
@@ -250,9 +253,6 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         __syncthreads();                          // P0: x chunks staged (feeders)
         __syncthreads();                          // P : tile 0 published
         int slot = 0, bpar = 0;
-#ifdef S2_TIMING
-        unsigned long long s2_wait = 0, s2_nt = 0, s2_t0 = __builtin_amdgcn_s_memtime();
-#endif
         // B operands of the current tile in all four rotations; half 0 = k-steps 0-1, 1 = 2-3
         double brot[4][NKK];
         auto load_b = [&](int buf, int half) {
@@ -306,11 +306,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                         const bool act = !PRED || (pr >= p0 && pr < p1);
                         if (act) mfma_pair(pr, 0);
                         __builtin_amdgcn_sched_barrier(0);
-#ifdef S2_TIMING
-                        if (pr == 4) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); s2_wait += __builtin_amdgcn_s_memtime() - t0_; ++s2_nt; }
-#else
                         if (pr == 4) __syncthreads();          // barrier i: tile i+1 is complete
-#endif
                         if (pr + 1 < NP) {
                             // (first pair: the k-step 2-3 half of this tile's B operands; its
                             // registers were still in use when the 0-1 half was prefetched)
@@ -387,9 +383,6 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             __syncthreads();                      // E1: sums visible to the feeders
             __syncthreads();                      // E2: block result written
         }
-#ifdef S2_TIMING
-        if (a.dbg && blockIdx.x == 0 && t == 0) { a.dbg[0] = s2_wait; a.dbg[1] = s2_nt; a.dbg[2] = __builtin_amdgcn_s_memtime() - s2_t0; }
-#endif
         return;
     }
 
@@ -564,14 +557,22 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     p1 = next_of(p0); p2 = next_of(p1); p3 = next_of(p2);
     const int hw_s = __builtin_amdgcn_readfirstlane(hw);
     typedef __attribute__((address_space(3))) void lds_void;
-    auto dma_tile = [&](int slot, unsigned toffs, int nq) {
+    // image of tile (jb, kc): 8 pieces of 4 KiB = the 8 sub-block pairs (32 rows each), a quarter
+    // of each piece per feeder wavefront.  (Requesting only the non-zero pairs q >= (kc - 16 jb) / 2
+    // of a lower-triangular diagonal tile -- 288 instead of 512 KiB per row block -- changes
+    // nothing, 248.9 vs 247.4 ms: the diagonal tiles do not wait for the image stream.)
+    auto dma_tile = [&](int slot, int jb, int kc) {
         double* dst = Aring + slot * S2_TILE + hw_s * 128;
+        const unsigned toffs = tile_off(jb, kc);
 #pragma unroll
-        for (int q = 0; q < nq; ++q)
+        for (int q = 0; q < S2_X_IMGPIECES; ++q)     // (< 8: elimination build, results wrong)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + q * 512), 16, (unsigned)lane * 16u,
                                                      toffs + (unsigned)(q * 4096) + (unsigned)hw_s * 1024u, 0, 0);
     };
     auto dma_parked = [&](int par, int c) {
+#ifdef S2_X_NOPARKDMA          // elimination build (results wrong): parked operands are not fetched
+        if (c >= 0) return;
+#endif
         double* dst = Bbuf + par * 1024 + hw_s * 256;
         const unsigned soff = (unsigned)c * (unsigned)(SW_BCH * 8) + (unsigned)hw_s * 1024u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)dst, 16, (unsigned)lane * 16u, soff, 0, SW_KAUX);
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     // ---- prologue: tile 0 and its operands, x chunks of tiles 0 and 1, requests for tile 1 ----
     __syncthreads();                              // C : constants visible
     load_candidates(p0.bl);
-    dma_tile(0, tile_off(p0.jb, p0.kc), 8);
+    dma_tile(0, p0.jb, p0.kc);
     x_put(0, x_fetch(p0.kc));
     x_put(1, x_fetch(p1.kc));
     __syncthreads();                              // P0
@@ -595,31 +596,17 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     for (long long b = blk0; b < a.blk_end; b += blk_step) ++nblk_mine;
     const long long ntot = ntile_blk * nblk_mine;
     bool last_m1 = (ntile_blk == 1), last_m2 = false;
-#ifdef S2_TIMING
-    unsigned long long fw_g = 0, fn_g = 0, fw_p = 0, fn_p = 0, fs_a = 0, fs_b = 0;
-#endif
     int slot = 1, par = 1;
     for (long long i = 0;; ++i) {
         // the matrix wavefronts have just passed barrier i-1: if tile i-1 closed a candidate
         // block, finish that block
         if (last_m2) epilogue();
         if (i == ntot) break;
-#ifdef S2_TIMING
-        const unsigned long long ft0 = __builtin_amdgcn_s_memtime();
-        const bool fgen = is_gen(p1);
-#endif
         // ---- produce tile i+1 = p1 ----
-        dma_tile(slot, tile_off(p1.jb, p1.kc), 8);
+        dma_tile(slot, p1.jb, p1.kc);
         if (p1.jb == jb_lo && p1.kc == 0) load_candidates(p1.bl);
-#ifdef S2_TIMING
-        const unsigned long long ft1 = __builtin_amdgcn_s_memtime();
-#endif
         if (is_gen(p1)) produce_b(p1.jb, p1.kc, par, par);
         else dma_parked(par, p1.kc);
-#ifdef S2_TIMING
-        const unsigned long long ft2 = __builtin_amdgcn_s_memtime();
-        if (!fgen) { fs_a += ft1 - ft0; fs_b += ft2 - ft1; }
-#endif
         x_put(par ^ 1, xq);                       // x chunk of tile i+2
         // VMEM requests of this iteration that barrier i need NOT wait for: the park stores of a
         // first-visit tile (read back a row block later) and the x chunk fetched for tile i+3 (a
@@ -633,18 +620,12 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         p0 = p1; p1 = p2; p2 = p3; p3 = next_of(p3);
         slot = slot == 2 ? 0 : slot + 1;
         par ^= 1;
-#ifdef S2_TIMING
-        { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - ft0; if (fgen) { fw_g += d_; ++fn_g; } else { fw_p += d_; ++fn_p; } }
-#endif
         // barrier i
         if (n_pend == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (n_pend == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (n_pend == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-#ifdef S2_TIMING
-    if (a.dbg && blockIdx.x == 0 && ht == 0) { a.dbg[3] = fw_g; a.dbg[4] = fn_g; a.dbg[5] = fw_p; a.dbg[6] = fn_p; a.dbg[7] = fs_a; a.dbg[8] = fs_b; }
-#endif
 }
 
 // The short last round of the persistent grid (and every launch with fewer candidate blocks
@@ -748,7 +729,7 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     const long long ncb = (a.m + SW_CAND - 1) / SW_CAND;
     const int nrb2 = s2_nrb(a.n);
     a.nrb = nrb2;
-#if defined(S2_TIMING) || defined(S2_PROFILE)
+#ifdef S2_PROFILE
     static unsigned long long* dbg2 = nullptr;
     if (!dbg2) (void)hipMalloc(&dbg2, 64 * sizeof(unsigned long long));
     a.dbg = dbg2;
@@ -766,16 +747,6 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     if (full > 0) {
         a.blk_begin = 0; a.blk_end = full; a.split = 0;
         launch((unsigned)(full < SW_GRID ? full : SW_GRID));
-#ifdef S2_TIMING
-        {
-            unsigned long long h[16];
-            (void)hipMemcpyAsync(h, dbg2, sizeof(h), hipMemcpyDeviceToHost, s);
-            (void)hipStreamSynchronize(s);
-            fprintf(stderr, "[sweep2 timing] matrix wave: %llu tiles, barrier wait %.0f cyc/tile, total %.0f cyc/tile | feeder work: gen tiles %.0f cyc (%llu), parked tiles %.0f cyc (%llu)\n",
-                    h[1], (double)h[0] / (h[1] ? h[1] : 1), (double)h[2] / (h[1] ? h[1] : 1), (double)h[3] / (h[4] ? h[4] : 1), h[4],
-                    (double)h[5] / (h[6] ? h[6] : 1), h[6]);
-        }
-#endif
     }
 #ifdef S2_PROFILE
     if (full > 0) {

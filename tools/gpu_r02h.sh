@@ -1,0 +1,14 @@
+#!/bin/bash
+C=approxposterior_amd/csrc
+cp $C/libapgp.so /tmp/ab_keep.so
+for rep in 1 2; do
+  for v in nopark img4 img0 ship; do
+    if [ $v = ship ]; then cp /tmp/ab_keep.so $C/libapgp.so; else cp tools/tmp/lib$v.so $C/libapgp.so; fi
+    echo "$v $(timeout 120 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check 2>&1 | grep -o 'kernel_ms[^,]*')"
+  done
+done | tee gpurun_out/ab_r02h.txt
+for v in prof prof_nopark prof_img4 prof_img0; do
+cp tools/tmp/lib$v.so $C/libapgp.so
+echo "== $v"; timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check 2>&1 | grep -o "sweep2 profile.*\|kernel_ms[^,]*" | tail -2
+done | tee gpurun_out/prof_r02h.txt
+cp /tmp/ab_keep.so $C/libapgp.so
