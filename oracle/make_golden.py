@@ -286,5 +286,78 @@ def main():
     print("done")
 
 
+def d8_truth(ncand=30, dps=50):
+    """Independent truth at D = 8 (VERDICT round 1, item 6): for the ``c3small_d8_n300``
+    fixture (N = 300, D = 8, ExpSquaredKernel without amplitude, white noise e^-12) compute
+    the GP algebra of SURVEY.md Appendix A.2-A.7 in %d-digit mpmath arithmetic -- Gram matrix,
+    Cholesky factor, alpha, log-likelihood, and mu / sigma^2 at the first ``ncand`` candidates --
+    straight from the formulas, sharing NO code with the oracle or the HIP path, and store it
+    in the fixture (``truth_idx``, ``mu_truth``, ``var_truth``, ``ll_truth``).  Both the oracle
+    (tests/test_oracle_pins.py) and the HIP path (tests/test_gpu_parity.py) are asserted
+    against it.""" % 50
+    import mpmath as mp
+    mp.mp.dps = dps
+    path = os.path.join(OUT, "c3small_d8_n300.npz")
+    d = dict(np.load(path))
+    X = [[mp.mpf(float(v)) for v in row] for row in d["theta"]]
+    y = [mp.mpf(float(v)) for v in d["y"]]
+    p = d["p"]
+    assert int(d["fit_amp"]) == 0 and len(p) == 9
+    mean = mp.mpf(float(p[0]))
+    w = [mp.exp(-mp.mpf(float(v))) for v in p[1:]]          # 1 / M_d
+    wn = mp.exp(mp.mpf(float(d["white_noise"])))
+    n, D = len(X), 8
+    half = mp.mpf(1) / 2
+
+    def kfun(a, b):
+        return mp.exp(-half * sum(w[k] * (a[k] - b[k]) ** 2 for k in range(D)))
+    K = mp.matrix(n, n)
+    for i in range(n):
+        for j in range(i + 1):
+            v = kfun(X[i], X[j])
+            K[i, j] = v
+            K[j, i] = v
+        K[i, i] += wn
+    L = mp.cholesky(K)
+
+    def fwd(b):                                             # L x = b
+        x = [mp.mpf(0)] * n
+        for i in range(n):
+            x[i] = (b[i] - sum(L[i, k] * x[k] for k in range(i))) / L[i, i]
+        return x
+
+    def bwd(b):                                             # L^T x = b
+        x = [mp.mpf(0)] * n
+        for i in reversed(range(n)):
+            x[i] = (b[i] - sum(L[k, i] * x[k] for k in range(i + 1, n))) / L[i, i]
+        return x
+    r = [y[i] - mean for i in range(n)]
+    z = fwd(r)
+    alpha = bwd(z)
+    logdet = 2 * sum(mp.log(L[i, i]) for i in range(n))
+    ll = -half * sum(v * v for v in z) - half * logdet - mp.mpf(n) / 2 * mp.log(2 * mp.pi)
+    idx = list(range(ncand))
+    mu_t, var_t = [], []
+    for c in d["cands"][:ncand]:
+        cc = [mp.mpf(float(v)) for v in c]
+        ks = [kfun(cc, X[i]) for i in range(n)]
+        v = fwd(ks)
+        mu_t.append(float(sum(ks[i] * alpha[i] for i in range(n)) + mean))
+        var_t.append(float(1 - sum(t * t for t in v)))
+    d["truth_idx"] = np.array(idx)
+    d["mu_truth"] = np.array(mu_t)
+    d["var_truth"] = np.array(var_t)
+    d["ll_truth"] = np.array(float(ll))
+    d["alpha_truth"] = np.array([float(a) for a in alpha])
+    np.savez_compressed(path, **d)
+    print("D=8 truth: oracle |mu - truth| max %.3e, |var - truth| max %.3e, |ll - truth| %.3e" % (
+        np.abs(d["mu"][:ncand] - d["mu_truth"]).max(), np.abs(d["var"][:ncand] - d["var_truth"]).max(),
+        abs(float(d["ll"]) - float(ll))))
+
+
 if __name__ == "__main__":
-    main()
+    if "--d8-truth" in sys.argv:
+        d8_truth()          # (augments the committed fixture; needs no reference import)
+    else:
+        main()
+        d8_truth()

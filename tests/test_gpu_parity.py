@@ -283,6 +283,30 @@ def test_gpll_guards(golden_dir, lib_loaded):
                     assert np.isclose(a_, b_, rtol=1e-8, atol=1e-8)
 
 
+def test_hip_against_mpmath_truth_d8(golden_dir, lib_loaded):
+    """HIP path vs the 50-digit mpmath truth of the D = 8, N = 300 fixture (mu, sigma^2,
+    log-likelihood, alpha; oracle/make_golden.py d8_truth): a comparison at D > 2 that does
+    not go through the oracle.  Bound: the fp64 conditioning limit 200 cond eps."""
+    go, agp = _mods()
+    g = np.load(os.path.join(golden_dir, "c3small_d8_n300.npz"))
+    gp = build(agp, g)
+    idx = g["truth_idx"]
+    tol = 200 * float(g["cond"]) * EPS
+    asum = np.abs(g["alpha_truth"]).sum()
+    mu, var = gp.predict(g["y"], g["cands"][idx], return_var=True)
+    assert np.abs(mu - g["mu_truth"]).max() <= tol * asum
+    assert np.abs(var - g["var_truth"]).max() <= tol
+    assert np.abs(gp.predict(g["y"], g["cands"][idx], return_cov=False) - g["mu_truth"]).max() <= tol * asum
+    assert abs(gp.log_likelihood(g["y"]) - float(g["ll_truth"])) <= tol * abs(float(g["ll_truth"]))
+    gp._solve(g["y"], need_alpha=True)
+    assert np.abs(gp._alpha.cpu().numpy() - g["alpha_truth"]).max() <= tol * np.abs(g["alpha_truth"]).max()
+    # the utilities at the truth's (mu, sigma^2): AGP through the HIP epilogue
+    bi, bu, u, _, _ = gp.acquire(g["y"], g["cands"][idx], "agp", return_all=True)
+    ut = -(g["mu_truth"] + 0.5 * np.log(2 * np.pi * np.e * g["var_truth"]))
+    assert np.abs(u - ut).max() <= tol * asum + 0.5 * tol / g["var_truth"].min() + 1e-13 * np.abs(ut).max()
+    assert bi == int(np.argmin(ut))
+
+
 def _synthetic(n, d, seed=0):
     from scipy.optimize import rosen
     rs = np.random.RandomState(seed)

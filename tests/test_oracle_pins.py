@@ -202,3 +202,25 @@ def test_oracle_linear_kernel_sum_gradient_finite_difference(order, fit_amp):
     Kxs = gp.kernel.get_value(t, X)
     Kinv = np.linalg.inv(gp.kernel.get_value(X) + np.exp(-6.0) * np.eye(40))
     assert np.allclose(var, np.diag(gp.kernel.get_value(t)) - np.einsum("ij,jk,ik->i", Kxs, Kinv, Kxs), atol=1e-9)
+
+
+def test_oracle_against_mpmath_truth_d8(golden_dir):
+    """Independent truth beyond D = 2: the c3small_d8_n300 fixture
+    carries mu / sigma^2 / log-likelihood / alpha computed in 50-digit mpmath arithmetic straight
+    from the GP formulas (oracle/make_golden.py d8_truth -- no code shared with the oracle).
+    The oracle must agree to the fp64 conditioning bound 200 cond eps."""
+    g = np.load(os.path.join(golden_dir, "c3small_d8_n300.npz"))
+    assert "mu_truth" in g.files, "run python -B oracle/make_golden.py --d8-truth"
+    D = g["theta"].shape[1]
+    p = g["p"]
+    gp = go.GP(kernel=go.ExpSquaredKernel(np.exp(p[1:]), ndim=D), fit_mean=True, mean=float(p[0]),
+               white_noise=float(g["white_noise"]), fit_white_noise=False)
+    gp.compute(g["theta"])
+    idx = g["truth_idx"]
+    mu, var = gp.predict(g["y"], g["cands"][idx], return_var=True)
+    tol = 200 * float(g["cond"]) * 2.2e-16
+    asum = np.abs(g["alpha_truth"]).sum()
+    assert np.abs(mu - g["mu_truth"]).max() <= tol * asum
+    assert np.abs(var - g["var_truth"]).max() <= tol
+    assert abs(gp.log_likelihood(g["y"]) - float(g["ll_truth"])) <= tol * abs(float(g["ll_truth"]))
+    assert np.abs(gp._compute_alpha(g["y"], False) - g["alpha_truth"]).max() <= tol * np.abs(g["alpha_truth"]).max()
