@@ -4,10 +4,10 @@
 // gpUtils.py:178; approx.py:717).  rocSOLVER's dpotrf reaches ~2 TFLOP/s at
 // N = 4096 on MI355X (11.8 ms, dozens of tiny kernels); this version is two
 // launches per 64-column block step:
-//   panel : every workgroup (one wavefront) re-factorises the 64x64 diagonal
+//   panel : every workgroup (two wavefronts) re-factorises the 64x64 diagonal
 //           block in registers (redundantly -- it is the critical path either
-//           way, and it saves a launch + a grid-wide dependency), then solves
-//           its 64 rows of the panel against it (row-per-lane substitution);
+//           way, and it saves a launch + a grid-wide dependency) while its second
+//           wavefront solves 64 rows of the panel against it (row-per-lane substitution);
 //   update: trailing lower-triangle tiles A_ik -= L_ij L_kj^T (64x64x64 MFMA
 //           f64 tiles; HBM-bound: each tile is read-modify-written once).
 // info follows LAPACK: 0 = OK, k > 0 = leading minor of order k not positive
@@ -47,23 +47,28 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
     a.info += blockIdx.y;
 }
 
-// Panel step, one wavefront per workgroup: workgroup b owns the 64 panel rows
-// [j0 + 64 + 64 b, +64) and re-factorises the 64x64 diagonal block itself (it is the
-// critical path either way; redundancy saves a launch and a grid-wide dependency).
+// Panel step of block column j, two wavefronts per workgroup; workgroup b owns the 64 panel rows
+// [j0 + 64 + 64 b, +64) and re-factorises the 64x64 diagonal block itself (it is the critical path
+// either way; redundancy saves a launch and a grid-wide dependency).
 //
-// The diagonal block is factorised in REGISTERS: lane i holds row i (64 doubles),
-// right-looking, fully unrolled.  Per pivot k: the pivot is a v_readlane, its
-// reciprocal square root a v_rsq_f64 + two Newton steps (no IEEE sqrt + divide on the
-// critical path), the scaled column goes through a 512-byte LDS line and comes back as
-// broadcast ds_read_b128 for the rank-1 update.  One wavefront, in-order LDS: no barrier
-// anywhere.  ~1650 cycles per pivot with the earlier 256-thread LDS version (three
-// barriers + IEEE sqrt/div per pivot), ~250 here.
-// The panel rows are then solved one row per lane, x L_jj^T = a, against broadcast
-// reads of L_jj (four partial sums per dot product).
-// scheduling fence for the straight-line panel code: the asm memory clobber stops the
-// SelectionDAG from hoisting the (address-independent) LDS reads of later steps, the
-// sched_barrier stops the machine scheduler -- without both, hundreds of reads are in
-// flight at once and the two 64-double register rows spill
+// Wavefront 0 factorises the diagonal block in REGISTERS: lane i holds row i (64 doubles),
+// right-looking, fully unrolled.  Per pivot k: the pivot is a v_readlane, its reciprocal square
+// root a v_rsq_f64 + two Newton steps (no IEEE sqrt + divide on the critical path), the scaled
+// column goes through a 512-byte LDS line and comes back as broadcast ds_read_b128 for the
+// rank-1 update.  One wavefront, in-order LDS: no barrier anywhere.  It publishes the factor as it
+// goes -- after pivot k column k of L_jj (Ls[.][k]), 1/L_kk (invd[k]) and the progress counter.
+// Wavefront 1 solves the workgroup's 64 panel rows, x L_jj^T = a, one row per lane against
+// broadcast reads of L_jj (four partial sums per dot product, the L values requested one stage
+// ahead), CONCURRENTLY and two pivots behind: row k of the solve needs row k of L_jj, final after
+// pivot k-1, and the prefetch of the next stage needs invd[k+1].  The panel solve (21.5 k cycles)
+// thus hides behind the factorisation (46 k) instead of following it (round 1: one wavefront did
+// both in turn, 89 k cycles per step; now ~75 k: 4.72 -> 4.32 ms at N = 4096, 0.98 -> 0.86 ms at
+// N = 1152).  Same arithmetic in the same order per element as the one-wavefront form.
+//
+// Scheduling fences for the straight-line code: the asm memory clobber stops the SelectionDAG
+// from hoisting the (address-independent) LDS reads of later steps, the sched_barrier stops the
+// machine scheduler -- without both, hundreds of reads are in flight at once and the 64-double
+// register rows spill.
 #ifdef APGP_PANEL_TIMING
 __device__ unsigned long long apgp_panel_stamps[8];
 #define PANEL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) apgp_panel_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -85,149 +90,128 @@ __host__ __device__ constexpr int trsm_gcount(int k, int g) {
     return c;
 }
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-__global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
+__device__ __forceinline__ int lds_load_volatile(const int* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const int*)p) : "memory");
+    return v;
+}
+__global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
     potrf_select(a);
     __shared__ __attribute__((aligned(16))) double col[2][PB];
-    __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];   // +2: row-per-lane writes spread over the banks
+    __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];
     __shared__ __attribute__((aligned(16))) double invd[PB];
     __shared__ double zblk[PB];
-    __shared__ double Xs[PB][PB + 1];
-    const int lane = threadIdx.x;
+    __shared__ int prog;                 // pivots published so far; PB + 1 once zblk is published too
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long j0 = a.j0;
     const int bs = (int)((a.n - j0) < PB ? (a.n - j0) : PB);
     const long long row = j0 + PB + (long long)blockIdx.x * PB + lane;
     const bool has_row = row < a.n;
+    if (threadIdx.x == 0) prog = 0;
+    __syncthreads();
 
-    PANEL_STAMP(0);
-    // row `lane` of the diagonal block (identity past the matrix edge / above the diagonal);
-    // one base address + immediate offsets (a per-element clamp costs a 64-bit address each)
-    double ar[PB];
-    if (bs == PB) {
-        const double* src = a.A + (j0 + lane) * a.lda + j0;
+    if (wv == 0) {
+        // ---------------- wavefront 0: the diagonal block ----------------
+        double ar[PB];
+        if (bs == PB) {
+            const double* src = a.A + (j0 + lane) * a.lda + j0;
 #pragma unroll
-        for (int k = 0; k < PB; ++k) ar[k] = src[k];
+            for (int k = 0; k < PB; ++k) ar[k] = src[k];
 #pragma unroll
-        for (int k = 0; k < PB; ++k) ar[k] = k <= lane ? ar[k] : 0.0;
-    } else {
-        const double* src = a.A + (j0 + (lane < bs ? lane : 0)) * a.lda + j0;
+            for (int k = 0; k < PB; ++k) ar[k] = k <= lane ? ar[k] : 0.0;
+        } else {
+            const double* src = a.A + (j0 + (lane < bs ? lane : 0)) * a.lda + j0;
 #pragma unroll
-        for (int k = 0; k < PB; ++k) {
-            double v = 0.0;
-            if (lane < bs && k <= lane) v = src[k];
-            ar[k] = (lane < bs && k <= lane) ? v : (k == lane ? 1.0 : 0.0);
+            for (int k = 0; k < PB; ++k) {
+                double v = 0.0;
+                if (lane < bs && k <= lane) v = src[k];
+                ar[k] = (lane < bs && k <= lane) ? v : (k == lane ? 1.0 : 0.0);
+            }
         }
-    }
-    // this lane's panel row rides along: requested now, parked in LDS while the
-    // factorisation has the VGPRs (two 64-double register rows do not fit the 256
-    // VALU-addressable registers); panel rows exist only below a full 64-column block
-    {
-        const double* src = a.A + (has_row ? row : j0) * a.lda + j0;
-        double xin[PB];
-#pragma unroll
-        for (int k = 0; k < PB; ++k) xin[k] = bs == PB ? src[k] : 0.0;
-#pragma unroll
-        for (int k = 0; k < PB; ++k) Xs[lane][k] = xin[k];
-    }
-    PANEL_FENCE();
-
-    PANEL_STAMP(1);
-    static_for<PB>([&](auto kc_) {
-        constexpr int k = decltype(kc_)::value;
-        const double piv = bcast_lane(ar[k], k);
-        const bool bad = !(piv > 0.0) || !(piv < INFINITY);
-        if (bad && blockIdx.x == 0 && lane == 0) atomicMin((unsigned int*)a.info, (unsigned int)(j0 + k + 1));
-        const double pv = bad ? 1.0 : piv;
-        // 1/sqrt(pv): hardware estimate + two Newton steps, then one residual correction of
-        // the root itself (d = sqrt(pv) to within an ulp; LAPACK's own roots differ by as much
-        // between libraries)
-        double r = __builtin_amdgcn_rsq(pv);
-        r = r * fma(-0.5 * pv * r, r, 1.5);
-        r = r * fma(-0.5 * pv * r, r, 1.5);
-        double d = pv * r;
-        d = fma(0.5 * r, fma(-d, d, pv), d);
-        const double inv = r;
-        if (lane == k) invd[k] = inv;
-        ar[k] = lane == k ? d : ar[k] * inv;     // lanes > k: L_ik (lanes < k: unused upper part)
-        double* cb = col[k & 1];
-        cb[lane] = ar[k];
-        // rank-1 update of the trailing columns: ar[j] -= L_ik * L_jk  (L_jk broadcast from LDS)
-        const double lik = ar[k];
-        if (((k + 1) & 1) && k + 1 < PB) {       // odd start: one 8-byte read, then aligned pairs
-            const double ljk = cb[k + 1];
-            ar[k + 1] = fma(-lik, ljk, ar[k + 1]);
-            asm volatile("" : "+v"(ar[k + 1]));
-        }
-        // (groups of 16 columns, fenced: hipcc would otherwise request the whole column --
-        // and the columns of later pivots -- at once and spill the register rows)
-#pragma unroll
-        for (int j0g = (k + 2) & ~1; j0g + 1 < PB; j0g += 16) {
-            f64x2 l2[8];
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-                if (j0g + 2 * g + 1 < PB) l2[g] = *(const f64x2*)(cb + j0g + 2 * g);
-            PANEL_FENCE();
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-                if (j0g + 2 * g + 1 < PB) {
-                    ar[j0g + 2 * g] = fma(-lik, l2[g].x, ar[j0g + 2 * g]);
-                    ar[j0g + 2 * g + 1] = fma(-lik, l2[g].y, ar[j0g + 2 * g + 1]);
-                    // pin the update here: left alone, hipcc sinks every column's updates
-                    // down to that column's own pivot (a left-looking order that keeps all
-                    // 2016 broadcast values alive -- in scratch)
-                    asm volatile("" : "+v"(ar[j0g + 2 * g]), "+v"(ar[j0g + 2 * g + 1]));
-                }
-            PANEL_FENCE();
-        }
-    });
-    PANEL_STAMP(2);
-    // L_jj rows to LDS for the broadcast reads below (zeros above the diagonal)
-#pragma unroll
-    for (int k = 0; k < PB; k += 2) {
-        f64x2 v;
-        v.x = k <= lane ? ar[k] : 0.0;
-        v.y = k + 1 <= lane ? ar[k + 1] : 0.0;
-        *(f64x2*)(&Ls[lane][k]) = v;
-    }
-    if (blockIdx.x == 0 && lane < bs) {
-        double* dst = a.A + (j0 + lane) * a.lda + j0;
-#pragma unroll
-        for (int k = 0; k < PB; ++k)
-            if (k <= lane) dst[k] = ar[k];
-    }
-    // fused forward solve z = L^-1 (rhs): the 64-block of the right-hand side against the
-    // fresh diagonal factor (shuffle forward substitution), then each panel row subtracts
-    // its share below.
-    if (a.rhs) {
-        double ri = (lane < bs) ? a.rhs[j0 + lane] : 0.0;
+        PANEL_FENCE();
         static_for<PB>([&](auto kc_) {
             constexpr int k = decltype(kc_)::value;
-            const double zk = bcast_lane(ri, k) * invd[k];
-            ri = lane == k ? zk : (lane > k ? fma(-ar[k], zk, ri) : ri);
-        });
-        zblk[lane] = ri;
-        if (blockIdx.x == 0 && lane < bs) a.rhs[j0 + lane] = ri;
-    }
-    PANEL_STAMP(3);
-    // rows of the panel below the diagonal block: x L_jj^T = a  (row-wise forward substitution)
-    PANEL_FENCE();
-    double x[PB];
+            const double piv = bcast_lane(ar[k], k);
+            const bool bad = !(piv > 0.0) || !(piv < INFINITY);
+            if (bad && blockIdx.x == 0 && lane == 0) atomicMin((unsigned int*)a.info, (unsigned int)(j0 + k + 1));
+            const double pv = bad ? 1.0 : piv;
+            double r = __builtin_amdgcn_rsq(pv);
+            r = r * fma(-0.5 * pv * r, r, 1.5);
+            r = r * fma(-0.5 * pv * r, r, 1.5);
+            double d = pv * r;
+            d = fma(0.5 * r, fma(-d, d, pv), d);
+            const double inv = r;
+            if (lane == k) invd[k] = inv;
+            ar[k] = lane == k ? d : ar[k] * inv;
+            double* cb = col[k & 1];
+            cb[lane] = ar[k];
+            Ls[lane][k] = k <= lane ? ar[k] : 0.0;      // column k of L_jj for the panel solve
+            if (lane == 0) *(volatile int*)&prog = k + 1;   // (same wavefront: LDS stores stay in order)
+            const double lik = ar[k];
+            if (((k + 1) & 1) && k + 1 < PB) {
+                const double ljk = cb[k + 1];
+                ar[k + 1] = fma(-lik, ljk, ar[k + 1]);
+                asm volatile("" : "+v"(ar[k + 1]));
+            }
 #pragma unroll
-    for (int k = 0; k < PB; ++k) x[k] = Xs[lane][k];
+            for (int j0g = (k + 2) & ~1; j0g + 1 < PB; j0g += 16) {
+                f64x2 l2[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    if (j0g + 2 * g + 1 < PB) l2[g] = *(const f64x2*)(cb + j0g + 2 * g);
+                PANEL_FENCE();
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    if (j0g + 2 * g + 1 < PB) {
+                        ar[j0g + 2 * g] = fma(-lik, l2[g].x, ar[j0g + 2 * g]);
+                        ar[j0g + 2 * g + 1] = fma(-lik, l2[g].y, ar[j0g + 2 * g + 1]);
+                        asm volatile("" : "+v"(ar[j0g + 2 * g]), "+v"(ar[j0g + 2 * g + 1]));
+                    }
+                PANEL_FENCE();
+            }
+        });
+        if (blockIdx.x == 0 && lane < bs) {
+            double* dst = a.A + (j0 + lane) * a.lda + j0;
+#pragma unroll
+            for (int k = 0; k < PB; ++k)
+                if (k <= lane) dst[k] = ar[k];
+        }
+        if (a.rhs) {
+            double ri = (lane < bs) ? a.rhs[j0 + lane] : 0.0;
+            static_for<PB>([&](auto kc_) {
+                constexpr int k = decltype(kc_)::value;
+                const double zk = bcast_lane(ri, k) * invd[k];
+                ri = lane == k ? zk : (lane > k ? fma(-ar[k], zk, ri) : ri);
+            });
+            zblk[lane] = ri;
+            if (blockIdx.x == 0 && lane < bs) a.rhs[j0 + lane] = ri;
+        }
+        if (lane == 0) *(volatile int*)&prog = PB + 1;
+        return;
+    }
+
+    // ---------------- wavefront 1: the 64 panel rows of this workgroup ----------------
+    double x[PB];
+    {
+        const double* src = a.A + (has_row ? row : j0) * a.lda + j0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) x[k] = (bs == PB && has_row) ? src[k] : 0.0;
+    }
     PANEL_FENCE();
-    // x[k] = (a[k] - sum_{m<k} x[m] L[k][m]) / L[k][k], k ascending.  The L values are
-    // broadcast LDS reads; they are requested ONE STAGE AHEAD of their use (a stage = 16
-    // columns of row k, or the row's last <= 3 columns + 1/L[k][k]) so that no LDS latency
-    // sits between the dependent dot products.
+    auto wait_prog = [&](int need) {
+        while (lds_load_volatile(&prog) < need) __builtin_amdgcn_s_sleep(1);
+        PANEL_FENCE();
+    };
     f64x2 lq[2][8], tq[2][2];
     double ivq[2];
-    auto load_wide = [&](auto kt, auto gt) {          // columns [16 g, 16 g + 16) of row k
+    auto load_wide = [&](auto kt, auto gt) {
         constexpr int k = decltype(kt)::value, g = decltype(gt)::value;
         constexpr int buf = trsm_gcount(k, g) & 1;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (16 * g + 2 * i + 1 < (k & ~3)) lq[buf][i] = *(const f64x2*)(&Ls[k][16 * g + 2 * i]);
     };
-    auto load_tail = [&](auto kt) {                   // columns [k & ~3, +4) of row k and 1/L[k][k]
+    auto load_tail = [&](auto kt) {
         constexpr int k = decltype(kt)::value;
         tq[k & 1][0] = *(const f64x2*)(&Ls[k][k & ~3]);
         tq[k & 1][1] = *(const f64x2*)(&Ls[k][(k & ~3) + 2]);
@@ -240,10 +224,12 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
             else load_tail(kt);
         }
     };
+    wait_prog(1);                          // row 0 of L_jj and invd[0]
     load_first_of(std::integral_constant<int, 0>{});
     static_for<PB>([&](auto kc_) {
         constexpr int k = decltype(kc_)::value;
-        // four partial sums: the dependent-FMA chain is the cost here
+        // rows k and (prefetch) k+1 of L_jj with their reciprocals: pivots 0 .. k+1 published
+        wait_prog(k + 2 < PB ? k + 2 : PB);
         double s0 = x[k], s1 = 0.0, s2 = 0.0, s3 = 0.0;
         static_for<4>([&](auto gc_) {
             constexpr int g = decltype(gc_)::value;
@@ -261,7 +247,7 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
                         s2 = fma(-x[m + 2], lq[buf][i + 1].x, s2);
                         s3 = fma(-x[m + 3], lq[buf][i + 1].y, s3);
                     }
-                asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));   // pin (see above)
+                asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
                 PANEL_FENCE();
             }
         });
@@ -274,16 +260,14 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
         }
         x[k] = ((s0 + s1) + (s2 + s3)) * ivq[k & 1];
         asm volatile("" : "+v"(x[k]));
-        // (the fences also keep hipcc from hoisting the address-independent LDS reads of later
-        // k's up here: hundreds of them in flight spill the 64-double register row)
         PANEL_FENCE();
     });
-    PANEL_STAMP(4);
     if (has_row) {
         double* ap = a.A + row * a.lda + j0;
 #pragma unroll
         for (int k = 0; k < PB; ++k) ap[k] = x[k];
         if (a.rhs) {
+            wait_prog(PB + 1);                 // zblk published
             double d0 = 0.0, d1 = 0.0;
 #pragma unroll
             for (int k = 0; k < PB; k += 2) {
@@ -293,7 +277,6 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(PotrfArgs a) {
             a.rhs[row] -= d0 + d1;
         }
     }
-    PANEL_STAMP(5);
 }
 
 // trailing update: tile (bi, bk), bi >= bk, of the blocks below/right of column block j:
@@ -380,7 +363,7 @@ static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t b
         a.j0 = jb * PB;
         const long long below = n - (a.j0 + PB);
         const unsigned pg = below > 0 ? (unsigned)((below + PB - 1) / PB) : 1u;
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg, (unsigned)batch), dim3(PB), 0, s, a);
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg, (unsigned)batch), dim3(2 * PB), 0, s, a);
         if (below > 0) {
             const long long tb = (below + PB - 1) / PB;
             hipLaunchKernelGGL(potrf_update_kernel, dim3((unsigned)(tb * (tb + 1) / 2), (unsigned)batch), dim3(256), 0, s, a);
