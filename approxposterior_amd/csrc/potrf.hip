@@ -62,7 +62,7 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
 // ahead), CONCURRENTLY and two pivots behind: row k of the solve needs row k of L_jj, final after
 // pivot k-1, and the prefetch of the next stage needs invd[k+1].  The panel solve (21.5 k cycles)
 // thus hides behind the factorisation (46 k) instead of following it (round 1: one wavefront did
-// both in turn, 89 k cycles per step; now ~75 k: 4.72 -> 4.32 ms at N = 4096, 0.98 -> 0.86 ms at
+// both in turn, 89 k cycles per step; now ~62 k: 4.72 -> 4.05 ms at N = 4096, 0.98 -> 0.78 ms at
 // N = 1152).  Same arithmetic in the same order per element as the one-wavefront form.
 //
 // Scheduling fences for the straight-line code: the asm memory clobber stops the SelectionDAG
@@ -71,7 +71,7 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
 // register rows spill.
 #ifdef APGP_PANEL_TIMING
 __device__ unsigned long long apgp_panel_stamps[8];
-#define PANEL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) apgp_panel_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PANEL_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && a.j0 == 2048) apgp_panel_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PANEL_STAMP(i) do { } while (0)
 #endif
@@ -90,6 +90,11 @@ __host__ __device__ constexpr int trsm_gcount(int k, int g) {
     return c;
 }
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// (a C++ volatile store through a generic pointer becomes a FLAT system-scope store plus
+// s_waitcnt vmcnt(0) -- hundreds of cycles per pivot on the critical path; this is the LDS store)
+__device__ __forceinline__ void lds_store_volatile(int* p, int v) {
+    asm volatile("ds_write_b32 %0, %1" : : "v"((unsigned)(size_t)(__attribute__((address_space(3))) int*)p), "v"(v) : "memory");
+}
 __device__ __forceinline__ int lds_load_volatile(const int* p) {
     int v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const int*)p) : "memory");
@@ -112,13 +117,28 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
 
     if (wv == 0) {
         // ---------------- wavefront 0: the diagonal block ----------------
+        PANEL_STAMP(0);
         double ar[PB];
         if (bs == PB) {
-            const double* src = a.A + (j0 + lane) * a.lda + j0;
+            // coalesced: lane = column (one 512-byte row of the block per load), transposed to
+            // lane = row through Ls (free until the first pivot is published).  A row-per-lane load
+            // touches 64 cache lines per instruction: ~10 k cycles at the head of every step, ~6 k so.
+            const double* src = a.A + j0 * a.lda + j0 + lane;
 #pragma unroll
-            for (int k = 0; k < PB; ++k) ar[k] = src[k];
+            for (int r0 = 0; r0 < PB; r0 += 16) {
+                double t[16];
 #pragma unroll
-            for (int k = 0; k < PB; ++k) ar[k] = k <= lane ? ar[k] : 0.0;
+                for (int r = 0; r < 16; ++r) t[r] = src[(long long)(r0 + r) * a.lda];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Ls[r0 + r][lane] = t[r];
+            }
+            PANEL_FENCE();
+#pragma unroll
+            for (int k = 0; k < PB; k += 2) {
+                const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
+                ar[k] = k <= lane ? v.x : 0.0;
+                ar[k + 1] = k + 1 <= lane ? v.y : 0.0;
+            }
         } else {
             const double* src = a.A + (j0 + (lane < bs ? lane : 0)) * a.lda + j0;
 #pragma unroll
@@ -129,6 +149,7 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
             }
         }
         PANEL_FENCE();
+        PANEL_STAMP(1);
         static_for<PB>([&](auto kc_) {
             constexpr int k = decltype(kc_)::value;
             const double piv = bcast_lane(ar[k], k);
@@ -141,27 +162,31 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
             double d = pv * r;
             d = fma(0.5 * r, fma(-d, d, pv), d);
             const double inv = r;
-            if (lane == k) invd[k] = inv;
+            invd[k] = inv;                           // (uniform value, every lane stores it: no divergent branch)
             ar[k] = lane == k ? d : ar[k] * inv;
             double* cb = col[k & 1];
             cb[lane] = ar[k];
             Ls[lane][k] = k <= lane ? ar[k] : 0.0;      // column k of L_jj for the panel solve
-            if (lane == 0) *(volatile int*)&prog = k + 1;   // (same wavefront: LDS stores stay in order)
+            lds_store_volatile(&prog, k + 1);           // (every lane, same word; same wavefront: LDS stores stay in order)
             const double lik = ar[k];
             if (((k + 1) & 1) && k + 1 < PB) {
                 const double ljk = cb[k + 1];
                 ar[k + 1] = fma(-lik, ljk, ar[k + 1]);
                 asm volatile("" : "+v"(ar[k + 1]));
             }
+            // (one group per pivot: this wavefront has a SIMD's whole register file behind it -- the
+            // workgroup's two wavefronts sit on different SIMDs --, so the column's broadcast values
+            // are all requested at once, up to 62 registers; the fences still keep hipcc from
+            // requesting the columns of LATER pivots up here)
 #pragma unroll
-            for (int j0g = (k + 2) & ~1; j0g + 1 < PB; j0g += 16) {
-                f64x2 l2[8];
+            for (int j0g = (k + 2) & ~1; j0g + 1 < PB; j0g += 64) {
+                f64x2 l2[32];
 #pragma unroll
-                for (int g = 0; g < 8; ++g)
+                for (int g = 0; g < 32; ++g)
                     if (j0g + 2 * g + 1 < PB) l2[g] = *(const f64x2*)(cb + j0g + 2 * g);
                 PANEL_FENCE();
 #pragma unroll
-                for (int g = 0; g < 8; ++g)
+                for (int g = 0; g < 32; ++g)
                     if (j0g + 2 * g + 1 < PB) {
                         ar[j0g + 2 * g] = fma(-lik, l2[g].x, ar[j0g + 2 * g]);
                         ar[j0g + 2 * g + 1] = fma(-lik, l2[g].y, ar[j0g + 2 * g + 1]);
@@ -170,6 +195,7 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
                 PANEL_FENCE();
             }
         });
+        PANEL_STAMP(2);
         if (blockIdx.x == 0 && lane < bs) {
             double* dst = a.A + (j0 + lane) * a.lda + j0;
 #pragma unroll
@@ -186,7 +212,8 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
             zblk[lane] = ri;
             if (blockIdx.x == 0 && lane < bs) a.rhs[j0 + lane] = ri;
         }
-        if (lane == 0) *(volatile int*)&prog = PB + 1;
+        lds_store_volatile(&prog, PB + 1);
+        PANEL_STAMP(3);
         return;
     }
 
@@ -262,6 +289,7 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
         asm volatile("" : "+v"(x[k]));
         PANEL_FENCE();
     });
+    PANEL_STAMP(4);
     if (has_row) {
         double* ap = a.A + row * a.lda + j0;
 #pragma unroll
@@ -277,6 +305,7 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
             a.rhs[row] -= d0 + d1;
         }
     }
+    PANEL_STAMP(5);
 }
 
 // trailing update: tile (bi, bk), bi >= bk, of the blocks below/right of column block j:

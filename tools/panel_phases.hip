@@ -17,8 +17,9 @@ int main() {
         (void)hipDeviceSynchronize();
         unsigned long long s[8];
         (void)hipMemcpyFromSymbol(s, HIP_SYMBOL(apgp_panel_stamps), sizeof(s));
-        printf("rc %d | last panel step cycles: load+park %llu potf2 %llu Ls+writeback+zsolve %llu xload %llu trsm %llu store %llu\n", rc,
-               s[1] - s[0], s[2] - s[1], s[3] - s[2], 0ull, s[4] - s[3], s[5] - s[4]);
+        printf("rc %d | panel step at column 2048, workgroup 0, cycles after the factorising wavefront's start: block loaded %llu | potf2 done %llu | "
+               "write-back + z-solve done %llu | (solving wavefront) panel solve done %llu | rows stored + rhs updated %llu\n", rc,
+               s[1] - s[0], s[2] - s[0], s[3] - s[0], s[4] - s[0], s[5] - s[0]);
     }
     return 0;
 }
