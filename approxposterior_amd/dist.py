@@ -61,15 +61,17 @@ def sharded_acquire(local_acquire, idx_offset, group=None, device=None):
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) \
             if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    # one 16-byte record per rank: utility as f64 plus the index bit pattern
-    mine = torch.tensor([bu, np.int64(bi).view(np.float64)], dtype=torch.float64, device=device)
+    # one 16-byte record per rank as two int64 words: the utility's bit pattern and the index.
+    # (Integer words survive any transport unchanged -- a float64 carrier for the index would be
+    # at the mercy of NaN canonicalisation the day someone swaps the gather for a reduction.)
+    mine = torch.tensor([int(np.float64(bu).view(np.int64)), int(bi)], dtype=torch.int64, device=device)
     world = dist.get_world_size(group)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
     pairs = []
     for g in gathered:
         h = g.cpu().numpy()
-        pairs.append((float(h[0]), int(h[1:2].view(np.int64)[0])))
+        pairs.append((float(h[0:1].view(np.float64)[0]), int(h[1])))
     return combine_best(pairs)
 
 

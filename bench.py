@@ -81,6 +81,23 @@ def profiled_traffic(n, d, m):
     return None, None
 
 
+def candidate_rows(m_total, ndim, lo_row, hi_row, keep_all=False):
+    """Rows [lo_row, hi_row) of THE candidate matrix: ``RandomState(1).uniform(-5, 5, (m_total, ndim))``
+    (SURVEY.md section 8d).  Every rank draws from the same stream and keeps its own rows, so the
+    shards of any world size tile one global matrix and the printed winner can be re-derived.
+    ``keep_all`` additionally returns the whole matrix (rank 0: oracle check of the winner)."""
+    rs = np.random.RandomState(1)
+    if keep_all:
+        cands_all = rs.uniform(-5.0, 5.0, size=(m_total, ndim))
+        return np.ascontiguousarray(cands_all[lo_row:hi_row]), cands_all
+    left = lo_row                      # skip the lower ranks' rows without holding them
+    while left > 0:
+        n = min(left, 1 << 20)
+        rs.uniform(-5.0, 5.0, size=(n, ndim))
+        left -= n
+    return np.ascontiguousarray(rs.uniform(-5.0, 5.0, size=(hi_row - lo_row, ndim))), None
+
+
 def f_var(n, d):
     """Algorithmic flops per candidate, SURVEY.md section 8(d)."""
     return float(n) * n + float(n) * (3 * d + 4)
@@ -215,20 +232,7 @@ def main():
 
     # candidates: ONE global NumPy seed-1 draw; this rank's rows; resident in HBM before the
     # timed region (the H2D copy is reported separately)
-    rs = np.random.RandomState(1)
-    if rank == 0 and not args.no_check:
-        cands_all = rs.uniform(-5.0, 5.0, size=(M_total, D))
-        mine = cands_all[lo_row:hi_row]
-    else:
-        # skip the rows of lower ranks without holding them (same stream positions)
-        left = lo_row
-        while left > 0:
-            n = min(left, 1 << 20)
-            rs.uniform(-5.0, 5.0, size=(n, D))
-            left -= n
-        mine = rs.uniform(-5.0, 5.0, size=(M, D))
-        cands_all = None
-    mine = np.ascontiguousarray(mine)
+    mine, cands_all = candidate_rows(M_total, D, lo_row, hi_row, keep_all=(rank == 0 and not args.no_check))
     torch.cuda.synchronize()
     t0 = time.time()
     T = torch.from_numpy(mine).to(dev)

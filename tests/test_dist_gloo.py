@@ -121,3 +121,27 @@ def test_replicated_ensembles_world2_gloo(tmp_path):
     assert c.shape == (2, 4, 3) and np.all(c == 5)
     with pytest.raises(ValueError):
         replicated_ensembles(lambda s: (np.ones((2, 4)), np.zeros((2, 4))))
+
+
+def test_bench_candidate_shards_tile_the_global_draw():
+    """bench.py's candidate matrix (C3 / C4): rank r's rows are rows
+    [r M/world, (r+1) M/world) of ONE NumPy seed-1 draw, for every world size -- so 8 ranks x 1.25e6
+    (C4 as written, --total-candidates) sweep exactly the matrix one rank would."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from approxposterior_amd.dist import shard_bounds
+    M, D = 100003, 8
+    whole = np.random.RandomState(1).uniform(-5.0, 5.0, size=(M, D))
+    for world in (1, 2, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = shard_bounds(M, world, r)
+            mine, allc = bench.candidate_rows(M, D, lo, hi, keep_all=(r == 0))
+            assert mine.shape == (hi - lo, D) and mine.flags["C_CONTIGUOUS"]
+            if r == 0:
+                assert np.array_equal(allc, whole)
+            parts.append(mine)
+        assert np.array_equal(np.vstack(parts), whole)
