@@ -6,7 +6,7 @@
 //   dK/dlog_constant = amp * k_se           (white noise excluded)
 //   dK/dlog_M_d      = K * 0.5 * dx_d^2 / M_d
 //   g_white_noise    = 0.5 * exp(white_noise) * trace(alpha alpha^T - Kinv)   (fit_white_noise)
-// K^-1 = W^T W (W = L^-1) is formed with an MFMA-f64 GEMM; K and dK are
+// K^-1 = W^T W (W = L^-1) is formed with an MFMA-f64 GEMM (four-block instruction, apgp_mma16); K and dK are
 // regenerated in registers from X (no N x N x P tensor in HBM).
 #include "apgp_common.h"
 
@@ -23,11 +23,13 @@ __global__ __launch_bounds__(256) void syrk_wtw_kernel(SyrkArgs a) {
     const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-    f64x4 acc[2][2];
+    double acc[2][2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
     const long long k0 = i0 > j0 ? i0 : j0;
     for (long long kk = k0; kk < a.np; kk += 16) {
         const int kr = t >> 4, cq = (t & 15) * 4;
@@ -44,10 +46,11 @@ __global__ __launch_bounds__(256) void syrk_wtw_kernel(SyrkArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = Bs[ks * 4 + (lane >> 4)][wc + 16 * j + (lane & 15)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                const ApgpBRot br = apgp_brot(bf[j]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) apgp_mma16(af[i], br, acc[i][j]);
+            }
         }
         __syncthreads();
     }
@@ -56,10 +59,10 @@ __global__ __launch_bounds__(256) void syrk_wtw_kernel(SyrkArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                long long gr = i0 + wr + 16 * i + (lane >> 4) + 4 * rg;
-                long long gc = j0 + wc + 16 * j + (lane & 15);
-                if (gr < a.n && gc < a.n) a.Kinv[gr * a.n + gc] = acc[i][j][rg];
+            for (int r = 0; r < 4; ++r) {
+                long long gr = i0 + wr + 16 * i + apgp_mma16_row(lane);
+                long long gc = j0 + wc + 16 * j + apgp_mma16_col(lane, r);
+                if (gr < a.n && gc < a.n) a.Kinv[gr * a.n + gc] = acc[i][j][r];
             }
 }
 

@@ -8,8 +8,8 @@
 //           block in registers (redundantly -- it is the critical path either
 //           way, and it saves a launch + a grid-wide dependency) while its second
 //           wavefront solves 64 rows of the panel against it (row-per-lane substitution);
-//   update: trailing lower-triangle tiles A_ik -= L_ij L_kj^T (64x64x64 MFMA
-//           f64 tiles; HBM-bound: each tile is read-modify-written once).
+//   update: trailing lower-triangle tiles A_ik -= L_ij L_kj^T (64x64x64 tiles on the
+//           four-block f64 MFMA; HBM-bound: each tile is read-modify-written once).
 // info follows LAPACK: 0 = OK, k > 0 = leading minor of order k not positive
 // definite (first failing pivot).
 #include "apgp_common.h"
@@ -28,6 +28,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 #define PB 64
+#define CB 4     // columns per step of the diagonal-block factorisation (potrf_panel_kernel)
 
 struct PotrfArgs {
     double* A;
@@ -70,7 +71,7 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
 // machine scheduler -- without both, hundreds of reads are in flight at once and the 64-double
 // register rows spill.
 #ifdef APGP_PANEL_TIMING
-__device__ unsigned long long apgp_panel_stamps[8];
+__device__ unsigned long long apgp_panel_stamps[16];
 #define PANEL_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && a.j0 == 2048) apgp_panel_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PANEL_STAMP(i) do { } while (0)
@@ -81,13 +82,6 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
-}
-// staging of the panel solve: 16-column groups of row k before its last (k & 3) columns
-__host__ __device__ constexpr int trsm_ng(int k) { return ((k & ~3) + 15) / 16; }
-__host__ __device__ constexpr int trsm_gcount(int k, int g) {
-    int c = g;
-    for (int q = 0; q < k; ++q) c += trsm_ng(q);
-    return c;
 }
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 // (a C++ volatile store through a generic pointer becomes a FLAT system-scope store plus
@@ -100,9 +94,40 @@ __device__ __forceinline__ int lds_load_volatile(const int* p) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const int*)p) : "memory");
     return v;
 }
+// rank-CB update of columns C0 + CB .. PB - 1 of a register row `row` with the row's new entries
+// xs (columns C0 .. C0 + CB - 1): row[j] -= sum_k xs[k] L[j][C0 + k], k ascending.  Row j of the new
+// columns is a broadcast read of the published factor.  Four columns advance together (a chain of
+// dependent f64 FMAs issues one per ~10 cycles, four independent ones one per ~4.4), two k per
+// step; the reads of a step are requested TR_AHEAD steps before their use.
+#define TR_AHEAD 4
+template <int C0>
+__device__ __forceinline__ void panel_trailing(double (&row)[PB], const double (&xs)[CB], const double (*Ls)[PB + 2]) {
+    constexpr int J0 = C0 + CB, NJ = PB - J0, NS = (NJ / 4) * (CB / 2);
+    static_assert(NJ % 4 == 0, "column groups of four");
+    if constexpr (NS > 0) {
+        f64x2 lb[TR_AHEAD][4];
+        auto request = [&](auto s_) {
+            constexpr int s = decltype(s_)::value, g = s / (CB / 2), kp = s % (CB / 2);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) lb[s % TR_AHEAD][jj] = *(const f64x2*)(&Ls[J0 + 4 * g + jj][C0 + 2 * kp]);
+        };
+        static_for<(TR_AHEAD < NS ? TR_AHEAD : NS)>(request);
+        PANEL_FENCE();
+        static_for<NS>([&](auto s_) {
+            constexpr int s = decltype(s_)::value, g = s / (CB / 2), kp = s % (CB / 2), slot = s % TR_AHEAD;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) row[J0 + 4 * g + jj] = fma(-xs[2 * kp], lb[slot][jj].x, row[J0 + 4 * g + jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) row[J0 + 4 * g + jj] = fma(-xs[2 * kp + 1], lb[slot][jj].y, row[J0 + 4 * g + jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) asm volatile("" : "+v"(row[J0 + 4 * g + jj]));
+            if constexpr (s + TR_AHEAD < NS) request(std::integral_constant<int, s + TR_AHEAD>{});
+            PANEL_FENCE();
+        });
+    }
+}
 __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
     potrf_select(a);
-    __shared__ __attribute__((aligned(16))) double col[2][PB];
     __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];
     __shared__ __attribute__((aligned(16))) double invd[PB];
     __shared__ double zblk[PB];
@@ -119,19 +144,17 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
         // ---------------- wavefront 0: the diagonal block ----------------
         PANEL_STAMP(0);
         double ar[PB];
+        double ri = (a.rhs && lane < bs) ? a.rhs[j0 + lane] : 0.0;
         if (bs == PB) {
-            // coalesced: lane = column (one 512-byte row of the block per load), transposed to
-            // lane = row through Ls (free until the first pivot is published).  A row-per-lane load
-            // touches 64 cache lines per instruction: ~10 k cycles at the head of every step, ~6 k so.
+            // coalesced: lane = column (one 512-byte row of the block per load, all 64 in flight
+            // together), transposed to lane = row through Ls (free until the first columns are
+            // published).  A row-per-lane load touches 64 cache lines per instruction.
             const double* src = a.A + j0 * a.lda + j0 + lane;
+            double t[PB];
 #pragma unroll
-            for (int r0 = 0; r0 < PB; r0 += 16) {
-                double t[16];
+            for (int r = 0; r < PB; ++r) t[r] = src[(long long)r * a.lda];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = src[(long long)(r0 + r) * a.lda];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Ls[r0 + r][lane] = t[r];
-            }
+            for (int r = 0; r < PB; ++r) Ls[r][lane] = t[r];
             PANEL_FENCE();
 #pragma unroll
             for (int k = 0; k < PB; k += 2) {
@@ -150,69 +173,102 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
         }
         PANEL_FENCE();
         PANEL_STAMP(1);
-        static_for<PB>([&](auto kc_) {
-            constexpr int k = decltype(kc_)::value;
-            const double piv = bcast_lane(ar[k], k);
-            const bool bad = !(piv > 0.0) || !(piv < INFINITY);
-            if (bad && blockIdx.x == 0 && lane == 0) atomicMin((unsigned int*)a.info, (unsigned int)(j0 + k + 1));
-            const double pv = bad ? 1.0 : piv;
-            double r = __builtin_amdgcn_rsq(pv);
-            r = r * fma(-0.5 * pv * r, r, 1.5);
-            r = r * fma(-0.5 * pv * r, r, 1.5);
-            double d = pv * r;
-            d = fma(0.5 * r, fma(-d, d, pv), d);
-            const double inv = r;
-            invd[k] = inv;                           // (uniform value, every lane stores it: no divergent branch)
-            ar[k] = lane == k ? d : ar[k] * inv;
-            double* cb = col[k & 1];
-            cb[lane] = ar[k];
-            Ls[lane][k] = k <= lane ? ar[k] : 0.0;      // column k of L_jj for the panel solve
-            lds_store_volatile(&prog, k + 1);           // (every lane, same word; same wavefront: LDS stores stay in order)
-            const double lik = ar[k];
-            if (((k + 1) & 1) && k + 1 < PB) {
-                const double ljk = cb[k + 1];
-                ar[k + 1] = fma(-lik, ljk, ar[k + 1]);
-                asm volatile("" : "+v"(ar[k + 1]));
+        int firstbad = 0x7fffffff;               // (uniform) first pivot that is not positive and finite
+        static_for<PB / CB>([&](auto cc_) {
+            constexpr int c0 = CB * decltype(cc_)::value;
+            // (1) the CB x CB diagonal block, as updated so far, and the CB right-hand-side entries
+            // into every lane (uniform registers)
+            double d[CB][CB], zb[CB];
+#pragma unroll
+            for (int r = 0; r < CB; ++r) {
+#pragma unroll
+                for (int q = 0; q <= r; ++q) d[r][q] = bcast_lane(ar[c0 + q], c0 + r);
+                zb[r] = bcast_lane(ri, c0 + r);
             }
-            // (one group per pivot: this wavefront has a SIMD's whole register file behind it -- the
-            // workgroup's two wavefronts sit on different SIMDs --, so the column's broadcast values
-            // are all requested at once, up to 62 registers; the fences still keep hipcc from
-            // requesting the columns of LATER pivots up here)
+            if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(6); }
+            // (2) its factor, computed by all lanes alike: the serial chain of CB pivots runs on
+            // registers alone -- no cross-lane step, no LDS round trip, no branch per pivot.  Per
+            // pivot: v_rsq_f64 seed, one third-order step (r (1 + e/2 + 3 e^2/8), e = 1 - p r^2:
+            // error e^3, four dependent operations), scale, update.  A pivot that is not positive
+            // and finite is recorded, not replaced: the factor is then undefined, as in LAPACK.
+            double inv[CB], sq[CB];
 #pragma unroll
-            for (int j0g = (k + 2) & ~1; j0g + 1 < PB; j0g += 64) {
-                f64x2 l2[32];
+            for (int k = 0; k < CB; ++k) {
+                const double pv = d[k][k];
+                const bool bad = !(pv > 0.0) || !(pv < INFINITY);
+                firstbad = (bad && firstbad == 0x7fffffff) ? c0 + k + 1 : firstbad;
+                double r = __builtin_amdgcn_rsq(pv);
+                {
+                    const double e = fma(-pv * r, r, 1.0);
+                    r = fma(r * e, fma(0.375, e, 0.5), r);
+                }
+                inv[k] = r;
 #pragma unroll
-                for (int g = 0; g < 32; ++g)
-                    if (j0g + 2 * g + 1 < PB) l2[g] = *(const f64x2*)(cb + j0g + 2 * g);
-                PANEL_FENCE();
+                for (int i = k + 1; i < CB; ++i) d[i][k] *= r;
 #pragma unroll
-                for (int g = 0; g < 32; ++g)
-                    if (j0g + 2 * g + 1 < PB) {
-                        ar[j0g + 2 * g] = fma(-lik, l2[g].x, ar[j0g + 2 * g]);
-                        ar[j0g + 2 * g + 1] = fma(-lik, l2[g].y, ar[j0g + 2 * g + 1]);
-                        asm volatile("" : "+v"(ar[j0g + 2 * g]), "+v"(ar[j0g + 2 * g + 1]));
-                    }
-                PANEL_FENCE();
+                for (int j = k + 1; j < CB; ++j)
+#pragma unroll
+                    for (int i = j; i < CB; ++i) d[i][j] = fma(-d[i][k], d[j][k], d[i][j]);
+                double dd = pv * r;                                  // (off the chain) sqrt(p), one Newton step
+                sq[k] = fma(0.5 * r, fma(-dd, dd, pv), dd);
+                double zacc = zb[k];                                 // forward solve riding along
+#pragma unroll
+                for (int m = 0; m < k; ++m) zacc = fma(-zb[m], d[k][m], zacc);
+                zb[k] = zacc * r;
             }
+            if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(7); }
+            // (3) every lane solves its own row against it (rows of the block itself reproduce the
+            // factor bit for bit: same operations in the same order)
+            double x[CB];
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                double sacc = ar[c0 + k];
+#pragma unroll
+                for (int m = 0; m < k; ++m) sacc = fma(-x[m], d[k][m], sacc);
+                sacc *= inv[k];
+                x[k] = lane == c0 + k ? sq[k] : (lane > c0 + k ? sacc : 0.0);
+                ar[c0 + k] = x[k];
+            }
+            {
+                double racc = ri;
+#pragma unroll
+                for (int k = 0; k < CB; ++k) racc = fma(-x[k], zb[k], racc);
+                ri = lane >= c0 + CB ? racc : ri;
+#pragma unroll
+                for (int k = 0; k < CB; ++k) ri = lane == c0 + k ? zb[k] : ri;
+            }
+            if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(8); }
+            // (4) publish columns c0 .. c0 + CB - 1 of L_jj and their reciprocal pivots (one lane:
+            // 64 lanes storing to one address serialise)
+#pragma unroll
+            for (int k = 0; k < CB; k += 2) *(f64x2*)(&Ls[lane][c0 + k]) = (f64x2){x[k], x[k + 1]};
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < CB; k += 2) *(f64x2*)(&invd[c0 + k]) = (f64x2){inv[k], inv[k + 1]};
+                lds_store_volatile(&prog, c0 + CB);     // (same wavefront: LDS stores stay in order)
+            }
+            PANEL_FENCE();
+            if (c0 == 0) { PANEL_STAMP(9); }
+            // (5) rank-CB update of the columns to the right; row j of the new columns comes back
+            // as broadcast reads, requested TR_AHEAD columns before their use
+            panel_trailing<c0>(ar, x, Ls);
+            if (c0 == 0) { PANEL_STAMP(10); }
         });
         PANEL_STAMP(2);
-        if (blockIdx.x == 0 && lane < bs) {
-            double* dst = a.A + (j0 + lane) * a.lda + j0;
-#pragma unroll
-            for (int k = 0; k < PB; ++k)
-                if (k <= lane) dst[k] = ar[k];
-        }
+        if (firstbad != 0x7fffffff && blockIdx.x == 0 && lane == 0)
+            atomicMin((unsigned int*)a.info, (unsigned int)(j0 + firstbad));
         if (a.rhs) {
-            double ri = (lane < bs) ? a.rhs[j0 + lane] : 0.0;
-            static_for<PB>([&](auto kc_) {
-                constexpr int k = decltype(kc_)::value;
-                const double zk = bcast_lane(ri, k) * invd[k];
-                ri = lane == k ? zk : (lane > k ? fma(-ar[k], zk, ri) : ri);
-            });
             zblk[lane] = ri;
             if (blockIdx.x == 0 && lane < bs) a.rhs[j0 + lane] = ri;
         }
         lds_store_volatile(&prog, PB + 1);
+        {
+            // L_jj back to the matrix, coalesced, from the published copy (every workgroup holds it:
+            // workgroup b stores the rows r = b mod gridDim.x)
+            double* dst = a.A + j0 * a.lda + j0 + lane;
+            for (int r = blockIdx.x; r < bs; r += gridDim.x)
+                if (lane <= r) dst[(long long)r * a.lda] = Ls[r][lane];
+        }
         PANEL_STAMP(3);
         return;
     }
@@ -229,65 +285,28 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
         while (lds_load_volatile(&prog) < need) __builtin_amdgcn_s_sleep(1);
         PANEL_FENCE();
     };
-    f64x2 lq[2][8], tq[2][2];
-    double ivq[2];
-    auto load_wide = [&](auto kt, auto gt) {
-        constexpr int k = decltype(kt)::value, g = decltype(gt)::value;
-        constexpr int buf = trsm_gcount(k, g) & 1;
+    static_for<PB / CB>([&](auto cc_) {
+        constexpr int c0 = CB * decltype(cc_)::value;
+        wait_prog(c0 + CB);                 // columns c0 .. c0 + CB - 1 of L_jj published
+        f64x2 dq[CB][CB / 2], iq[CB / 2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (16 * g + 2 * i + 1 < (k & ~3)) lq[buf][i] = *(const f64x2*)(&Ls[k][16 * g + 2 * i]);
-    };
-    auto load_tail = [&](auto kt) {
-        constexpr int k = decltype(kt)::value;
-        tq[k & 1][0] = *(const f64x2*)(&Ls[k][k & ~3]);
-        tq[k & 1][1] = *(const f64x2*)(&Ls[k][(k & ~3) + 2]);
-        ivq[k & 1] = invd[k];
-    };
-    auto load_first_of = [&](auto kt) {
-        constexpr int k = decltype(kt)::value;
-        if constexpr (k < PB) {
-            if constexpr (trsm_ng(k) > 0) load_wide(kt, std::integral_constant<int, 0>{});
-            else load_tail(kt);
-        }
-    };
-    wait_prog(1);                          // row 0 of L_jj and invd[0]
-    load_first_of(std::integral_constant<int, 0>{});
-    static_for<PB>([&](auto kc_) {
-        constexpr int k = decltype(kc_)::value;
-        // rows k and (prefetch) k+1 of L_jj with their reciprocals: pivots 0 .. k+1 published
-        wait_prog(k + 2 < PB ? k + 2 : PB);
-        double s0 = x[k], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        static_for<4>([&](auto gc_) {
-            constexpr int g = decltype(gc_)::value;
-            if constexpr (g < trsm_ng(k)) {
-                if constexpr (g + 1 < trsm_ng(k)) load_wide(kc_, std::integral_constant<int, g + 1>{});
-                else load_tail(kc_);
-                PANEL_FENCE();
-                constexpr int buf = trsm_gcount(k, g) & 1;
+        for (int r = 0; r < CB; ++r)
 #pragma unroll
-                for (int i = 0; i < 8; i += 2)
-                    if (16 * g + 2 * i + 3 < k) {
-                        const int m = 16 * g + 2 * i;
-                        s0 = fma(-x[m], lq[buf][i].x, s0);
-                        s1 = fma(-x[m + 1], lq[buf][i].y, s1);
-                        s2 = fma(-x[m + 2], lq[buf][i + 1].x, s2);
-                        s3 = fma(-x[m + 3], lq[buf][i + 1].y, s3);
-                    }
-                asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
-                PANEL_FENCE();
-            }
-        });
-        load_first_of(std::integral_constant<int, k + 1>{});
+            for (int q = 0; 2 * q < r; ++q) dq[r][q] = *(const f64x2*)(&Ls[c0 + r][c0 + 2 * q]);
+#pragma unroll
+        for (int q = 0; q < CB / 2; ++q) iq[q] = *(const f64x2*)(&invd[c0 + 2 * q]);
         PANEL_FENCE();
-        {
-            const double tl[4] = {tq[k & 1][0].x, tq[k & 1][0].y, tq[k & 1][1].x, tq[k & 1][1].y};
+        double xs[CB];
 #pragma unroll
-            for (int m = k & ~3; m < k; ++m) s0 = fma(-x[m], tl[m - (k & ~3)], s0);
+        for (int k = 0; k < CB; ++k) {
+            double sacc = x[c0 + k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) sacc = fma(-xs[m], (m & 1) ? dq[k][m >> 1].y : dq[k][m >> 1].x, sacc);
+            xs[k] = sacc * ((k & 1) ? iq[k >> 1].y : iq[k >> 1].x);
+            x[c0 + k] = xs[k];
         }
-        x[k] = ((s0 + s1) + (s2 + s3)) * ivq[k & 1];
-        asm volatile("" : "+v"(x[k]));
         PANEL_FENCE();
+        panel_trailing<c0>(x, xs, Ls);
     });
     PANEL_STAMP(4);
     if (has_row) {
@@ -330,11 +349,13 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(PotrfArgs a) {
     }
     __syncthreads();
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-    f64x4 acc[2][2];
+    double acc[2][2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
 #pragma unroll
     for (int ks = 0; ks < PB / 4; ++ks) {
         double af[2], bf[2];
@@ -343,20 +364,21 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(PotrfArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) bf[j] = Rs[wc + 16 * j + (lane & 15)][ks * 4 + (lane >> 4)];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const ApgpBRot br = apgp_brot(bf[j]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) apgp_mma16(af[i], br, acc[i][j]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const long long gr = ri + wr + 16 * i + (lane >> 4) + 4 * rg;
-                const long long gc = rk + wc + 16 * j + (lane & 15);
-                if (gr < a.n && gc < a.n && gc <= gr) a.A[gr * a.lda + gc] -= acc[i][j][rg];
+            for (int r = 0; r < 4; ++r) {
+                const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
+                const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, r);
+                if (gr < a.n && gc < a.n && gc <= gr) a.A[gr * a.lda + gc] -= acc[i][j][r];
             }
 }
 

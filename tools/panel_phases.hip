@@ -15,11 +15,13 @@ int main() {
         (void)hipMemcpy(A, h.data(), n * n * 8, hipMemcpyHostToDevice);
         int rc = apgp_potrf(A, n, n, yd, 0.0, z, info, nullptr);
         (void)hipDeviceSynchronize();
-        unsigned long long s[8];
+        unsigned long long s[16];
         (void)hipMemcpyFromSymbol(s, HIP_SYMBOL(apgp_panel_stamps), sizeof(s));
         printf("rc %d | panel step at column 2048, workgroup 0, cycles after the factorising wavefront's start: block loaded %llu | potf2 done %llu | "
                "write-back + z-solve done %llu | (solving wavefront) panel solve done %llu | rows stored + rhs updated %llu\n", rc,
                s[1] - s[0], s[2] - s[0], s[3] - s[0], s[4] - s[0], s[5] - s[0]);
+        printf("   first column group: diagonal block broadcast %llu | its factor %llu | row solve %llu | published %llu | columns to the right updated %llu\n",
+               s[6] - s[1], s[7] - s[6], s[8] - s[7], s[9] - s[8], s[10] - s[9]);
     }
     return 0;
 }
