@@ -195,33 +195,3 @@ __device__ __forceinline__ void apgp_exp4(const double (&xin)[4], double (&out)[
         out[i] = __hiloint2double(hi, __double2loint(res[i]));
     }
 }
-
-// ---------------------------------------------------------------------------
-// 16 x 16 (+)= (16 x 4) * (4 x 16) on v_mfma_f64_4x4x4_4b_f64, the fp64 matrix instruction that
-// runs at the FP64 peak on gfx950 (v_mfma_f64_16x16x4_f64 runs at less than half of it; DESIGN.md
-// section 2).  Operand fragments are those of the 16x16x4 instruction (A: lane = row + 16 k,
-// B: lane = col + 16 k).  The four-block instruction multiplies row group b (rows 4b .. 4b+3)
-// with column group b only, so the product takes four of them with the B fragment rotated by
-// 4 r lanes inside each 16-lane row (DPP row_ror: lane l reads lane l - 4 r, tools/mma16_probe.hip):
-// rotation r pairs row group b with column group (b - r) & 3.  acc[r] of lane l then holds element
-//     row = 4 * ((l >> 2) & 3) + (l >> 4),   col = 4 * ((((l >> 2) & 3) - r) & 3) + (l & 3).
-// ---------------------------------------------------------------------------
-template <int R>
-__device__ __forceinline__ double apgp_row_ror4(double v) {
-    if (R == 0) return v;
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + 4 * R, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + 4 * R, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-struct ApgpBRot { double r[4]; };
-__device__ __forceinline__ ApgpBRot apgp_brot(double bf) {
-    ApgpBRot b;
-    b.r[0] = bf; b.r[1] = apgp_row_ror4<1>(bf); b.r[2] = apgp_row_ror4<2>(bf); b.r[3] = apgp_row_ror4<3>(bf);
-    return b;
-}
-__device__ __forceinline__ void apgp_mma16(double af, const ApgpBRot& b, double (&acc)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, b.r[r], acc[r], 0, 0, 0);
-}
-__device__ __forceinline__ int apgp_mma16_row(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
-__device__ __forceinline__ int apgp_mma16_col(int lane, int r) { return 4 * ((((lane >> 2) & 3) - r) & 3) + (lane & 3); }

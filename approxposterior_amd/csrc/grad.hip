@@ -9,8 +9,9 @@
 // K^-1 = W^T W (W = L^-1) is formed with an MFMA-f64 GEMM (four-block instruction, apgp_mma16); K and dK are
 // regenerated in registers from X (no N x N x P tensor in HBM).
 #include "apgp_common.h"
+#include "mma16.h"
 
-// Kinv[i][j] = sum_{k >= max(i,j)} W[k][i] W[k][j]   (W lower triangular)
+// Kinv[i][j] = sum_{k >= max(i,j)} W[k][i] W[k][j]   (W lower triangular); tiles with bi >= bj only
 struct SyrkArgs {
     const double* W;
     double* Kinv;
@@ -18,9 +19,15 @@ struct SyrkArgs {
 };
 
 __global__ __launch_bounds__(256) void syrk_wtw_kernel(SyrkArgs a) {
-    __shared__ double As[16][80];   // W[k][i0 + .]  (k-major: A^T tile)
-    __shared__ double Bs[16][80];   // W[k][j0 + .]
-    const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
+    __shared__ __attribute__((aligned(16))) double lds[GEMM64_LDS_DOUBLES];
+    // lower-triangle tiles only (Kinv is symmetric and grad_tile_kernel reads the lower tiles),
+    // row block by row block: the k range of tile (bi, bj) is [64 bi, np), so the longest come first
+    const long long tix = blockIdx.x;
+    long long bi = (long long)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= tix) ++bi;
+    while (bi * (bi + 1) / 2 > tix) --bi;
+    const long long bj = tix - bi * (bi + 1) / 2;
+    const long long i0 = bi * 64, j0 = bj * 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
     double acc[2][2][4];
@@ -30,30 +37,7 @@ __global__ __launch_bounds__(256) void syrk_wtw_kernel(SyrkArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
-    const long long k0 = i0 > j0 ? i0 : j0;
-    for (long long kk = k0; kk < a.np; kk += 16) {
-        const int kr = t >> 4, cq = (t & 15) * 4;
-        const double* pa = a.W + (kk + kr) * a.ldw + i0 + cq;
-        const double* pb = a.W + (kk + kr) * a.ldw + j0 + cq;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { As[kr][cq + e] = pa[e]; Bs[kr][cq + e] = pb[e]; }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            double af[2], bf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = As[ks * 4 + (lane >> 4)][wr + 16 * i + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Bs[ks * 4 + (lane >> 4)][wc + 16 * j + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const ApgpBRot br = apgp_brot(bf[j]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) apgp_mma16(af[i], br, acc[i][j]);
-            }
-        }
-        __syncthreads();
-    }
+    apgp_gemm64_tile<true, true>(a.W + i0, a.ldw, 0, a.W + j0, a.ldw, 0, i0, a.np, lds, acc);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -84,7 +68,14 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
     __shared__ double etab[APGP_EXP_TAB_N];
     apgp_exp_tab_load(etab);
     const int t = threadIdx.x;
-    const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
+    // lower-triangle tiles (bi >= bj); the summand is symmetric, so an off-diagonal tile counts twice
+    const long long tix = blockIdx.x;
+    long long bi = (long long)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= tix) ++bi;
+    while (bi * (bi + 1) / 2 > tix) --bi;
+    const long long bj = tix - bi * (bi + 1) / 2;
+    const long long i0 = bi * 64, j0 = bj * 64;
+    const double tile_weight = bi == bj ? 1.0 : 2.0;
     for (int e = t; e < 64 * DPAD; e += 256) {
         int r = e / DPAD, d = e % DPAD;
         long long gi = i0 + r, gj = j0 + r;
@@ -147,8 +138,7 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(GradArgs a) {
     __syncthreads();
     if (t < 2 + DPAD) {
         double v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-        const long long blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-        a.partial[blk * (2 + DPAD) + t] = v;
+        a.partial[tix * (2 + DPAD) + t] = tile_weight * v;
     }
 }
 
@@ -198,17 +188,18 @@ extern "C" int apgp_grad_loglik(const double* X, const double* alpha, const doub
     const unsigned nb = (unsigned)(np / 64);
     SyrkArgs sa;
     sa.W = winv; sa.Kinv = work; sa.ldw = ldw; sa.np = np; sa.n = n;
-    hipLaunchKernelGGL(syrk_wtw_kernel, dim3(nb, nb), dim3(256), 0, s, sa);
+    const unsigned nlow = nb * (nb + 1) / 2;
+    hipLaunchKernelGGL(syrk_wtw_kernel, dim3(nlow), dim3(256), 0, s, sa);
     g.X = X; g.alpha = alpha; g.Kinv = work; g.partial = work + n * n; g.n = n;
     const int pw = 2 + g.kc.dpad;
     switch (g.kc.dpad) {
-        case 2: hipLaunchKernelGGL(grad_tile_kernel<2>, dim3(nb, nb), dim3(256), 0, s, g); break;
-        case 4: hipLaunchKernelGGL(grad_tile_kernel<4>, dim3(nb, nb), dim3(256), 0, s, g); break;
-        case 8: hipLaunchKernelGGL(grad_tile_kernel<8>, dim3(nb, nb), dim3(256), 0, s, g); break;
-        default: hipLaunchKernelGGL(grad_tile_kernel<16>, dim3(nb, nb), dim3(256), 0, s, g); break;
+        case 2: hipLaunchKernelGGL(grad_tile_kernel<2>, dim3(nlow), dim3(256), 0, s, g); break;
+        case 4: hipLaunchKernelGGL(grad_tile_kernel<4>, dim3(nlow), dim3(256), 0, s, g); break;
+        case 8: hipLaunchKernelGGL(grad_tile_kernel<8>, dim3(nlow), dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL(grad_tile_kernel<16>, dim3(nlow), dim3(256), 0, s, g); break;
     }
     hipLaunchKernelGGL(grad_final_kernel, dim3(1), dim3(1024), 0, s, (const double*)g.partial,
-                       (long long)nb * nb, pw, alpha, (const double*)work, (long long)n, g.kc.ndim, out);
+                       (long long)nlow, pw, alpha, (const double*)work, (long long)n, g.kc.ndim, out);
     APGP_CHECK_LAUNCH();
     return 0;
 }

@@ -4,6 +4,7 @@
 // apply_inverse (scipy cholesky + cho_solve) as used by GP.log_likelihood,
 // GP._compute_alpha and GP.predict (gpUtils.py:78; utility.py:131,178,224).
 #include "apgp_common.h"
+#include "mma16.h"
 
 // ---------------------------------------------------------------------------
 // sizes
@@ -394,8 +395,7 @@ struct MergeArgs {
 // four-block f64 MFMA (apgp_mma16: twice the rate of v_mfma_f64_16x16x4 on gfx950); K staged
 // through LDS in chunks of 16.
 __global__ __launch_bounds__(256) void trtri_merge_kernel(MergeArgs a) {
-    __shared__ double As[64][17];
-    __shared__ double Bs[16][80];
+    __shared__ __attribute__((aligned(16))) double lds[GEMM64_LDS_DOUBLES];
     const int q = blockIdx.z;
     const long long first0 = (long long)2 * q * a.s;          // in 64-blocks
     const long long second0 = first0 + a.s;
@@ -404,16 +404,6 @@ __global__ __launch_bounds__(256) void trtri_merge_kernel(MergeArgs a) {
     if (rb >= a.nb || rb >= first0 + 2 * a.s) return;
     const long long cb = first0 + blockIdx.x;                // output col block
     const long long r0 = rb * 64, c0 = cb * 64;
-    long long k0, k1;
-    const double *Ap, *Bp;
-    long long lda, ldb;
-    if (a.phase == 1) {   // T[r, c] = sum_k L[r, k] W[k, c], k in first, W lower => k >= c
-        k0 = c0; k1 = second0 * 64;
-        Ap = a.L; lda = a.ldl; Bp = a.W; ldb = a.ldw;
-    } else {              // W[r, c] = -sum_k W[r, k] T[k, c], k in second, W lower => k <= r
-        k0 = second0 * 64; k1 = r0 + 64;
-        Ap = a.W; lda = a.ldw; Bp = a.T; ldb = a.ldw;
-    }
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
     double acc[2][2][4];
@@ -423,37 +413,10 @@ __global__ __launch_bounds__(256) void trtri_merge_kernel(MergeArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
-    for (long long kk = k0; kk < k1; kk += 16) {
-        {   // A tile: 64 rows x 16 k ; thread -> (row = t>>2, 4 consecutive k)
-            int row = t >> 2, kq = (t & 3) * 4;
-            const double* p = Ap + (r0 + row) * lda + kk + kq;
-            const bool ok = (a.phase != 1) || (r0 + row < a.n);   // L has only n rows
-            As[row][kq + 0] = ok ? p[0] : 0.0; As[row][kq + 1] = ok ? p[1] : 0.0;
-            As[row][kq + 2] = ok ? p[2] : 0.0; As[row][kq + 3] = ok ? p[3] : 0.0;
-        }
-        {   // B tile: 16 k x 64 cols ; thread -> (k = t>>4, 4 consecutive cols)
-            int kr = t >> 4, cq = (t & 15) * 4;
-            const double* p = Bp + (kk + kr) * ldb + c0 + cq;
-            Bs[kr][cq + 0] = p[0]; Bs[kr][cq + 1] = p[1];
-            Bs[kr][cq + 2] = p[2]; Bs[kr][cq + 3] = p[3];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            double af[2], bf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = As[wr + 16 * i + (lane & 15)][ks * 4 + (lane >> 4)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Bs[ks * 4 + (lane >> 4)][wc + 16 * j + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const ApgpBRot br = apgp_brot(bf[j]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) apgp_mma16(af[i], br, acc[i][j]);
-            }
-        }
-        __syncthreads();
-    }
+    if (a.phase == 1)     // T[r, c] = sum_k L[r, k] W[k, c], k in first, W lower => k >= c ; L has only n rows
+        apgp_gemm64_tile<false, true>(a.L + r0 * a.ldl, a.ldl, a.n - r0, a.W + c0, a.ldw, 0, c0, second0 * 64, lds, acc);
+    else                  // W[r, c] = -sum_k W[r, k] T[k, c], k in second, W lower => k <= r
+        apgp_gemm64_tile<false, true>(a.W + r0 * a.ldw, a.ldw, 64, a.T + c0, a.ldw, 0, second0 * 64, r0 + 64, lds, acc);
     double* Cp = (a.phase == 1) ? a.T : a.W;
     const double sgn = (a.phase == 1) ? 1.0 : -1.0;
 #pragma unroll
@@ -462,7 +425,7 @@ __global__ __launch_bounds__(256) void trtri_merge_kernel(MergeArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                // four-block layout (apgp_common.h): rotation r of lane l -> (row, col) of the 16 x 16 block
+                // four-block layout (mma16.h): rotation r of lane l -> (row, col) of the 16 x 16 block
                 long long gr = r0 + wr + 16 * i + apgp_mma16_row(lane);
                 long long gc = c0 + wc + 16 * j + apgp_mma16_col(lane, r);
                 Cp[gr * a.ldw + gc] = sgn * acc[i][j][r];

@@ -13,6 +13,7 @@
 // info follows LAPACK: 0 = OK, k > 0 = leading minor of order k not positive
 // definite (first failing pivot).
 #include "apgp_common.h"
+#include "mma16.h"
 #include <type_traits>
 #include <utility>
 
@@ -331,8 +332,7 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
 // A[ri.., rk..] -= L[ri.., j0..j0+64) * L[rk.., j0..j0+64)^T
 __global__ __launch_bounds__(256) void potrf_update_kernel(PotrfArgs a) {
     potrf_select(a);
-    __shared__ double Ls[PB][PB + 1];   // L[ri + r][j0 + k]
-    __shared__ double Rs[PB][PB + 1];   // L[rk + c][j0 + k]
+    __shared__ __attribute__((aligned(16))) double lds[GEMM64_LDS_DOUBLES];
     // linear tile index -> (bi, bk) in the lower triangle
     const long long tix = blockIdx.x;
     long long bi = (long long)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
@@ -342,34 +342,9 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(PotrfArgs a) {
     const long long base = a.j0 + PB;
     const long long ri = base + bi * PB, rk = base + bk * PB;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    for (int e = t; e < PB * PB; e += 256) {
-        const int r = e >> 6, k = e & 63;
-        Ls[r][k] = (ri + r < a.n) ? a.A[(ri + r) * a.lda + a.j0 + k] : 0.0;
-        Rs[r][k] = (rk + r < a.n) ? a.A[(rk + r) * a.lda + a.j0 + k] : 0.0;
-    }
-    __syncthreads();
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-    double acc[2][2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
-#pragma unroll
-    for (int ks = 0; ks < PB / 4; ++ks) {
-        double af[2], bf[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = Ls[wr + 16 * i + (lane & 15)][ks * 4 + (lane >> 4)];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = Rs[wc + 16 * j + (lane & 15)][ks * 4 + (lane >> 4)];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const ApgpBRot br = apgp_brot(bf[j]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) apgp_mma16(af[i], br, acc[i][j]);
-        }
-    }
+    // the tile's own elements are requested first: they are needed last
+    double cin[2][2][4], acc[2][2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -378,7 +353,20 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(PotrfArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
                 const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, r);
-                if (gr < a.n && gc < a.n && gc <= gr) a.A[gr * a.lda + gc] -= acc[i][j][r];
+                cin[i][j][r] = (gr < a.n && gc < a.n && gc <= gr) ? a.A[gr * a.lda + gc] : 0.0;
+                acc[i][j][r] = 0.0;
+            }
+    apgp_gemm64_tile<false, false>(a.A + ri * a.lda + a.j0, a.lda, a.n - ri, a.A + rk * a.lda + a.j0, a.lda, a.n - rk,
+                                   0, PB, lds, acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
+                const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, r);
+                if (gr < a.n && gc < a.n && gc <= gr) a.A[gr * a.lda + gc] = cin[i][j][r] - acc[i][j][r];
             }
 }
 
