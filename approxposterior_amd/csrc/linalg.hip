@@ -400,36 +400,46 @@ __global__ __launch_bounds__(256) void trtri_merge_kernel(MergeArgs a) {
     const long long first0 = (long long)2 * q * a.s;          // in 64-blocks
     const long long second0 = first0 + a.s;
     if (second0 >= a.nb) return;
-    const long long rb = second0 + blockIdx.y;               // output row block
-    if (rb >= a.nb || rb >= first0 + 2 * a.s) return;
-    const long long cb = first0 + blockIdx.x;                // output col block
-    const long long r0 = rb * 64, c0 = cb * 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-    double acc[2][2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
-    if (a.phase == 1)     // T[r, c] = sum_k L[r, k] W[k, c], k in first, W lower => k >= c ; L has only n rows
-        apgp_gemm64_tile<false, true>(a.L + r0 * a.ldl, a.ldl, a.n - r0, a.W + c0, a.ldw, 0, c0, second0 * 64, lds, acc);
-    else                  // W[r, c] = -sum_k W[r, k] T[k, c], k in second, W lower => k <= r
-        apgp_gemm64_tile<false, true>(a.W + r0 * a.ldw, a.ldw, 64, a.T + c0, a.ldw, 0, second0 * 64, r0 + 64, lds, acc);
     double* Cp = (a.phase == 1) ? a.T : a.W;
     const double sgn = (a.phase == 1) ? 1.0 : -1.0;
+    // The k range of a tile grows with its column block in phase 1 (k >= c) and with its row block
+    // in phase 2 (k <= r): a workgroup takes the two tiles whose ranges add up to the same length
+    // for every workgroup (block u and block s - 1 - u), so the launch is balanced by construction
+    // whatever the dispatch order.  (s = 1: one tile.)
+    const int ntile = a.s > 1 ? 2 : 1;
+    for (int h = 0; h < ntile; ++h) {
+        long long bx = blockIdx.x, by = blockIdx.y;
+        if (a.phase == 1) { if (h) bx = a.s - 1 - bx; }
+        else { if (h) by = a.s - 1 - by; }
+        const long long rb = second0 + by;                   // output row block
+        if (rb >= a.nb) continue;
+        const long long cb = first0 + bx;                    // output col block
+        const long long r0 = rb * 64, c0 = cb * 64;
+        double acc[2][2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // four-block layout (mma16.h): rotation r of lane l -> (row, col) of the 16 x 16 block
-                long long gr = r0 + wr + 16 * i + apgp_mma16_row(lane);
-                long long gc = c0 + wc + 16 * j + apgp_mma16_col(lane, r);
-                Cp[gr * a.ldw + gc] = sgn * acc[i][j][r];
-            }
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+        if (a.phase == 1)     // T[r, c] = sum_k L[r, k] W[k, c], k in first, W lower => k >= c ; L has only n rows
+            apgp_gemm64_tile<false, true>(a.L + r0 * a.ldl, a.ldl, a.n - r0, a.W + c0, a.ldw, 0, c0, second0 * 64, lds, acc);
+        else                  // W[r, c] = -sum_k W[r, k] T[k, c], k in second, W lower => k <= r
+            apgp_gemm64_tile<false, true>(a.W + r0 * a.ldw, a.ldw, 64, a.T + c0, a.ldw, 0, second0 * 64, r0 + 64, lds, acc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // four-block layout (mma16.h): rotation r of lane l -> (row, col) of the 16 x 16 block
+                    long long gr = r0 + wr + 16 * i + apgp_mma16_row(lane);
+                    long long gc = c0 + wc + 16 * j + apgp_mma16_col(lane, r);
+                    Cp[gr * a.ldw + gc] = sgn * acc[i][j][r];
+                }
+    }
 }
 
 // Packed tile (ib, kc): ROW_BLOCK rows x K_CHUNK(=16) k stored as
@@ -482,11 +492,11 @@ extern "C" int apgp_trtri_pack(const double* L, int64_t n, int64_t ldl, double* 
         MergeArgs a;
         a.L = L; a.W = W; a.T = T; a.ldl = ldl; a.ldw = np; a.n = n; a.nb = nb; a.s = lev;
         int pairs = (nb + 2 * lev - 1) / (2 * lev);
-        dim3 grid(lev, lev, pairs);
+        const int half = lev > 1 ? lev / 2 : 1;      // two complementary tiles per workgroup (trtri_merge_kernel)
         a.phase = 1;
-        hipLaunchKernelGGL(trtri_merge_kernel, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(trtri_merge_kernel, dim3(half, lev, pairs), dim3(256), 0, s, a);
         a.phase = 2;
-        hipLaunchKernelGGL(trtri_merge_kernel, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(trtri_merge_kernel, dim3(lev, half, pairs), dim3(256), 0, s, a);
     }
     if (packed) {
         long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;

@@ -43,16 +43,23 @@ __device__ __forceinline__ int apgp_mma16_col(int lane, int r) { return 4 * ((((
 // ---------------------------------------------------------------------------
 #define GEMM64_LDS_DOUBLES (2 * (16 * 80 + 16 * 80))
 typedef double f64x2_g __attribute__((ext_vector_type(2), aligned(8)));   // global operand rows are only 8-byte aligned (ld = n)
-template <bool AK, bool BK>
-__device__ __forceinline__ void apgp_gemm64_tile(const double* __restrict__ Ap, long long lda, long long a_rows,
-                                                 const double* __restrict__ Bp, long long ldb, long long b_rows,
-                                                 long long k0, long long k1, double* lds, double (&acc)[2][2][4]) {
+// With BB (row-major B only) the product B B^T of the B rows rides along in acc2 (same tile shape:
+// its A fragments are read from the B chunk), at the cost of its MFMAs alone.
+template <bool AK, bool BK, bool BB>
+__device__ __forceinline__ void apgp_gemm64_tile2(const double* __restrict__ Ap, long long lda, long long a_rows,
+                                                  const double* __restrict__ Bp, long long ldb, long long b_rows,
+                                                  long long k0, long long k1, double* lds, double (&acc)[2][2][4],
+                                                  double (&acc2)[2][2][4]) {
+    static_assert(!BB || !BK, "B B^T needs the row-major B chunk");
     // LDS: [buffer][A 1280 | B 1280]; a k-major chunk is [16][80], a row-major one [64][18]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
     const int kr = t >> 4, cq = (t & 15) * 4;       // k-major chunk: thread -> (k, 4 consecutive columns)
     const int rr = t >> 2, rq = (t & 3) * 4;        // row-major chunk: thread -> (row, 4 consecutive k)
     const bool a_ok = AK || rr < a_rows, b_ok = BK || rr < b_rows;
+    int bcol[4];                                     // column of the B fragment lane under rotation r (apgp_brot)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bcol[r] = ((lane & 15) - 4 * r) & 15;
     f64x2 ra[2], rb[2];
     auto gload = [&](long long kk) {
         const double* pa = AK ? Ap + (kk + kr) * lda + cq : Ap + (long long)rr * lda + kk + rq;
@@ -82,24 +89,49 @@ __device__ __forceinline__ void apgp_gemm64_tile(const double* __restrict__ Ap, 
         const double* Bs = As + 1280;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            double af[2], bf[2];
+            // the four rotations of a B fragment are four reads at rotated addresses (LDS is nearly
+            // idle here; six DPP moves per fragment cost more issue slots than the MFMAs leave)
+            double af[2], bf[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 af[i] = AK ? As[(ks * 4 + (lane >> 4)) * 80 + wr + 16 * i + (lane & 15)]
                            : As[(wr + 16 * i + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
 #pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bf[j][r] = BK ? Bs[(ks * 4 + (lane >> 4)) * 80 + wc + 16 * j + bcol[r]]
+                                  : Bs[(wc + 16 * j + bcol[r]) * 18 + ks * 4 + (lane >> 4)];
+#pragma unroll
             for (int j = 0; j < 2; ++j)
-                bf[j] = BK ? Bs[(ks * 4 + (lane >> 4)) * 80 + wc + 16 * j + (lane & 15)]
-                           : Bs[(wc + 16 * j + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const ApgpBRot br = apgp_brot(bf[j]);
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) apgp_mma16(af[i], br, acc[i][j]);
+                    for (int r = 0; r < 4; ++r)
+                        acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf[j][r], acc[i][j][r], 0, 0, 0);
+            if constexpr (BB) {
+                double bfa[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) bfa[i] = Bs[(wr + 16 * i + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc2[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bfa[i], bf[j][r], acc2[i][j][r], 0, 0, 0);
             }
         }
         if (more) sstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
+}
+
+template <bool AK, bool BK>
+__device__ __forceinline__ void apgp_gemm64_tile(const double* __restrict__ Ap, long long lda, long long a_rows,
+                                                 const double* __restrict__ Bp, long long ldb, long long b_rows,
+                                                 long long k0, long long k1, double* lds, double (&acc)[2][2][4]) {
+    double none[2][2][4];
+    apgp_gemm64_tile2<AK, BK, false>(Ap, lda, a_rows, Bp, ldb, b_rows, k0, k1, lds, acc, none);
 }

@@ -16,6 +16,8 @@
 #include "mma16.h"
 #include <type_traits>
 #include <utility>
+#include <map>
+#include <mutex>
 
 // compile-time loop: the body sees its index as a constant expression, so the register
 // arrays below are indexed statically whatever hipcc's unroll heuristics decide
@@ -38,6 +40,13 @@ struct PotrfArgs {
     long long j0;        // first column of the current block
     double shift;        // rhs is used as (rhs - shift); applied at block step 0 .. as read
     int* info;
+    // factored diagonal blocks, nb x 64 x 64 per matrix (NULL: written straight into A).  A panel
+    // workgroup reads the raw block from A when it starts and stores rows of the factor when it ends;
+    // sibling workgroups are not guaranteed to start together, so the factor goes here and is copied
+    // into A by potrf_finish_kernel.
+    double* dscr;
+    long long batch_dscr;    // per matrix: nb * 64 * 64 factor blocks, then nb * 64 entries of the forward solve (same hazard)
+    long long zoff;          // offset of the latter
     // batched factorisation (apgp_nll_eval_batch): blockIdx.y selects the matrix
     long long batch_A, batch_rhs;   // element strides between consecutive matrices / right-hand sides
 };
@@ -47,6 +56,7 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
     a.A += (long long)blockIdx.y * a.batch_A;
     if (a.rhs) a.rhs += (long long)blockIdx.y * a.batch_rhs;
     a.info += blockIdx.y;
+    if (a.dscr) a.dscr += (long long)blockIdx.y * a.batch_dscr;
 }
 
 // Panel step of block column j, two wavefronts per workgroup; workgroup b owns the 64 panel rows
@@ -73,9 +83,12 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
 // register rows spill.
 #ifdef APGP_PANEL_TIMING
 __device__ unsigned long long apgp_panel_stamps[16];
-#define PANEL_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && a.j0 == 2048) apgp_panel_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long apgp_step_stamps[16];   // 100 MHz wall clock, fused step at column 2048: workgroups 0 and 1
+#define STEP_STAMP(i) do { if (base == 2048 && bi < 2 && (threadIdx.x & 63) == 0) apgp_step_stamps[(i) + 6 * bi] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PANEL_STAMP(i) do { if (wb_index == 0 && (threadIdx.x & 63) == 0 && j0 == 2048) apgp_panel_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PANEL_STAMP(i) do { } while (0)
+#define STEP_STAMP(i) do { } while (0)
 #endif
 // broadcast of lane `src` (compile-time constant): two v_readlane_b32 (a few cycles) --
 // __shfl with a constant lane still goes through ds_bpermute (an LDS round trip)
@@ -127,161 +140,122 @@ __device__ __forceinline__ void panel_trailing(double (&row)[PB], const double (
         });
     }
 }
-__global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
-    potrf_select(a);
-    __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];
-    __shared__ __attribute__((aligned(16))) double invd[PB];
-    __shared__ double zblk[PB];
-    __shared__ int prog;                 // pivots published so far; PB + 1 once zblk is published too
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long j0 = a.j0;
-    const int bs = (int)((a.n - j0) < PB ? (a.n - j0) : PB);
-    const long long row = j0 + PB + (long long)blockIdx.x * PB + lane;
-    const bool has_row = row < a.n;
-    if (threadIdx.x == 0) prog = 0;
-    __syncthreads();
-
-    if (wv == 0) {
-        // ---------------- wavefront 0: the diagonal block ----------------
-        PANEL_STAMP(0);
-        double ar[PB];
-        double ri = (a.rhs && lane < bs) ? a.rhs[j0 + lane] : 0.0;
-        if (bs == PB) {
-            // coalesced: lane = column (one 512-byte row of the block per load, all 64 in flight
-            // together), transposed to lane = row through Ls (free until the first columns are
-            // published).  A row-per-lane load touches 64 cache lines per instruction.
-            const double* src = a.A + j0 * a.lda + j0 + lane;
-            double t[PB];
+// The two wavefront roles of a panel step (block column j0, bs = its width).  The caller loads
+// the operands: `ar` = row `lane` of the diagonal block (zero above the diagonal, identity rows
+// past bs), `ri` = the right-hand-side entry of that row; `x` = panel row `row` of the workgroup.
+// Ls / invd / zblk / prog: the workgroup's LDS exchange area (prog zeroed before the first use).
+__device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long j0, const int bs, const int lane,
+                                                  double (&ar)[PB], double ri, double (*Ls)[PB + 2], double* invd,
+                                                  double* zblk, int* prog_p, const int wb_index, const int wb_count) {
+#define prog (*prog_p)
+    PANEL_FENCE();
+    PANEL_STAMP(1);
+    int firstbad = 0x7fffffff;               // (uniform) first pivot that is not positive and finite
+    static_for<PB / CB>([&](auto cc_) {
+        constexpr int c0 = CB * decltype(cc_)::value;
+        // (1) the CB x CB diagonal block, as updated so far, and the CB right-hand-side entries
+        // into every lane (uniform registers)
+        double d[CB][CB], zb[CB];
 #pragma unroll
-            for (int r = 0; r < PB; ++r) t[r] = src[(long long)r * a.lda];
+        for (int r = 0; r < CB; ++r) {
 #pragma unroll
-            for (int r = 0; r < PB; ++r) Ls[r][lane] = t[r];
-            PANEL_FENCE();
+            for (int q = 0; q <= r; ++q) d[r][q] = bcast_lane(ar[c0 + q], c0 + r);
+            zb[r] = bcast_lane(ri, c0 + r);
+        }
+        if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(6); }
+        // (2) its factor, computed by all lanes alike: the serial chain of CB pivots runs on
+        // registers alone -- no cross-lane step, no LDS round trip, no branch per pivot.  Per
+        // pivot: v_rsq_f64 seed, one third-order step (r (1 + e/2 + 3 e^2/8), e = 1 - p r^2:
+        // error e^3, four dependent operations), scale, update.  A pivot that is not positive
+        // and finite is recorded, not replaced: the factor is then undefined, as in LAPACK.
+        double inv[CB], sq[CB];
 #pragma unroll
-            for (int k = 0; k < PB; k += 2) {
-                const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
-                ar[k] = k <= lane ? v.x : 0.0;
-                ar[k + 1] = k + 1 <= lane ? v.y : 0.0;
+        for (int k = 0; k < CB; ++k) {
+            const double pv = d[k][k];
+            const bool bad = !(pv > 0.0) || !(pv < INFINITY);
+            firstbad = (bad && firstbad == 0x7fffffff) ? c0 + k + 1 : firstbad;
+            double r = __builtin_amdgcn_rsq(pv);
+            {
+                const double e = fma(-pv * r, r, 1.0);
+                r = fma(r * e, fma(0.375, e, 0.5), r);
             }
-        } else {
-            const double* src = a.A + (j0 + (lane < bs ? lane : 0)) * a.lda + j0;
+            inv[k] = r;
 #pragma unroll
-            for (int k = 0; k < PB; ++k) {
-                double v = 0.0;
-                if (lane < bs && k <= lane) v = src[k];
-                ar[k] = (lane < bs && k <= lane) ? v : (k == lane ? 1.0 : 0.0);
-            }
+            for (int i = k + 1; i < CB; ++i) d[i][k] *= r;
+#pragma unroll
+            for (int j = k + 1; j < CB; ++j)
+#pragma unroll
+                for (int i = j; i < CB; ++i) d[i][j] = fma(-d[i][k], d[j][k], d[i][j]);
+            double dd = pv * r;                                  // (off the chain) sqrt(p), one Newton step
+            sq[k] = fma(0.5 * r, fma(-dd, dd, pv), dd);
+            double zacc = zb[k];                                 // forward solve riding along
+#pragma unroll
+            for (int m = 0; m < k; ++m) zacc = fma(-zb[m], d[k][m], zacc);
+            zb[k] = zacc * r;
+        }
+        if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(7); }
+        // (3) every lane solves its own row against it (rows of the block itself reproduce the
+        // factor bit for bit: same operations in the same order)
+        double x[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            double sacc = ar[c0 + k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) sacc = fma(-x[m], d[k][m], sacc);
+            sacc *= inv[k];
+            x[k] = lane == c0 + k ? sq[k] : (lane > c0 + k ? sacc : 0.0);
+            ar[c0 + k] = x[k];
+        }
+        {
+            double racc = ri;
+#pragma unroll
+            for (int k = 0; k < CB; ++k) racc = fma(-x[k], zb[k], racc);
+            ri = lane >= c0 + CB ? racc : ri;
+#pragma unroll
+            for (int k = 0; k < CB; ++k) ri = lane == c0 + k ? zb[k] : ri;
+        }
+        if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(8); }
+        // (4) publish columns c0 .. c0 + CB - 1 of L_jj and their reciprocal pivots (one lane:
+        // 64 lanes storing to one address serialise)
+#pragma unroll
+        for (int k = 0; k < CB; k += 2) *(f64x2*)(&Ls[lane][c0 + k]) = (f64x2){x[k], x[k + 1]};
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < CB; k += 2) *(f64x2*)(&invd[c0 + k]) = (f64x2){inv[k], inv[k + 1]};
+            lds_store_volatile(&prog, c0 + CB);     // (same wavefront: LDS stores stay in order)
         }
         PANEL_FENCE();
-        PANEL_STAMP(1);
-        int firstbad = 0x7fffffff;               // (uniform) first pivot that is not positive and finite
-        static_for<PB / CB>([&](auto cc_) {
-            constexpr int c0 = CB * decltype(cc_)::value;
-            // (1) the CB x CB diagonal block, as updated so far, and the CB right-hand-side entries
-            // into every lane (uniform registers)
-            double d[CB][CB], zb[CB];
-#pragma unroll
-            for (int r = 0; r < CB; ++r) {
-#pragma unroll
-                for (int q = 0; q <= r; ++q) d[r][q] = bcast_lane(ar[c0 + q], c0 + r);
-                zb[r] = bcast_lane(ri, c0 + r);
-            }
-            if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(6); }
-            // (2) its factor, computed by all lanes alike: the serial chain of CB pivots runs on
-            // registers alone -- no cross-lane step, no LDS round trip, no branch per pivot.  Per
-            // pivot: v_rsq_f64 seed, one third-order step (r (1 + e/2 + 3 e^2/8), e = 1 - p r^2:
-            // error e^3, four dependent operations), scale, update.  A pivot that is not positive
-            // and finite is recorded, not replaced: the factor is then undefined, as in LAPACK.
-            double inv[CB], sq[CB];
-#pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                const double pv = d[k][k];
-                const bool bad = !(pv > 0.0) || !(pv < INFINITY);
-                firstbad = (bad && firstbad == 0x7fffffff) ? c0 + k + 1 : firstbad;
-                double r = __builtin_amdgcn_rsq(pv);
-                {
-                    const double e = fma(-pv * r, r, 1.0);
-                    r = fma(r * e, fma(0.375, e, 0.5), r);
-                }
-                inv[k] = r;
-#pragma unroll
-                for (int i = k + 1; i < CB; ++i) d[i][k] *= r;
-#pragma unroll
-                for (int j = k + 1; j < CB; ++j)
-#pragma unroll
-                    for (int i = j; i < CB; ++i) d[i][j] = fma(-d[i][k], d[j][k], d[i][j]);
-                double dd = pv * r;                                  // (off the chain) sqrt(p), one Newton step
-                sq[k] = fma(0.5 * r, fma(-dd, dd, pv), dd);
-                double zacc = zb[k];                                 // forward solve riding along
-#pragma unroll
-                for (int m = 0; m < k; ++m) zacc = fma(-zb[m], d[k][m], zacc);
-                zb[k] = zacc * r;
-            }
-            if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(7); }
-            // (3) every lane solves its own row against it (rows of the block itself reproduce the
-            // factor bit for bit: same operations in the same order)
-            double x[CB];
-#pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                double sacc = ar[c0 + k];
-#pragma unroll
-                for (int m = 0; m < k; ++m) sacc = fma(-x[m], d[k][m], sacc);
-                sacc *= inv[k];
-                x[k] = lane == c0 + k ? sq[k] : (lane > c0 + k ? sacc : 0.0);
-                ar[c0 + k] = x[k];
-            }
-            {
-                double racc = ri;
-#pragma unroll
-                for (int k = 0; k < CB; ++k) racc = fma(-x[k], zb[k], racc);
-                ri = lane >= c0 + CB ? racc : ri;
-#pragma unroll
-                for (int k = 0; k < CB; ++k) ri = lane == c0 + k ? zb[k] : ri;
-            }
-            if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(8); }
-            // (4) publish columns c0 .. c0 + CB - 1 of L_jj and their reciprocal pivots (one lane:
-            // 64 lanes storing to one address serialise)
-#pragma unroll
-            for (int k = 0; k < CB; k += 2) *(f64x2*)(&Ls[lane][c0 + k]) = (f64x2){x[k], x[k + 1]};
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < CB; k += 2) *(f64x2*)(&invd[c0 + k]) = (f64x2){inv[k], inv[k + 1]};
-                lds_store_volatile(&prog, c0 + CB);     // (same wavefront: LDS stores stay in order)
-            }
-            PANEL_FENCE();
-            if (c0 == 0) { PANEL_STAMP(9); }
-            // (5) rank-CB update of the columns to the right; row j of the new columns comes back
-            // as broadcast reads, requested TR_AHEAD columns before their use
-            panel_trailing<c0>(ar, x, Ls);
-            if (c0 == 0) { PANEL_STAMP(10); }
-        });
-        PANEL_STAMP(2);
-        if (firstbad != 0x7fffffff && blockIdx.x == 0 && lane == 0)
-            atomicMin((unsigned int*)a.info, (unsigned int)(j0 + firstbad));
-        if (a.rhs) {
-            zblk[lane] = ri;
-            if (blockIdx.x == 0 && lane < bs) a.rhs[j0 + lane] = ri;
-        }
-        lds_store_volatile(&prog, PB + 1);
-        {
-            // L_jj back to the matrix, coalesced, from the published copy (every workgroup holds it:
-            // workgroup b stores the rows r = b mod gridDim.x)
-            double* dst = a.A + j0 * a.lda + j0 + lane;
-            for (int r = blockIdx.x; r < bs; r += gridDim.x)
-                if (lane <= r) dst[(long long)r * a.lda] = Ls[r][lane];
-        }
-        PANEL_STAMP(3);
-        return;
+        if (c0 == 0) { PANEL_STAMP(9); }
+        // (5) rank-CB update of the columns to the right; row j of the new columns comes back
+        // as broadcast reads, requested TR_AHEAD columns before their use
+        panel_trailing<c0>(ar, x, Ls);
+        if (c0 == 0) { PANEL_STAMP(10); }
+    });
+    PANEL_STAMP(2);
+    if (firstbad != 0x7fffffff && wb_index == 0 && lane == 0)
+        atomicMin((unsigned int*)a.info, (unsigned int)(j0 + firstbad));
+    if (a.rhs) {
+        zblk[lane] = ri;
+        if (wb_index == 0 && lane < bs) (a.dscr ? a.dscr + a.zoff : a.rhs)[j0 + lane] = ri;
     }
-
-    // ---------------- wavefront 1: the 64 panel rows of this workgroup ----------------
-    double x[PB];
+    lds_store_volatile(&prog, PB + 1);
     {
-        const double* src = a.A + (has_row ? row : j0) * a.lda + j0;
-#pragma unroll
-        for (int k = 0; k < PB; ++k) x[k] = (bs == PB && has_row) ? src[k] : 0.0;
+        // L_jj out, coalesced, from the published copy (every workgroup holds it: workgroup number
+        // wb_index of wb_count stores the rows r = wb_index mod wb_count) -- into the scratch blocks
+        // when siblings exist (PotrfArgs::dscr), else straight into the matrix
+        double* dst = a.dscr ? a.dscr + (j0 / PB) * (PB * PB) + lane : a.A + j0 * a.lda + j0 + lane;
+        const long long ldd = a.dscr ? PB : a.lda;
+        for (int r = wb_index; r < bs; r += wb_count)
+            if (lane <= r) dst[(long long)r * ldd] = Ls[r][lane];
     }
-    PANEL_FENCE();
+    PANEL_STAMP(3);
+#undef prog
+}
+
+__device__ __forceinline__ void panel_solve_wave(PotrfArgs& a, const long long j0, const long long row, const bool has_row,
+                                                 const int lane, double (&x)[PB], const double (*Ls)[PB + 2],
+                                                 const double* invd, const double* zblk, int* prog_p, const int wb_index) {
+#define prog (*prog_p)
     auto wait_prog = [&](int need) {
         while (lds_load_volatile(&prog) < need) __builtin_amdgcn_s_sleep(1);
         PANEL_FENCE();
@@ -326,48 +300,229 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
         }
     }
     PANEL_STAMP(5);
+#undef prog
 }
 
-// trailing update: tile (bi, bk), bi >= bk, of the blocks below/right of column block j:
-// A[ri.., rk..] -= L[ri.., j0..j0+64) * L[rk.., j0..j0+64)^T
-__global__ __launch_bounds__(256) void potrf_update_kernel(PotrfArgs a) {
+__global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
     potrf_select(a);
-    __shared__ __attribute__((aligned(16))) double lds[GEMM64_LDS_DOUBLES];
-    // linear tile index -> (bi, bk) in the lower triangle
-    const long long tix = blockIdx.x;
-    long long bi = (long long)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
-    while ((bi + 1) * (bi + 2) / 2 <= tix) ++bi;
-    while (bi * (bi + 1) / 2 > tix) --bi;
-    const long long bk = tix - bi * (bi + 1) / 2;
-    const long long base = a.j0 + PB;
+    __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];
+    __shared__ __attribute__((aligned(16))) double invd[PB];
+    __shared__ double zblk[PB];
+    __shared__ int prog;                 // columns published so far; PB + 1 once zblk is published too
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long j0 = a.j0;
+    const int bs = (int)((a.n - j0) < PB ? (a.n - j0) : PB);
+    const long long row = j0 + PB + (long long)blockIdx.x * PB + lane;
+    const bool has_row = row < a.n;
+    const int wb_index = blockIdx.x;
+    if (threadIdx.x == 0) prog = 0;
+    __syncthreads();
+
+    if (wv == 0) {
+        // ---------------- wavefront 0: the diagonal block ----------------
+        PANEL_STAMP(0);
+        double ar[PB];
+        const double ri = (a.rhs && lane < bs) ? a.rhs[j0 + lane] : 0.0;
+        if (bs == PB) {
+            // coalesced: lane = column (one 512-byte row of the block per load, all 64 in flight
+            // together), transposed to lane = row through Ls (free until the first columns are
+            // published).  A row-per-lane load touches 64 cache lines per instruction.
+            const double* src = a.A + j0 * a.lda + j0 + lane;
+            double t[PB];
+#pragma unroll
+            for (int r = 0; r < PB; ++r) t[r] = src[(long long)r * a.lda];
+#pragma unroll
+            for (int r = 0; r < PB; ++r) Ls[r][lane] = t[r];
+            PANEL_FENCE();
+#pragma unroll
+            for (int k = 0; k < PB; k += 2) {
+                const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
+                ar[k] = k <= lane ? v.x : 0.0;
+                ar[k + 1] = k + 1 <= lane ? v.y : 0.0;
+            }
+        } else {
+            const double* src = a.A + (j0 + (lane < bs ? lane : 0)) * a.lda + j0;
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                double v = 0.0;
+                if (lane < bs && k <= lane) v = src[k];
+                ar[k] = (lane < bs && k <= lane) ? v : (k == lane ? 1.0 : 0.0);
+            }
+        }
+        panel_factor_wave(a, j0, bs, lane, ar, ri, Ls, invd, zblk, &prog, wb_index, (int)gridDim.x);
+        return;
+    }
+
+    // ---------------- wavefront 1: the 64 panel rows of this workgroup ----------------
+    double x[PB];
+    {
+        const double* src = a.A + (has_row ? row : j0) * a.lda + j0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) x[k] = (bs == PB && has_row) ? src[k] : 0.0;
+    }
+    PANEL_FENCE();
+    panel_solve_wave(a, j0, row, has_row, lane, x, Ls, invd, zblk, &prog, wb_index);
+}
+
+// One launch per block step after the first: the trailing update of block column j AND the panel
+// step of block column j + 1 (look-ahead).  Workgroups 0 .. tb-1 own the first trailing tile
+// column -- the next diagonal block (workgroup 0) and the next panel rows (workgroups 1 ..) -- and
+// carry on with the panel step as soon as their tile is updated, while the other workgroups are
+// still updating the rest of the trailing matrix: a step costs max(update, first tile + panel)
+// instead of their sum.  There is no dependency between workgroups inside the launch: a panel
+// workgroup updates the next diagonal block ITSELF (a second 64x64x64 product, redundantly, as it
+// re-factorises it redundantly anyway), so nothing waits on a flag or a memory round trip.  The
+// updated tiles never go through memory either: accumulators -> LDS -> one row per lane.
+__global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
+    potrf_select(a);
+    __shared__ __attribute__((aligned(16))) double lds[GEMM64_LDS_DOUBLES];   // GEMM buffers / tile staging / Ls of the panel step
+    __shared__ __attribute__((aligned(16))) double invd[PB];
+    __shared__ double zblk[PB];
+    __shared__ int prog;
+    static_assert(GEMM64_LDS_DOUBLES >= PB * (PB + 2), "Ls aliases the GEMM buffers");
+    const long long base = a.j0 + PB;                     // first row / column of the trailing matrix
+    const long long tb = (a.n - base + PB - 1) / PB;      // its size in blocks
+    const bool first = (long long)blockIdx.x < tb;
+    long long bi, bk;
+    if (first) { bi = blockIdx.x; bk = 0; }
+    else {
+        // the other tiles: lower triangle of the (tb - 1) x (tb - 1) blocks below / right of tile (0, 0)
+        const long long tix = (long long)blockIdx.x - tb;
+        long long b2 = (long long)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+        while ((b2 + 1) * (b2 + 2) / 2 <= tix) ++b2;
+        while (b2 * (b2 + 1) / 2 > tix) --b2;
+        bi = b2 + 1;
+        bk = tix - b2 * (b2 + 1) / 2 + 1;
+    }
     const long long ri = base + bi * PB, rk = base + bk * PB;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-    // the tile's own elements are requested first: they are needed last
-    double cin[2][2][4], acc[2][2][4];
+    STEP_STAMP(0);
+    const int bs = (int)((a.n - base) < PB ? (a.n - base) : PB);
+    const double rhs_i = (first && w == 0 && a.rhs && lane < bs) ? a.rhs[base + lane] : 0.0;   // (needed late: requested now)
+    if (!first) {
+        // plain trailing tile; its own elements are requested first: they are needed last
+        double cin[2][2][4], v[2][2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
-                const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, r);
-                cin[i][j][r] = (gr < a.n && gc < a.n && gc <= gr) ? a.A[gr * a.lda + gc] : 0.0;
-                acc[i][j][r] = 0.0;
+                for (int r = 0; r < 4; ++r) {
+                    const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
+                    const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, r);
+                    cin[i][j][r] = (gr < a.n && gc < a.n && gc <= gr) ? a.A[gr * a.lda + gc] : 0.0;
+                    v[i][j][r] = 0.0;
+                }
+        apgp_gemm64_tile<false, false>(a.A + ri * a.lda + a.j0, a.lda, a.n - ri, a.A + rk * a.lda + a.j0, a.lda, a.n - rk,
+                                       0, PB, lds, v);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
+                    const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, r);
+                    if (gr < a.n && gc < a.n && gc <= gr) a.A[gr * a.lda + gc] = cin[i][j][r] - v[i][j][r];
+                }
+        return;
+    }
+    // first tile column.  A panel workgroup (bi > 0) also needs tile (0, 0), the next diagonal
+    // block: B B^T of the same B rows, riding along in the same product.
+    const bool two = bi != 0;
+    double v[2][2][4], v2[2][2][4];
+    {
+        double cin[2][2][4], cin2[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, r);
+                    const long long gr = ri + lr, gc = rk + lc;
+                    cin[i][j][r] = (gr < a.n && gc < a.n && gc <= gr) ? a.A[gr * a.lda + gc] : 0.0;
+                    cin2[i][j][r] = (two && lc <= lr) ? a.A[(base + lr) * a.lda + base + lc] : 0.0;   // (two: the block is full)
+                    v[i][j][r] = 0.0;
+                    v2[i][j][r] = 0.0;
+                }
+        apgp_gemm64_tile2<false, false, true>(a.A + ri * a.lda + a.j0, a.lda, a.n - ri, a.A + rk * a.lda + a.j0, a.lda,
+                                              a.n - rk, 0, PB, lds, v, v2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[i][j][r] = cin[i][j][r] - v[i][j][r];
+                    v2[i][j][r] = cin2[i][j][r] - v2[i][j][r];
+                }
+    }
+    // ---------------- first tile column: the panel step of block column `base` ----------------
+    STEP_STAMP(1);
+    double (*Ls)[PB + 2] = (double (*)[PB + 2])lds;       // (the GEMM ended with a barrier: its buffers are free)
+    const long long row = ri + lane;
+    const bool has_row = row < a.n;
+    double rowv[PB];        // panel row (solving wavefront) / diagonal-block row (factorising wavefront) of this lane
+    if (two) {
+        // own tile = 64 panel rows: through LDS into the solving wavefront's registers
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Ls[wr + 16 * i + apgp_mma16_row(lane)][wc + 16 * j + apgp_mma16_col(lane, r)] = v[i][j][r];
+        __syncthreads();
+        if (w == 1) {
+#pragma unroll
+            for (int k = 0; k < PB; k += 2) {
+                const f64x2 q = *(const f64x2*)(&Ls[lane][k]);
+                rowv[k] = has_row ? q.x : 0.0;
+                rowv[k + 1] = has_row ? q.y : 0.0;
             }
-    apgp_gemm64_tile<false, false>(a.A + ri * a.lda + a.j0, a.lda, a.n - ri, a.A + rk * a.lda + a.j0, a.lda, a.n - rk,
-                                   0, PB, lds, acc);
+        }
+        __syncthreads();
+    }
+    // the updated diagonal block, same way, for the factorising wavefront (two loops, not one
+    // with a select between the arrays: a select of element ADDRESSES keeps both arrays in memory)
+    if (two) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
-                const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, r);
-                if (gr < a.n && gc < a.n && gc <= gr) a.A[gr * a.lda + gc] = cin[i][j][r] - acc[i][j][r];
-            }
+                for (int r = 0; r < 4; ++r)
+                    Ls[wr + 16 * i + apgp_mma16_row(lane)][wc + 16 * j + apgp_mma16_col(lane, r)] = v2[i][j][r];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Ls[wr + 16 * i + apgp_mma16_row(lane)][wc + 16 * j + apgp_mma16_col(lane, r)] = v[i][j][r];
+    }
+    if (t == 0) prog = 0;
+    __syncthreads();
+    STEP_STAMP(2);
+    if (w >= 2 || (w == 1 && bi == 0)) return;           // (the diagonal tile has no panel rows)
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < PB; k += 2) {
+            const f64x2 q = *(const f64x2*)(&Ls[lane][k]);
+            rowv[k] = (lane < bs && k <= lane) ? q.x : ((k == lane) ? 1.0 : 0.0);
+            rowv[k + 1] = (lane < bs && k + 1 <= lane) ? q.y : ((k + 1 == lane) ? 1.0 : 0.0);
+        }
+        STEP_STAMP(3);
+        panel_factor_wave(a, base, bs, lane, rowv, rhs_i, Ls, invd, zblk, &prog, (int)bi, (int)tb);
+        STEP_STAMP(4);
+    } else {
+        PANEL_FENCE();
+        panel_solve_wave(a, base, row, has_row, lane, rowv, Ls, invd, zblk, &prog, (int)bi);
+        STEP_STAMP(5);
+    }
 }
 
 __global__ __launch_bounds__(256) void potrf_rhs_init_kernel(const double* y, double shift, double* rhs, long long n) {
@@ -375,9 +530,40 @@ __global__ __launch_bounds__(256) void potrf_rhs_init_kernel(const double* y, do
     if (i < n) rhs[i] = y[i] - shift;
 }
 
-__global__ void potrf_finish_kernel(int* info) {
-    info += blockIdx.x;
-    if (*(unsigned int*)info == 0xffffffffu) *info = 0;
+// info = UINT_MAX ("no failure yet") -> 0; factored diagonal blocks from the scratch into the matrix
+__global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
+    potrf_select(a);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *(unsigned int*)a.info == 0xffffffffu) *a.info = 0;
+    if (!a.dscr) return;
+    const long long j0 = (long long)blockIdx.x * PB;
+    const int bs = (int)((a.n - j0) < PB ? (a.n - j0) : PB);
+    const double* src = a.dscr + (long long)blockIdx.x * (PB * PB);
+    for (int e = threadIdx.x; e < PB * PB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (r < bs && c <= r) a.A[(j0 + r) * a.lda + j0 + c] = src[e];
+    }
+    if (a.rhs && threadIdx.x < bs) a.rhs[j0 + threadIdx.x] = a.dscr[a.zoff + j0 + threadIdx.x];
+}
+
+// stream-ordered scratch for the diagonal blocks, kept per (device, stream) and grown on demand:
+// calls on one stream are serialised, so they can share it; calls on different streams cannot
+static double* potrf_scratch(hipStream_t s, size_t doubles) {
+    struct Scr { double* p; size_t doubles; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Scr> tab;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    Scr& e = tab[std::make_pair(dev, s)];
+    if (e.doubles < doubles) {
+        if (e.p) (void)hipFreeAsync(e.p, s);
+        e.p = nullptr; e.doubles = 0;
+        const size_t want = doubles + doubles / 2;
+        double* p = nullptr;
+        if (hipMallocAsync((void**)&p, want * sizeof(double), s) != hipSuccess) return nullptr;
+        e.p = p; e.doubles = want;
+    }
+    return e.p;
 }
 
 // `batch` matrices A + b * batch_A (right-hand sides y - shifts[b] -> z + b * n) factorised by
@@ -398,17 +584,28 @@ static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t b
             hipLaunchKernelGGL(potrf_rhs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, shifts[b],
                                z + b * n, (long long)n);
     const long long nb = (n + PB - 1) / PB;
-    for (long long jb = 0; jb < nb; ++jb) {
-        a.j0 = jb * PB;
-        const long long below = n - (a.j0 + PB);
-        const unsigned pg = below > 0 ? (unsigned)((below + PB - 1) / PB) : 1u;
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg, (unsigned)batch), dim3(2 * PB), 0, s, a);
-        if (below > 0) {
-            const long long tb = (below + PB - 1) / PB;
-            hipLaunchKernelGGL(potrf_update_kernel, dim3((unsigned)(tb * (tb + 1) / 2), (unsigned)batch), dim3(256), 0, s, a);
+    // block column 0: panel step alone; then one launch per step = trailing update of column jb +
+    // panel step of column jb + 1 (potrf_step_kernel)
+    a.dscr = nullptr; a.zoff = nb * (long long)(PB * PB); a.batch_dscr = a.zoff + nb * PB;
+    if (nb > 1) {
+        a.dscr = potrf_scratch(s, (size_t)a.batch_dscr * (size_t)batch);
+        if (!a.dscr) {
+            apgp_set_error("apgp_potrf: scratch allocation failed");
+            return -2;
         }
     }
-    hipLaunchKernelGGL(potrf_finish_kernel, dim3((unsigned)batch), dim3(1), 0, s, info_dev);
+    {
+        a.j0 = 0;
+        const long long below = n - PB;
+        const unsigned pg = below > 0 ? (unsigned)((below + PB - 1) / PB) : 1u;
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg, (unsigned)batch), dim3(2 * PB), 0, s, a);
+    }
+    for (long long jb = 0; jb + 1 < nb; ++jb) {
+        a.j0 = jb * PB;
+        const long long tb = (n - (a.j0 + PB) + PB - 1) / PB;
+        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(tb + tb * (tb - 1) / 2), (unsigned)batch), dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(potrf_finish_kernel, dim3((unsigned)nb, (unsigned)batch), dim3(256), 0, s, a);
     APGP_CHECK_LAUNCH();
     return 0;
 }

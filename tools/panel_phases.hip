@@ -20,6 +20,12 @@ int main() {
         printf("rc %d | panel step at column 2048, workgroup 0, cycles after the factorising wavefront's start: block loaded %llu | potf2 done %llu | "
                "write-back + z-solve done %llu | (solving wavefront) panel solve done %llu | rows stored + rhs updated %llu\n", rc,
                s[1] - s[0], s[2] - s[0], s[3] - s[0], s[4] - s[0], s[5] - s[0]);
+        unsigned long long q[16];
+        (void)hipMemcpyFromSymbol(q, HIP_SYMBOL(apgp_step_stamps), sizeof(q));
+        printf("   fused step at column 2048 (10 ns ticks after the workgroup's start; workgroup 0 | workgroup 1): tile updated %lld | %lld ; diagonal tile updated %lld | %lld ; "
+               "factor starts %lld | %lld ; factor done %lld | %lld ; wg1 rows solved %lld ; wg1 started %lld after wg0\n",
+               (long long)(q[1] - q[0]), (long long)(q[7] - q[6]), (long long)(q[2] - q[0]), (long long)(q[8] - q[6]), (long long)(q[3] - q[0]), (long long)(q[9] - q[6]),
+               (long long)(q[4] - q[0]), (long long)(q[10] - q[6]), (long long)(q[11] - q[6]), (long long)(q[6] - q[0]));
         printf("   first column group: diagonal block broadcast %llu | its factor %llu | row solve %llu | published %llu | columns to the right updated %llu\n",
                s[6] - s[1], s[7] - s[6], s[8] - s[7], s[9] - s[8], s[10] - s[9]);
     }
