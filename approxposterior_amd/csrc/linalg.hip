@@ -5,6 +5,16 @@
 // GP._compute_alpha and GP.predict (gpUtils.py:78; utility.py:131,178,224).
 #include "apgp_common.h"
 #include "mma16.h"
+#include <type_traits>
+#include <utility>
+template <int... Is, class F>
+__device__ __forceinline__ void trtri_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void trtri_static_for(F&& f) {
+    trtri_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 // ---------------------------------------------------------------------------
 // sizes
@@ -356,29 +366,47 @@ extern "C" int apgp_winv_apply(const double* winv, int64_t ldw, int64_t n, const
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* L, long long n, long long ldl,
                                                         double* W, long long ldw) {
-    __shared__ double Lb[64][65];
-    __shared__ double Xb[64][65];
+    // lane c owns column c of X = L_jj^-1 in registers; row i of L_jj is the same for every lane
+    // and comes back as broadcast LDS reads (the bound: ~20 cycles per ds_read_b128 and wavefront,
+    // tools/lat_probe.hip).  Fully unrolled, x[k] = 0 above the diagonal, so the sum runs over all
+    // k < i in order: the same operations on the same values as a per-column loop from k = c.
+    __shared__ __attribute__((aligned(16))) double Lb[64][66];
     const long long j0 = (long long)blockIdx.x * 64;
     const int c = threadIdx.x;
-    for (int i = 0; i < 64; ++i) {
-        long long gr = j0 + i, gc = j0 + c;
-        double v = (i == c) ? 1.0 : 0.0;
-        if (gr < n && gc < n && c <= i) v = L[gr * ldl + gc];
-        Lb[i][c] = v;
+    __shared__ __attribute__((aligned(16))) double rinv[64];
+    {
+        double v[64];                                   // all 64 rows requested together: one latency
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const long long gr = j0 + r, gc = j0 + c;
+            v[r] = (gr < n && gc < n && c <= r) ? L[gr * ldl + gc] : ((r == c) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            Lb[r][c] = v[r];                            // (coalesced: lane = column)
+            if (r == c) rinv[c] = 1.0 / v[r];           // reciprocal pivots, as LAPACK's dtrti2 scales by -1/a_jj
+        }
     }
     __syncthreads();
-    for (int i = 0; i < 64; ++i) {
-        double v;
-        if (i < c) v = 0.0;
-        else if (i == c) v = 1.0 / Lb[c][c];
-        else {
-            double s = 0.0;
-            for (int k = c; k < i; ++k) s = fma(Lb[i][k], Xb[k][c], s);
-            v = -s / Lb[i][i];
-        }
-        Xb[i][c] = v;   // column c is private to this lane
-    }
-    for (int i = 0; i < 64; ++i) W[(j0 + i) * ldw + j0 + c] = Xb[i][c];
+    double x[64];
+    trtri_static_for<64>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        double srow = 0.0;
+        f64x2 lr[(i + 1) / 2 > 0 ? (i + 1) / 2 : 1];
+#pragma unroll
+        for (int k = 0; k + 1 < i + 1 && k < i; k += 2) lr[k / 2] = *(const f64x2*)(&Lb[i][k]);
+        const double ri = rinv[i];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < i; ++k) srow = fma((k & 1) ? lr[k / 2].y : lr[k / 2].x, x[k], srow);
+        x[i] = i < c ? 0.0 : (i == c ? ri : -srow * ri);
+        asm volatile("" : "+v"(x[i]));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int i = 0; i < 64; ++i) W[(j0 + i) * ldw + j0 + c] = x[i];
 }
 
 struct MergeArgs {
@@ -389,6 +417,7 @@ struct MergeArgs {
     int nb;      // number of 64-blocks
     int s;       // level: blocks per half
     int phase;   // 1: T = C * Ainv ; 2: W[second,first] = -Binv * T
+    int pair;    // two complementary tiles per workgroup (launches of >= 512 tiles)
 };
 
 // 64 x 64 output tile, 4 wavefronts (2 x 2), each 32 x 32 = 2 x 2 blocks of 16 x 16 on the
@@ -407,8 +436,8 @@ __global__ __launch_bounds__(256) void trtri_merge_kernel(MergeArgs a) {
     // The k range of a tile grows with its column block in phase 1 (k >= c) and with its row block
     // in phase 2 (k <= r): a workgroup takes the two tiles whose ranges add up to the same length
     // for every workgroup (block u and block s - 1 - u), so the launch is balanced by construction
-    // whatever the dispatch order.  (s = 1: one tile.)
-    const int ntile = a.s > 1 ? 2 : 1;
+    // whatever the dispatch order.  (Small launches: one tile per workgroup.)
+    const int ntile = a.pair ? 2 : 1;
     for (int h = 0; h < ntile; ++h) {
         long long bx = blockIdx.x, by = blockIdx.y;
         if (a.phase == 1) { if (h) bx = a.s - 1 - bx; }
@@ -492,7 +521,10 @@ extern "C" int apgp_trtri_pack(const double* L, int64_t n, int64_t ldl, double* 
         MergeArgs a;
         a.L = L; a.W = W; a.T = T; a.ldl = ldl; a.ldw = np; a.n = n; a.nb = nb; a.s = lev;
         int pairs = (nb + 2 * lev - 1) / (2 * lev);
-        const int half = lev > 1 ? lev / 2 : 1;      // two complementary tiles per workgroup (trtri_merge_kernel)
+        // two complementary tiles per workgroup once the launch fills the chip (trtri_merge_kernel);
+        // below that the second tile would only lengthen the launch
+        a.pair = (lev > 1 && (long long)lev * lev * pairs >= 512) ? 1 : 0;
+        const int half = a.pair ? lev / 2 : lev;
         a.phase = 1;
         hipLaunchKernelGGL(trtri_merge_kernel, dim3(half, lev, pairs), dim3(256), 0, s, a);
         a.phase = 2;

@@ -220,6 +220,30 @@ def test_nll_batch_is_bit_identical_to_single_evaluations(n, d):
     print("nll_batch N=%d: 7 evaluations %.2f ms batched, %.2f ms one by one" % (n, 1e3 * t_batch, 1e3 * t_single))
 
 
+def test_nll_batch_oversubscribed_is_bit_identical_to_single_evaluations():
+    """More matrices in one batched Cholesky than the chip holds workgroups for (120 x N=450:
+    120 x 28 tiles per step against ~512 resident workgroups), so sibling workgroups of one
+    matrix start at different times.  A panel workgroup reads the raw diagonal block when it
+    starts and the factored block is stored when another one ends: the result must not depend
+    on that order (potrf.hip routes the factored blocks through a scratch).  Bit-identical to
+    one-by-one evaluation."""
+    from approxposterior_amd import gpUtils
+    n, d, m = 450, 3, 120
+    rs = np.random.RandomState(11)
+    X = rs.uniform(-5, 5, size=(n, d))
+    y = np.sin(X).sum(axis=1) + 0.1 * rs.randn(n)
+    np.random.seed(3)
+    gp = gpUtils.defaultGP(X, y, fitAmp=True)
+    p_own = np.array(gp.get_parameter_vector())
+    P = np.array([p_own + 0.2 * rs.randn(len(p_own)) for _ in range(m)])
+    with np.errstate(all="ignore"):
+        batch = np.array([gp.nll_batch(P, y) for _ in range(3)])
+        single = np.array([gpUtils._nll(p, gp, y, None) for p in P])
+    assert np.all(np.isfinite(single))
+    for b in batch:
+        assert np.array_equal(b, single)
+
+
 def test_optimizegp_batched_restarts_equal_sequential():
     """gpUtils.optimizeGP with its restarts evaluated in lock-step on the device returns
     exactly the hyper-parameters of the reference's sequential loop (gpUtils.py:223-254)."""
