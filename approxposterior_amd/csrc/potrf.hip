@@ -61,23 +61,29 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
     if (a.dscr) a.dscr += (long long)blockIdx.y * a.batch_dscr;
 }
 
-// Panel step of block column j, two wavefronts per workgroup; workgroup b owns the 64 panel rows
+// Panel step of block column j, three wavefronts per workgroup; workgroup b owns the 64 panel rows
 // [j0 + 64 + 64 b, +64) and re-factorises the 64x64 diagonal block itself (it is the critical path
-// either way; redundancy saves a launch and a grid-wide dependency).
+// either way; redundancy removes every dependency between workgroups).
 //
-// Wavefront 0 factorises the diagonal block in REGISTERS: lane i holds row i (64 doubles),
-// right-looking, fully unrolled.  Per pivot k: the pivot is a v_readlane, its reciprocal square
-// root a v_rsq_f64 + two Newton steps (no IEEE sqrt + divide on the critical path), the scaled
-// column goes through a 512-byte LDS line and comes back as broadcast ds_read_b128 for the
-// rank-1 update.  One wavefront, in-order LDS: no barrier anywhere.  It publishes the factor as it
-// goes -- after pivot k column k of L_jj (Ls[.][k]), 1/L_kk (invd[k]) and the progress counter.
-// Wavefront 1 solves the workgroup's 64 panel rows, x L_jj^T = a, one row per lane against
-// broadcast reads of L_jj (four partial sums per dot product, the L values requested one stage
-// ahead), CONCURRENTLY and two pivots behind: row k of the solve needs row k of L_jj, final after
-// pivot k-1, and the prefetch of the next stage needs invd[k+1].  The panel solve (21.5 k cycles)
-// thus hides behind the factorisation (46 k) instead of following it (round 1: one wavefront did
-// both in turn, 89 k cycles per step; now ~62 k: 4.72 -> 4.05 ms at N = 4096, 0.98 -> 0.78 ms at
-// N = 1152).  Same arithmetic in the same order per element as the one-wavefront form.
+// Wavefront 0 (panel_factor_wave) factorises the diagonal block in REGISTERS: lane i holds row i,
+// right-looking, fully unrolled, in groups of CB = 4 columns.  Per group: the 4x4 diagonal
+// sub-block is broadcast (v_readlane) and factorised BY EVERY LANE ALIKE -- v_rsq_f64 + one
+// third-order step per pivot, no cross-lane step, no LDS round trip, no branch --, every lane solves
+// its own four entries against it (rows of the sub-block reproduce the factor bit for bit), the
+// group is published (columns of L_jj in Ls, reciprocal pivots in invd, progress counter), and the
+// columns to the right get their rank-4 update from broadcast ds_read_b128 (panel_trailing).  The
+// forward solve z = L^-1 (y - mean) rides along in the same groups.  One wavefront, in-order LDS:
+// no barrier anywhere.  (Round 1 / early round 2: one pivot at a time through an LDS line, 670
+// cycles per pivot; a 64-lane store to ONE LDS address serialises -- publishing invd from every
+// lane cost ~1000 cycles per group.)
+// Wavefront 1 (panel_solve_wave) solves the workgroup's 64 panel rows, x L_jj^T = a, one row per
+// lane, the same way and one group behind.
+// Wavefront 2 (panel_helper_wave) applies groups 0 .. 7 to columns 32 .. 63 of the diagonal block's
+// rows while wavefront 0 applies them to columns < 32 only, and hands the columns back before
+// group 8: the rank-4 updates are bound by uniform-address LDS reads PER WAVEFRONT (~20 cycles per
+// ds_read_b128, tools/lat_probe.hip), so a second wavefront nearly halves them (factorisation at
+// column 2048: 16.5 -> 12.8 us).
+// Same arithmetic in the same order per element whichever wavefront applies it.
 //
 // Scheduling fences for the straight-line code: the asm memory clobber stops the SelectionDAG
 // from hoisting the (address-independent) LDS reads of later steps, the sched_barrier stops the
@@ -110,16 +116,17 @@ __device__ __forceinline__ int lds_load_volatile(const int* p) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const int*)p) : "memory");
     return v;
 }
-// rank-CB update of columns C0 + CB .. PB - 1 of a register row `row` with the row's new entries
-// xs (columns C0 .. C0 + CB - 1): row[j] -= sum_k xs[k] L[j][C0 + k], k ascending.  Row j of the new
+// rank-CB update of columns J0 .. J1 - 1 of a register row with the row's new entries xs (columns
+// C0 .. C0 + CB - 1): row[j] -= sum_k xs[k] L[j][C0 + k], k ascending.  Row j of the new
 // columns is a broadcast read of the published factor.  Four columns advance together (a chain of
 // dependent f64 FMAs issues one per ~10 cycles, four independent ones one per ~4.4), two k per
 // step; the reads of a step are requested TR_AHEAD steps before their use.
 #define TR_AHEAD 4
-template <int C0>
-__device__ __forceinline__ void panel_trailing(double (&row)[PB], const double (&xs)[CB], const double (*Ls)[PB + 2]) {
-    constexpr int J0 = C0 + CB, NJ = PB - J0, NS = (NJ / 4) * (CB / 2);
-    static_assert(NJ % 4 == 0, "column groups of four");
+template <int C0, int J0, int J1, int OFF, int LEN>
+__device__ __forceinline__ void panel_trailing(double (&row)[LEN], const double (&xs)[CB], const double (*Ls)[PB + 2]) {
+    // columns J0 .. J1 - 1; row[j - OFF] holds column j
+    constexpr int NJ = J1 - J0, NS = (NJ > 0 ? NJ / 4 : 0) * (CB / 2);
+    static_assert(NJ <= 0 || NJ % 4 == 0, "column groups of four");
     if constexpr (NS > 0) {
         f64x2 lb[TR_AHEAD][4];
         auto request = [&](auto s_) {
@@ -132,29 +139,80 @@ __device__ __forceinline__ void panel_trailing(double (&row)[PB], const double (
         static_for<NS>([&](auto s_) {
             constexpr int s = decltype(s_)::value, g = s / (CB / 2), kp = s % (CB / 2), slot = s % TR_AHEAD;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) row[J0 + 4 * g + jj] = fma(-xs[2 * kp], lb[slot][jj].x, row[J0 + 4 * g + jj]);
+            for (int jj = 0; jj < 4; ++jj) row[J0 - OFF + 4 * g + jj] = fma(-xs[2 * kp], lb[slot][jj].x, row[J0 - OFF + 4 * g + jj]);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) row[J0 + 4 * g + jj] = fma(-xs[2 * kp + 1], lb[slot][jj].y, row[J0 + 4 * g + jj]);
+            for (int jj = 0; jj < 4; ++jj) row[J0 - OFF + 4 * g + jj] = fma(-xs[2 * kp + 1], lb[slot][jj].y, row[J0 - OFF + 4 * g + jj]);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) asm volatile("" : "+v"(row[J0 + 4 * g + jj]));
+            for (int jj = 0; jj < 4; ++jj) asm volatile("" : "+v"(row[J0 - OFF + 4 * g + jj]));
             if constexpr (s + TR_AHEAD < NS) request(std::integral_constant<int, s + TR_AHEAD>{});
             PANEL_FENCE();
         });
     }
 }
+// Helper wavefront of a panel step: while the factorising wavefront works through the column
+// groups left of HELPER_COL0 (and applies them to the columns left of it only), this one applies
+// them to columns HELPER_COL0 .. PB - 1 of the same 64 rows, one row per lane, from the groups as
+// they are published -- the rank-4 updates are bound by uniform-address LDS reads per wavefront
+// (~20 cycles per ds_read_b128), and a second wavefront has its own.  The updated columns go back
+// through the staging positions Ls[lane][HELPER_COL0 ..] (not yet published at that point).
+#define HELPER_COL0 32
+__device__ __forceinline__ void panel_helper_wave(const int bs, const int lane, double (*Ls)[PB + 2], int* prog_p, int* hflag_p) {
+#define prog (*prog_p)
+    double hi[PB - HELPER_COL0];
+#pragma unroll
+    for (int k = HELPER_COL0; k < PB; k += 2) {
+        const f64x2 q = *(const f64x2*)(&Ls[lane][k]);
+        hi[k - HELPER_COL0] = (lane < bs && k <= lane) ? q.x : ((k == lane) ? 1.0 : 0.0);
+        hi[k + 1 - HELPER_COL0] = (lane < bs && k + 1 <= lane) ? q.y : ((k + 1 == lane) ? 1.0 : 0.0);
+    }
+    PANEL_FENCE();
+    static_for<HELPER_COL0 / CB>([&](auto cc_) {
+        constexpr int c0 = CB * decltype(cc_)::value;
+        while (lds_load_volatile(&prog) < c0 + CB) __builtin_amdgcn_s_sleep(1);
+        PANEL_FENCE();
+        double xs[CB];
+#pragma unroll
+        for (int k = 0; k < CB; k += 2) {
+            const f64x2 q = *(const f64x2*)(&Ls[lane][c0 + k]);
+            xs[k] = q.x;
+            xs[k + 1] = q.y;
+        }
+        PANEL_FENCE();
+        panel_trailing<c0, HELPER_COL0, PB, HELPER_COL0, PB - HELPER_COL0>(hi, xs, Ls);
+    });
+#pragma unroll
+    for (int k = HELPER_COL0; k < PB; k += 2) *(f64x2*)(&Ls[lane][k]) = (f64x2){hi[k - HELPER_COL0], hi[k + 1 - HELPER_COL0]};
+    lds_store_volatile(hflag_p, 1);                      // (same wavefront: LDS stores stay in order)
+#undef prog
+}
+
 // The two wavefront roles of a panel step (block column j0, bs = its width).  The caller loads
 // the operands: `ar` = row `lane` of the diagonal block (zero above the diagonal, identity rows
 // past bs), `ri` = the right-hand-side entry of that row; `x` = panel row `row` of the workgroup.
 // Ls / invd / zblk / prog: the workgroup's LDS exchange area (prog zeroed before the first use).
 __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long j0, const int bs, const int lane,
                                                   double (&ar)[PB], double ri, double (*Ls)[PB + 2], double* invd,
-                                                  double* zblk, int* prog_p, const int wb_index, const int wb_count) {
+                                                  double* zblk, int* prog_p, const int* hflag_p, const int wb_index,
+                                                  const int wb_count) {
 #define prog (*prog_p)
     PANEL_FENCE();
     PANEL_STAMP(1);
     int firstbad = 0x7fffffff;               // (uniform) first pivot that is not positive and finite
     static_for<PB / CB>([&](auto cc_) {
         constexpr int c0 = CB * decltype(cc_)::value;
+        if constexpr (c0 == HELPER_COL0) {
+            // columns HELPER_COL0 .. of this row come back from the helper wavefront, updated with
+            // the groups before this one (panel_helper_wave)
+            while (lds_load_volatile(hflag_p) == 0) __builtin_amdgcn_s_sleep(1);
+            PANEL_FENCE();
+#pragma unroll
+            for (int k = HELPER_COL0; k < PB; k += 2) {
+                const f64x2 q = *(const f64x2*)(&Ls[lane][k]);
+                ar[k] = q.x;
+                ar[k + 1] = q.y;
+            }
+            PANEL_FENCE();
+        }
         // (1) the CB x CB diagonal block, as updated so far, and the CB right-hand-side entries
         // into every lane (uniform registers)
         double d[CB][CB], zb[CB];
@@ -230,7 +288,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
         if (c0 == 0) { PANEL_STAMP(9); }
         // (5) rank-CB update of the columns to the right; row j of the new columns comes back
         // as broadcast reads, requested TR_AHEAD columns before their use
-        panel_trailing<c0>(ar, x, Ls);
+        panel_trailing<c0, c0 + CB, (c0 < HELPER_COL0 ? HELPER_COL0 : PB), 0, PB>(ar, x, Ls);
         if (c0 == 0) { PANEL_STAMP(10); }
     });
     PANEL_STAMP(2);
@@ -283,7 +341,7 @@ __device__ __forceinline__ void panel_solve_wave(PotrfArgs& a, const long long j
             x[c0 + k] = xs[k];
         }
         PANEL_FENCE();
-        panel_trailing<c0>(x, xs, Ls);
+        panel_trailing<c0, c0 + CB, PB, 0, PB>(x, xs, Ls);
     });
     PANEL_STAMP(4);
     if (has_row) {
@@ -305,20 +363,20 @@ __device__ __forceinline__ void panel_solve_wave(PotrfArgs& a, const long long j
 #undef prog
 }
 
-__global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
+__global__ __launch_bounds__(192) void potrf_panel_kernel(PotrfArgs a) {
     potrf_select(a);
     __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];
     __shared__ __attribute__((aligned(16))) double invd[PB];
     __shared__ double zblk[PB];
     __shared__ int prog;                 // columns published so far; PB + 1 once zblk is published too
+    __shared__ int hflag;                // the helper wavefront's columns are back in Ls
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long j0 = a.j0;
     const int bs = (int)((a.n - j0) < PB ? (a.n - j0) : PB);
     const long long row = j0 + PB + (long long)blockIdx.x * PB + lane;
     const bool has_row = row < a.n;
     const int wb_index = blockIdx.x;
-    if (threadIdx.x == 0) prog = 0;
-    __syncthreads();
+    if (threadIdx.x == 0) { prog = 0; hflag = 0; }
 
     if (wv == 0) {
         // ---------------- wavefront 0: the diagonal block ----------------
@@ -335,23 +393,24 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
             for (int r = 0; r < PB; ++r) t[r] = src[(long long)r * a.lda];
 #pragma unroll
             for (int r = 0; r < PB; ++r) Ls[r][lane] = t[r];
-            PANEL_FENCE();
-#pragma unroll
-            for (int k = 0; k < PB; k += 2) {
-                const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
-                ar[k] = k <= lane ? v.x : 0.0;
-                ar[k + 1] = k + 1 <= lane ? v.y : 0.0;
-            }
         } else {
             const double* src = a.A + (j0 + (lane < bs ? lane : 0)) * a.lda + j0;
 #pragma unroll
-            for (int k = 0; k < PB; ++k) {
-                double v = 0.0;
-                if (lane < bs && k <= lane) v = src[k];
-                ar[k] = (lane < bs && k <= lane) ? v : (k == lane ? 1.0 : 0.0);
-            }
+            for (int k = 0; k < PB; ++k) Ls[lane][k] = (lane < bs && k <= lane) ? src[k] : 0.0;
         }
-        panel_factor_wave(a, j0, bs, lane, ar, ri, Ls, invd, zblk, &prog, wb_index, (int)gridDim.x);
+        __syncthreads();                                   // the block is staged (the helper reads its columns too)
+#pragma unroll
+        for (int k = 0; k < PB; k += 2) {
+            const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
+            ar[k] = (lane < bs && k <= lane) ? v.x : ((k == lane) ? 1.0 : 0.0);
+            ar[k + 1] = (lane < bs && k + 1 <= lane) ? v.y : ((k + 1 == lane) ? 1.0 : 0.0);
+        }
+        panel_factor_wave(a, j0, bs, lane, ar, ri, Ls, invd, zblk, &prog, &hflag, wb_index, (int)gridDim.x);
+        return;
+    }
+    if (wv == 2) {
+        __syncthreads();
+        panel_helper_wave(bs, lane, Ls, &prog, &hflag);
         return;
     }
 
@@ -362,6 +421,7 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(PotrfArgs a) {
 #pragma unroll
         for (int k = 0; k < PB; ++k) x[k] = (bs == PB && has_row) ? src[k] : 0.0;
     }
+    __syncthreads();
     PANEL_FENCE();
     panel_solve_wave(a, j0, row, has_row, lane, x, Ls, invd, zblk, &prog, wb_index);
 }
@@ -380,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
     __shared__ __attribute__((aligned(16))) double lds[GEMM64_LDS_DOUBLES];   // GEMM buffers / tile staging / Ls of the panel step
     __shared__ __attribute__((aligned(16))) double invd[PB];
     __shared__ double zblk[PB];
-    __shared__ int prog;
+    __shared__ int prog, hflag;
     static_assert(GEMM64_LDS_DOUBLES >= PB * (PB + 2), "Ls aliases the GEMM buffers");
     const long long base = a.j0 + PB;                     // first row / column of the trailing matrix
     const long long tb = (a.n - base + PB - 1) / PB;      // its size in blocks
@@ -506,10 +566,14 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
                 for (int r = 0; r < 4; ++r)
                     Ls[wr + 16 * i + apgp_mma16_row(lane)][wc + 16 * j + apgp_mma16_col(lane, r)] = v[i][j][r];
     }
-    if (t == 0) prog = 0;
+    if (t == 0) { prog = 0; hflag = 0; }
     __syncthreads();
     STEP_STAMP(2);
-    if (w >= 2 || (w == 1 && bi == 0)) return;           // (the diagonal tile has no panel rows)
+    if (w == 3 || (w == 1 && bi == 0)) return;           // (the diagonal tile has no panel rows)
+    if (w == 2) {
+        panel_helper_wave(bs, lane, Ls, &prog, &hflag);
+        return;
+    }
     if (w == 0) {
 #pragma unroll
         for (int k = 0; k < PB; k += 2) {
@@ -518,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
             rowv[k + 1] = (lane < bs && k + 1 <= lane) ? q.y : ((k + 1 == lane) ? 1.0 : 0.0);
         }
         STEP_STAMP(3);
-        panel_factor_wave(a, base, bs, lane, rowv, rhs_i, Ls, invd, zblk, &prog, (int)bi, (int)tb);
+        panel_factor_wave(a, base, bs, lane, rowv, rhs_i, Ls, invd, zblk, &prog, &hflag, (int)bi, (int)tb);
         STEP_STAMP(4);
     } else {
         PANEL_FENCE();
@@ -600,7 +664,7 @@ static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t b
         a.j0 = 0;
         const long long below = n - PB;
         const unsigned pg = below > 0 ? (unsigned)((below + PB - 1) / PB) : 1u;
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg, (unsigned)batch), dim3(2 * PB), 0, s, a);
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg, (unsigned)batch), dim3(3 * PB), 0, s, a);
     }
     for (long long jb = 0; jb + 1 < nb; ++jb) {
         a.j0 = jb * PB;
