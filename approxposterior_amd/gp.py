@@ -47,6 +47,9 @@ UTILITY_KINDS = {"agp": _lib.UTIL_AGP, "bape": _lib.UTIL_BAPE, "jones": _lib.UTI
 # (apgp_acquire_solve) is used instead.  ``GP.variance_mode`` = "solve" | "inverse"
 # overrides the choice for one object (tests); no environment variable is read.
 COND_SOLVE = 1.0e10
+# from this size on a missing L^-1 is formed before the first solve (gp._solve): apgp_trtri_pack is
+# 0.11 ms at N = 512 against 0.08 + 0.09 ms for the two triangular solves it replaces, 0.8 vs 3.2 ms at 4096
+W_FIRST_MIN_N = 512
 
 
 # ---------------------------------------------------------------------------
@@ -567,8 +570,14 @@ class GP(object):
         n = len(y)
         same = (self._alpha_y is not None and self._alpha_mean == self.mean.value
                 and np.array_equal(self._alpha_y, y))
-        via_w = (self._work is not None and (self.variance_mode or "") != "solve"
-                 and self.cond_estimate is not None and self.cond_estimate <= COND_SOLVE)
+        trust_w = ((self.variance_mode or "") != "solve" and self.cond_estimate is not None
+                   and self.cond_estimate <= COND_SOLVE)
+        need_solve = (not same or self._z is None) or (need_alpha and self._alpha is None)
+        if trust_w and need_solve and self._work is None and n >= W_FIRST_MIN_N:
+            # no inverse yet: L^-1 (0.8 ms at N = 4096) + a matrix-vector product per solve is cheaper
+            # than ONE single-workgroup triangular solve (1.6 ms), and the next sweep wants it anyway
+            self._ensure_linv()
+        via_w = self._work is not None and trust_w
         np64 = (n + 63) // 64 * 64
         with torch.cuda.device(dev):
             st = self._stream(torch)
