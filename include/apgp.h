@@ -110,7 +110,9 @@ int apgp_kernel_cross(const double* X1, int64_t m, const double* X2, int64_t n,
  * GP.log_likelihood needs right after a refactorisation: r^T K^-1 r = z.z), so
  * an _nll evaluation needs no separate triangular solve.
  * *info_dev (device int32): 0 = OK, k > 0 = leading minor of order k is not
- * positive definite (LAPACK dpotrf convention; george/SciPy raise LinAlgError). */
+ * positive definite (LAPACK dpotrf convention; george/SciPy raise LinAlgError).
+ * For n > 64 the library keeps a stream-ordered scratch (hipMallocAsync) of
+ * (n/64) (64^2 + 64) doubles per matrix per (device, stream), grown on demand. */
 int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, double shift, double* z,
                int32_t* info_dev, void* stream);
 
