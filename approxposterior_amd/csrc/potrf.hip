@@ -3,14 +3,15 @@
 // (every gpUtils._nll evaluation, gpUtils.py:74-78, and GP.compute,
 // gpUtils.py:178; approx.py:717).  rocSOLVER's dpotrf reaches ~2 TFLOP/s at
 // N = 4096 on MI355X (11.8 ms, dozens of tiny kernels); this version is ONE
-// launch per 64-column block step (2.1 ms):
+// launch per 64-column block step (1.9 ms):
 //   potrf_panel_kernel (block column 0 only) : the panel step alone;
 //   potrf_step_kernel(j)                     : trailing update of block column j, A_ik -= L_ij L_kj^T
 //           (64x64x64 tiles on the four-block f64 MFMA, mma16.h), AND the panel step of block
 //           column j + 1 by the workgroups of the first trailing tile column (look-ahead);
 //   panel step: every workgroup re-factorises the 64x64 diagonal block in registers (redundantly
 //           -- it is the critical path either way, and it removes every dependency between
-//           workgroups) while its second wavefront solves 64 panel rows against it;
+//           workgroups) while its second wavefront solves 64 panel rows against it and a third
+//           applies the first column groups to the right half of the diagonal block;
 //   potrf_finish_kernel: info, and the factored diagonal blocks from the scratch into the matrix.
 // info follows LAPACK: 0 = OK, k > 0 = leading minor of order k not positive
 // definite (first failing pivot).
