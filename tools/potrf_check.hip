@@ -5,7 +5,7 @@
 #include <vector>
 #include <cmath>
 int main() {
-    for (long long n : {64LL, 100LL, 128LL, 130LL, 200LL, 1024LL, 1100LL}) {
+    for (long long n : {1LL, 2LL, 31LL, 33LL, 63LL, 64LL, 65LL, 100LL, 127LL, 128LL, 129LL, 130LL, 191LL, 192LL, 193LL, 200LL, 257LL, 1024LL, 1100LL}) {
         std::vector<double> h(n * n, 0.0), y(n, 1.0), L(n * n, 0.0);
         for (long long i = 0; i < n; ++i) for (long long j = 0; j <= i; ++j) h[i * n + j] = (i == j) ? 4.0 + 0.001 * i : 0.5 / (1.0 + (i - j));
         // host reference
