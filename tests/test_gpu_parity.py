@@ -371,8 +371,11 @@ def test_alpha_through_resident_inverse(n, d, lib_loaded):
     tol = max(1e-12, 200 * np.linalg.cond(K) * EPS)
     want = gpo._compute_alpha(y, False)
     quad = float((y - np.median(y)) @ want)
-    ztz_t = gp._solve(y, need_alpha=True)                  # nothing resident yet: triangular solves
+    gp.variance_mode = "solve"                             # the triangular solves at every size (from N = 512
+    ztz_t = gp._solve(y, need_alpha=True)                  # on gp._solve would form L^-1 first, see W_FIRST_MIN_N)
     a_t = gp._alpha.cpu().numpy()
+    assert gp._work is None
+    gp.variance_mode = None
     gp._ensure_linv()
     gp._z = gp._alpha = gp._alpha_y = None
     ztz_w = gp._solve(y, need_alpha=True)                  # W resident: matrix-vector products
@@ -385,6 +388,48 @@ def test_alpha_through_resident_inverse(n, d, lib_loaded):
     mu, var = gp.predict(y, T, return_var=True)
     mo, vo = gpo.predict(y, T, return_var=True)
     assert np.abs(mu - mo).max() <= tol * np.abs(want).sum() and np.abs(var - vo).max() <= tol
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 129, 193, 257, 700, 1100])
+def test_cholesky_c_abi_against_lapack(n, lib_loaded):
+    """apgp_potrf through the C ABI at ragged sizes (one block, block boundaries +-1, the fused
+    update + panel launches with a partial last block): L against numpy's Cholesky of the same
+    matrix, the forward solve riding along against a triangular solve, and the bytes above the
+    diagonal untouched ("only the lower triangle of A is read and written")."""
+    import torch
+    from scipy.linalg import solve_triangular
+    rs = np.random.RandomState(100 + n)
+    X = rs.uniform(-3, 3, size=(n, 3))
+    d2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    K = np.exp(-0.5 * d2) + 1e-6 * np.eye(n)
+    y = rs.randn(n)
+    Lref = np.linalg.cholesky(K)
+    zref = solve_triangular(Lref, y - 0.25, lower=True)
+    A = np.tril(K) + np.triu(np.full((n, n), 7.5), 1)      # a sentinel above the diagonal
+    Ad = torch.from_numpy(A).cuda()
+    yd = torch.from_numpy(y).cuda()
+    zd = torch.empty(n, dtype=torch.float64, device="cuda")
+    info = torch.full((1,), -5, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):                                     # (second call: the cached scratch)
+        Ad.copy_(torch.from_numpy(A))
+        rc = lib_loaded.apgp_potrf(Ad.data_ptr(), n, n, yd.data_ptr(), 0.25, zd.data_ptr(), info.data_ptr(), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        L = Ad.cpu().numpy()
+        tol = 50 * np.linalg.cond(K) * EPS
+        assert np.abs(np.tril(L) - Lref).max() <= tol * np.abs(Lref).max()
+        assert np.array_equal(np.triu(L, 1), np.triu(A, 1))
+        assert np.abs(zd.cpu().numpy() - zref).max() <= tol * max(1.0, np.abs(zref).max())
+    # not positive definite: LAPACK's info (first failing leading minor)
+    B = np.tril(K)
+    kbad = n // 2
+    B[kbad, kbad] = -1.0
+    Ad.copy_(torch.from_numpy(B))
+    assert lib_loaded.apgp_potrf(Ad.data_ptr(), n, n, None, 0.0, None, info.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(info.item()) == kbad + 1
 
 
 @pytest.mark.parametrize("m", [5000, 40000])
