@@ -617,6 +617,12 @@ def test_illconditioned_uses_solve_path(golden_dir, lib_loaded):
     assert u_true[bi] <= u_true.min() + 0.3 * abs(u_true.min())
 
 
+def make_full_logdet(make, X):
+    g = make()
+    g.compute(X)
+    return g.log_determinant
+
+
 def test_incremental_factor_extension(lib_loaded):
     """Appending design points (approx.py:693-717): the O(N^2) factor extension
     (compute(x, previous=old_gp)) must agree with a full refactorisation, fall back
@@ -627,7 +633,11 @@ def test_incremental_factor_extension(lib_loaded):
         return agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 8.0), ndim=8), fit_mean=True,
                       mean=np.median(y), white_noise=-12, fit_white_noise=False)
     old = make(); old.compute(X[:690])
-    ext = make(); ext.compute(X, previous=old)
+    ext = make()
+    ext.extend_max_rows = 64              # (by cost, ten rows at N = 700 would be refactorised)
+    ext.compute(X, previous=old)
+    one = make(); one.compute(X[:691], previous=old)      # the default rule appends a single row
+    assert one._L.shape == (691, 691) and np.isclose(one.log_determinant, make_full_logdet(make, X[:691]), rtol=1e-12)
     full = make(); full.compute(X)
     assert ext._L.shape == (700, 700)
     assert np.isclose(ext.log_determinant, full.log_determinant, rtol=1e-12)
