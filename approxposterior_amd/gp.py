@@ -450,6 +450,10 @@ class GP(object):
             return False
         torch, dev, lib = self._rt()
         ks = self._kernel_struct()
+        w_prev = None
+        if (getattr(prev, "_work", None) is not None and (prev.variance_mode or "") != "solve"
+                and prev.cond_estimate is not None and prev.cond_estimate <= COND_SOLVE):
+            w_prev = prev._work
         self._reset_device_state()
         self._computed = False
         with torch.cuda.device(dev):
@@ -465,8 +469,15 @@ class GP(object):
                 # no host round trip per row (a failed pivot is reported through `info`)
                 _lib.check(lib.apgp_kernel_cross(self._x_d[j:].data_ptr(), 1, self._x_d.data_ptr(), j,
                                                  ctypes.byref(ks), row.data_ptr(), n1, st), "apgp_kernel_cross")
-                _lib.check(lib.apgp_trsv(L.data_ptr(), j, n1, row.data_ptr(), 0.0, 0, L[j].data_ptr(),
-                                         ss.data_ptr(), st), "apgp_trsv(append)")
+                if j == n0 and w_prev is not None:
+                    # the previous fit's dense L^-1 is resident (a sweep ran on it): l = W k is an
+                    # HBM-rate matrix-vector product (18 us at N = 4096; the solve: 1.6 ms)
+                    _lib.check(lib.apgp_winv_apply(w_prev.data_ptr(), (n0 + 63) // 64 * 64, n0, row.data_ptr(), 0.0,
+                                                   0, L[j].data_ptr(), ss.data_ptr(), None, st),
+                               "apgp_winv_apply(append)")
+                else:
+                    _lib.check(lib.apgp_trsv(L.data_ptr(), j, n1, row.data_ptr(), 0.0, 0, L[j].data_ptr(),
+                                             ss.data_ptr(), st), "apgp_trsv(append)")
                 kxx = ks.amp            # k(x_new, x_new): amplitude + the linear term's sum_d (x_d^2)^P
                 if ks.lin_coef != 0.0:
                     kxx += ks.lin_coef * float(np.sum((self._x[j] * self._x[j]) ** ks.lin_order))

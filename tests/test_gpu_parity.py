@@ -636,7 +636,10 @@ def test_incremental_factor_extension(lib_loaded):
     ext = make()
     ext.extend_max_rows = 64              # (by cost, ten rows at N = 700 would be refactorised)
     ext.compute(X, previous=old)
-    one = make(); one.compute(X[:691], previous=old)      # the default rule appends a single row
+    one = make(); one.compute(X[:691], previous=old)      # the default rule appends a single row (triangular solve)
+    old._ensure_linv()                                    # with L^-1 resident the row is a matrix-vector product
+    onew = make(); onew.compute(X[:691], previous=old)
+    assert np.abs(onew._L[690].cpu().numpy() - one._L[690].cpu().numpy()).max() <= 1e-10 * np.abs(one._L[690].cpu().numpy()).max()
     assert one._L.shape == (691, 691) and np.isclose(one.log_determinant, make_full_logdet(make, X[:691]), rtol=1e-12)
     full = make(); full.compute(X)
     assert ext._L.shape == (700, 700)
