@@ -82,7 +82,47 @@ __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
     }
     __syncthreads();
 
-    // GP mean of the point whose scaled coordinates are p[0..DPAD): one wavefront
+    // GP means of TWO points (scaled coordinates p0 / p1[0..DPAD)) by one wavefront: every training
+    // row read from LDS serves both (the stream is 80 B per row and is read by all 16 wavefronts of
+    // every half-step: with one point per pass the LDS, not the arithmetic, set the pace).  Each
+    // point's sum runs in the same order as a single-point pass.
+    auto gp_mean2 = [&](const double* p0, const double* p1, double& m0, double& m1) {
+        double t0[DPAD], t1[DPAD];
+#pragma unroll
+        for (int d = 0; d < DPAD; ++d) { t0[d] = p0[d]; t1[d] = p1[d]; }
+        double acc0 = 0.0, acc1 = 0.0;
+        const int nn = (int)a.n;
+        for (int k = lane; k < nn; k += 64) {
+            const double* xr = (XLDS ? (const double*)xsl : a.xs) + k * XS;
+            double xv[DPAD];
+#pragma unroll
+            for (int d = 0; d < DPAD; ++d) xv[d] = xr[d];
+            const double al = xr[DPAD];
+            double s0 = 0.0, s03 = 0.0, s1 = 0.0, s13 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DPAD; d += 2) {
+                const double a0 = t0[d] - xv[d], a1 = t0[d + 1] - xv[d + 1];
+                const double b0 = t1[d] - xv[d], b1 = t1[d + 1] - xv[d + 1];
+                s0 = fma(a0, a0, s0); s03 = fma(a1, a1, s03);
+                s1 = fma(b0, b0, s1); s13 = fma(b1, b1, s13);
+            }
+            double kv0 = a.amp * apgp_exp(-(s0 + s03), etab);
+            double kv1 = a.amp * apgp_exp(-(s1 + s13), etab);
+            if (a.lin_coef != 0.0) {
+                double ls;
+                APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, t0[d_] * xv[d_] * a.lw[d_]);
+                kv0 = fma(a.lin_coef, ls, kv0);
+                APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, t1[d_] * xv[d_] * a.lw[d_]);
+                kv1 = fma(a.lin_coef, ls, kv1);
+            }
+            acc0 = fma(kv0, al, acc0);
+            acc1 = fma(kv1, al, acc1);
+        }
+        for (int o = 32; o > 0; o >>= 1) { acc0 += __shfl_xor(acc0, o); acc1 += __shfl_xor(acc1, o); }
+        m0 = acc0 + a.mean;
+        m1 = acc1 + a.mean;
+    };
+    // one point per pass (start-up; and D > 8, where two points' registers do not fit 16 wavefronts)
     auto gp_mean = [&](const double* p) {
         double tt[DPAD];
 #pragma unroll
@@ -152,10 +192,25 @@ __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
                 uacc[t] = u01(c2[0], c2[1]);
             }
             __syncthreads();
-            for (int i = wv; i < H; i += 16) {
-                double m = -INFINITY;
-                if (qok[i]) m = gp_mean(qs[i]);         // wave-uniform branch
-                if (lane == 0) lpq[i] = m;
+            if constexpr (DPAD > 8) {
+                for (int i = wv; i < H; i += 16) {
+                    double m = -INFINITY;
+                    if (qok[i]) m = gp_mean(qs[i]);         // wave-uniform branch
+                    if (lane == 0) lpq[i] = m;
+                }
+            } else
+            for (int i = wv; i < H; i += 32) {
+                // proposals i and i + 16 of this wavefront in one pass over the training stream
+                const int i1 = i + 16;
+                const bool ok0 = qok[i] != 0, ok1 = i1 < H && qok[i1] != 0;     // wave-uniform
+                double m0 = -INFINITY, m1 = -INFINITY;
+                if (ok0 && ok1) gp_mean2(qs[i], qs[i1], m0, m1);
+                else if (ok0) m0 = gp_mean(qs[i]);
+                else if (ok1) m1 = gp_mean(qs[i1]);
+                if (lane == 0) {
+                    lpq[i] = m0;
+                    if (i1 < H) lpq[i1] = m1;
+                }
             }
             __syncthreads();
             if (t < H) {
