@@ -25,6 +25,12 @@ struct GramArgs {
     double* K;
     long long n, ldk;
     KernConst kc;
+    // optional (apgp_nll_eval): the Cholesky's right-hand side z = y - shift and its info word are
+    // initialised by this launch instead of a memset and a kernel of their own
+    const double* y;
+    double* z;
+    int* info;
+    double shift;
 };
 
 // 64 x 64 output tile per workgroup, 256 threads: thread = (column c, row
@@ -43,6 +49,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     while ((bi + 1) * (bi + 2) / 2 <= tix) ++bi;
     while (bi * (bi + 1) / 2 > tix) --bi;
     const long long i0 = bi * 64, j0 = (tix - bi * (bi + 1) / 2) * 64;
+    if (a.z && j0 == 0 && t < 64 && i0 + t < a.n) a.z[i0 + t] = a.y[i0 + t] - a.shift;    // (tile column 0 covers all rows)
+    if (a.info && tix == 0 && t == 0) *(unsigned int*)a.info = 0xffffffffu;               // "no failure yet" (potrf.hip)
     for (int e = t; e < 64 * DPAD; e += 256) {
         int r = e / DPAD, d = e % DPAD;
         long long gi = i0 + r, gj = j0 + r;
@@ -84,13 +92,16 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     }
 }
 
-extern "C" int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern, double* K,
-                         int64_t ldk, void* stream) {
+// Gram matrix; with z != NULL also z = y - shift and *info_dev = "no failure yet" for the
+// factorisation that follows (apgp_nll_eval: two launches fewer per evaluation)
+int apgp_gram_with_rhs(const double* X, int64_t n, const apgp_kernel_t* kern, double* K, int64_t ldk,
+                       const double* y, double shift, double* z, int32_t* info_dev, void* stream) {
     APGP_CHECK_ARG(X && K && kern, "null pointer");
     APGP_CHECK_ARG(n >= 1 && ldk >= n, "n >= 1 and ldk >= n required");
     GramArgs a;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &a.kc) == 0, "kernel parameters");
     a.X = X; a.K = K; a.n = n; a.ldk = ldk;
+    a.y = y; a.z = z; a.info = info_dev; a.shift = shift;
     const long long nb = (n + 63) / 64;
     dim3 grid((unsigned)(nb * (nb + 1) / 2)), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -102,6 +113,11 @@ extern "C" int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern, 
     }
     APGP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern, double* K,
+                         int64_t ldk, void* stream) {
+    return apgp_gram_with_rhs(X, n, kern, K, ldk, NULL, 0.0, NULL, NULL, stream);
 }
 
 

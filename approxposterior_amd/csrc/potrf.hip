@@ -47,6 +47,7 @@ struct PotrfArgs {
     // workgroup reads the raw block from A when it starts and stores rows of the factor when it ends;
     // sibling workgroups are not guaranteed to start together, so the factor goes here and is copied
     // into A by potrf_finish_kernel.
+    double* out5;            // optional (apgp_nll_eval): potrf_finish_kernel also writes the 5-value fit summary
     double* dscr;
     long long batch_dscr;    // per matrix: nb * 64 * 64 factor blocks, then nb * 64 entries of the forward solve (same hazard)
     long long zoff;          // offset of the latter
@@ -60,6 +61,7 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
     if (a.rhs) a.rhs += (long long)blockIdx.y * a.batch_rhs;
     a.info += blockIdx.y;
     if (a.dscr) a.dscr += (long long)blockIdx.y * a.batch_dscr;
+    if (a.out5) a.out5 += 5 * (long long)blockIdx.y;
 }
 
 // Panel step of block column j, three wavefronts per workgroup; workgroup b owns the 64 panel rows
@@ -597,10 +599,53 @@ __global__ __launch_bounds__(256) void potrf_rhs_init_kernel(const double* y, do
     if (i < n) rhs[i] = y[i] - shift;
 }
 
-// info = UINT_MAX ("no failure yet") -> 0; factored diagonal blocks from the scratch into the matrix
+// info = UINT_MAX ("no failure yet") -> 0; factored diagonal blocks from the scratch into the matrix;
+// with a.out5 the fit summary of apgp_fit_summary (2 sum log L_ii | min L_ii | max L_ii | z.z | info)
+// as well, by workgroup 0, with the operations of linalg.hip's logdet_kernel in the same order: its
+// 1024 threads are four "virtual" threads per thread here (v = t + 256 q belongs to wavefront
+// v / 64 = t / 64 + 4 q, lane t % 64), so every butterfly and the final sum over 16 wavefront
+// partials see the same operands.
 __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
     potrf_select(a);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && *(unsigned int*)a.info == 0xffffffffu) *a.info = 0;
+    __shared__ double ssum[16], smin[16], smax[16], szz[16];
+    __shared__ int sinfo;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (*(unsigned int*)a.info == 0xffffffffu) *a.info = 0;
+        sinfo = *a.info;
+    }
+    if (blockIdx.x == 0 && a.out5) {
+        const int t = threadIdx.x;
+        const double* zsrc = a.rhs ? (a.dscr ? a.dscr + a.zoff : a.rhs) : nullptr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double sl = 0.0, mn = INFINITY, mx = -INFINITY, zz = 0.0;
+            for (long long i = t + 256 * q; i < a.n; i += 1024) {
+                const double d = a.dscr ? a.dscr[(i / PB) * (PB * PB) + (i % PB) * (PB + 1)] : a.A[i * a.lda + i];
+                sl += log(d);
+                mn = fmin(mn, d);
+                mx = fmax(mx, d);
+                if (zsrc) zz = fma(zsrc[i], zsrc[i], zz);
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                sl += __shfl_xor(sl, o);
+                zz += __shfl_xor(zz, o);
+                mn = fmin(mn, __shfl_xor(mn, o));
+                mx = fmax(mx, __shfl_xor(mx, o));
+            }
+            const int w = (t >> 6) + 4 * q;
+            if ((t & 63) == 0) { ssum[w] = sl; smin[w] = mn; smax[w] = mx; szz[w] = zz; }
+        }
+        __syncthreads();
+        if (t == 0) {
+            double sl = 0.0, zz = 0.0, mn = INFINITY, mx = -INFINITY;
+            for (int i = 0; i < 16; ++i) { sl += ssum[i]; zz += szz[i]; mn = fmin(mn, smin[i]); mx = fmax(mx, smax[i]); }
+            a.out5[0] = 2.0 * sl;
+            a.out5[1] = mn;
+            a.out5[2] = mx;
+            a.out5[3] = zz;
+            a.out5[4] = (double)sinfo;
+        }
+    }
     if (!a.dscr) return;
     const long long j0 = (long long)blockIdx.x * PB;
     const int bs = (int)((a.n - j0) < PB ? (a.n - j0) : PB);
@@ -636,17 +681,20 @@ static double* potrf_scratch(hipStream_t s, size_t doubles) {
 // `batch` matrices A + b * batch_A (right-hand sides y - shifts[b] -> z + b * n) factorised by
 // the same launches: gridDim.y = batch.  The Cholesky of one small matrix is a chain of
 // latency-bound steps that leaves most of the chip idle, so a batch costs little more than one.
+// pre_init: info and z = y - shift were initialised by the caller's Gram launch (apgp_gram_with_rhs);
+// out5 != NULL: the finish kernel also writes the fit summary (5 doubles per matrix)
 static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t batch_A, const double* y,
-                     const double* shifts, double* z, int32_t* info_dev, hipStream_t s) {
+                     const double* shifts, double* z, int32_t* info_dev, hipStream_t s, bool pre_init = false,
+                     double* out5 = nullptr) {
     // info = UINT_MAX means "no failure yet"; normalised to 0 by the caller-visible finish kernel
-    if (hipMemsetAsync(info_dev, 0xff, sizeof(int32_t) * batch, s) != hipSuccess) {
+    if (!pre_init && hipMemsetAsync(info_dev, 0xff, sizeof(int32_t) * batch, s) != hipSuccess) {
         apgp_set_error("apgp_potrf: memset failed");
         return -2;
     }
     PotrfArgs a;
-    a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = 0.0; a.info = info_dev;
+    a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
     a.batch_A = batch_A; a.batch_rhs = n;
-    if (z)
+    if (z && !pre_init)
         for (int64_t b = 0; b < batch; ++b)
             hipLaunchKernelGGL(potrf_rhs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, shifts[b],
                                z + b * n, (long long)n);
@@ -690,20 +738,20 @@ extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, do
 // stream synchronisation.  Powell / Nelder-Mead call this hundreds to thousands of times
 // per fit; at N = 50 the separate calls' host overhead was as long
 // as the kernels themselves.
-extern "C" int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern, double* K, int64_t ldk, void* stream);
-extern "C" int apgp_fit_summary(const double* L, int64_t n, int64_t ldl, const double* z, const int32_t* info_dev,
-                                double* out5, void* stream);
+int apgp_gram_with_rhs(const double* X, int64_t n, const apgp_kernel_t* kern, double* K, int64_t ldk,
+                       const double* y, double shift, double* z, int32_t* info_dev, void* stream);   // gram.hip
 extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern, const double* y, double mean,
                              double* K, double* z, int32_t* info_dev, double* out5_dev, double* out5_host,
                              void* stream) {
     APGP_CHECK_ARG(X && kern && y && K && z && info_dev && out5_dev && out5_host, "null pointer");
-    int rc = apgp_gram(X, n, kern, K, n, stream);
-    if (rc != 0) return rc;
-    rc = apgp_potrf(K, n, n, y, mean, z, info_dev, stream);
-    if (rc != 0) return rc;
-    rc = apgp_fit_summary(K, n, n, z, info_dev, out5_dev, stream);
+    APGP_CHECK_ARG(n >= 1, "n >= 1 required");
+    // three launches fewer than the separate calls: the Gram launch initialises the right-hand side
+    // and the info word, the Cholesky's last launch writes the summary
+    int rc = apgp_gram_with_rhs(X, n, kern, K, n, y, mean, z, info_dev, stream);
     if (rc != 0) return rc;
     hipStream_t s = (hipStream_t)stream;
+    rc = potrf_run(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, out5_dev);
+    if (rc != 0) return rc;
     if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         apgp_set_error("apgp_nll_eval: D2H copy failed");
@@ -725,11 +773,9 @@ extern "C" int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch, co
     APGP_CHECK_ARG(n >= 1, "n >= 1 required");
     int rc;
     for (int64_t b = 0; b < batch; ++b)
-        if ((rc = apgp_gram(X, n, kerns + b, K + b * n * n, n, stream)) != 0) return rc;
-    if ((rc = potrf_run(K, n, n, batch, n * n, y, means, z, info_dev, (hipStream_t)stream)) != 0) return rc;
-    for (int64_t b = 0; b < batch; ++b)
-        if ((rc = apgp_fit_summary(K + b * n * n, n, n, z + b * n, info_dev + b, out5_dev + 5 * b, stream)) != 0) return rc;
+        if ((rc = apgp_gram_with_rhs(X, n, kerns + b, K + b * n * n, n, y, means[b], z + b * n, info_dev + b, stream)) != 0) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = potrf_run(K, n, n, batch, n * n, y, means, z, info_dev, s, true, out5_dev)) != 0) return rc;
     if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double) * batch, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         apgp_set_error("apgp_nll_eval_batch: D2H copy failed");
