@@ -686,6 +686,10 @@ static double* potrf_scratch(hipStream_t s, size_t doubles) {
 static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t batch_A, const double* y,
                      const double* shifts, double* z, int32_t* info_dev, hipStream_t s, bool pre_init = false,
                      double* out5 = nullptr) {
+    // One factorisation's launches are enqueued as a unit: two host threads on the same stream (ctypes
+    // releases the GIL) must not interleave theirs -- they share the stream's scratch (potrf_scratch).
+    static std::mutex enqueue_mu;
+    std::lock_guard<std::mutex> enqueue_lock(enqueue_mu);
     // info = UINT_MAX means "no failure yet"; normalised to 0 by the caller-visible finish kernel
     if (!pre_init && hipMemsetAsync(info_dev, 0xff, sizeof(int32_t) * batch, s) != hipSuccess) {
         apgp_set_error("apgp_potrf: memset failed");

@@ -244,6 +244,37 @@ def test_nll_batch_oversubscribed_is_bit_identical_to_single_evaluations():
         assert np.array_equal(b, single)
 
 
+def test_nll_from_concurrent_host_threads():
+    """Two host threads evaluating _nll on their own GP objects at the same time (ctypes releases
+    the GIL; both enqueue on the current stream): each factorisation's launches must stay a unit --
+    the Cholesky keeps per-stream scratch -- and every value must equal the single-threaded one."""
+    import threading
+    from approxposterior_amd import gpUtils
+    n, d = 200, 3
+    rs = np.random.RandomState(21)
+    X = rs.uniform(-5, 5, size=(n, d))
+    y = np.sin(X).sum(axis=1) + 0.1 * rs.randn(n)
+    np.random.seed(4)
+    gps = [gpUtils.defaultGP(X, y, fitAmp=True) for _ in range(2)]
+    p0 = np.array(gps[0].get_parameter_vector())
+    P = [np.array([p0 + 0.1 * rs.randn(len(p0)) for _ in range(60)]) for _ in range(2)]
+    with np.errstate(all="ignore"):
+        want = [np.array([gpUtils._nll(p, gps[k], y, None) for p in P[k]]) for k in range(2)]
+    got = [None, None]
+
+    def work(k):
+        with np.errstate(all="ignore"):
+            got[k] = np.array([gpUtils._nll(p, gps[k], y, None) for p in P[k]])
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert np.array_equal(got[k], want[k])
+
+
 def test_optimizegp_batched_restarts_equal_sequential():
     """gpUtils.optimizeGP with its restarts evaluated in lock-step on the device returns
     exactly the hyper-parameters of the reference's sequential loop (gpUtils.py:223-254)."""
