@@ -432,6 +432,54 @@ def test_cholesky_c_abi_against_lapack(n, lib_loaded):
     assert int(info.item()) == kbad + 1
 
 
+@pytest.mark.parametrize("n", [1, 63, 65, 130, 700, 2100])
+def test_triangular_inverse_c_abi_against_lapack(n, lib_loaded):
+    """apgp_trtri_pack through the C ABI: the dense W = L^-1 it leaves behind against a triangular
+    solve with the identity -- one block, block boundaries +-1, several merge levels, and N = 2100
+    (33 blocks: the top merge level takes the paired-tile path with a ragged last block)."""
+    import torch
+    from scipy.linalg import solve_triangular
+    rs = np.random.RandomState(300 + n)
+    X = rs.uniform(-3, 3, size=(n, 3))
+    d2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    K = np.exp(-0.5 * d2) + 1e-4 * np.eye(n)
+    L = np.linalg.cholesky(K)
+    Wref = solve_triangular(L, np.eye(n), lower=True)
+    Ld = torch.from_numpy(L).cuda()
+    work = torch.empty(int(lib_loaded.apgp_trtri_work_len(n)), dtype=torch.float64, device="cuda")
+    packed = torch.empty(int(lib_loaded.apgp_packed_linv_len(n)), dtype=torch.float64, device="cuda")
+    Wd = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib_loaded.apgp_trtri_pack(Ld.data_ptr(), n, n, work.data_ptr(), packed.data_ptr(), Wd.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    W = Wd.cpu().numpy()
+    assert np.array_equal(np.triu(W, 1), np.zeros((n, n)))
+    # forward error of a triangular inverse: ~ cond(L) eps relative to |W|
+    tol = 50 * np.linalg.cond(L) * EPS
+    assert np.abs(W - Wref).max() <= tol * np.abs(Wref).max()
+
+
+@pytest.mark.parametrize("n,d", [(1300, 5), (257, 2)])
+def test_gradient_many_tiles(n, d, lib_loaded):
+    """K4 beyond the fixtures' sizes: K^-1 on the lower-triangle tiles only, gradient tiles
+    counted twice off the diagonal (21 x 22 / 2 tiles at N = 1300) -- against the oracle's
+    gradient (full matrices, NumPy)."""
+    go, agp = _mods()
+    X, y = _synthetic(n, d, seed=3)
+    def make(mod):
+        k = mod.Product(mod.ConstantKernel(np.log(2.0), ndim=d), mod.ExpSquaredKernel(np.full(d, 3.0 * d), ndim=d))
+        g = mod.GP(kernel=k, fit_mean=True, mean=float(np.median(y)), white_noise=-9.0, fit_white_noise=False)
+        g.compute(X)
+        return g
+    gpo, gp = make(go), make(agp)
+    want = gpo.grad_log_likelihood(y, quiet=True)
+    got = gp.grad_log_likelihood(y, quiet=True)
+    K = gpo.kernel.get_value(gpo._x)
+    K[np.diag_indices_from(K)] += np.exp(-9.0)
+    tol = max(1e-11, 500 * np.linalg.cond(K) * EPS)
+    assert np.allclose(got, want, rtol=tol, atol=tol * np.abs(want).max())
+
+
 @pytest.mark.parametrize("m", [5000, 40000])
 def test_multi_row_block_utilities_mask_nan(m, lib_loaded):
     """N > 512 (several row blocks: parked operands, persistent + split launches) with everything
