@@ -5,6 +5,8 @@
 // GP._compute_alpha and GP.predict (gpUtils.py:78; utility.py:131,178,224).
 #include "apgp_common.h"
 #include "mma16.h"
+#include "scratch.h"
+#include <mutex>
 #include <type_traits>
 #include <utility>
 template <int... Is, class F>
@@ -212,21 +214,163 @@ __global__ __launch_bounds__(1024) void trsv_kernel(TrsvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// K3, blocked: the same solves as a sequence of small launches, one per 64-row block, for N >= 768.
+// Launch jb: every workgroup (four wavefronts) solves the 64 x 64 diagonal block against the current
+// right-hand side of block jb itself (redundantly: 1 us, and no workgroup waits for another) and
+// applies the result to ITS block of the remaining rows (forward: block rows below, a wavefront-wide sum
+// per row; transposed: block columns to the left, coalesced as they lie).  Workgroup 0 keeps
+// the solved block.  The working right-hand side lives in stream-ordered scratch (scratch.h): the
+// solution goes to x, so no workgroup overwrites what a sibling still has to read.
+// 64 launches of ~4 us at N = 4096 instead of one single-workgroup kernel of 1.6 ms.
+// ---------------------------------------------------------------------------
+struct TrsvStepArgs {
+    const double* L;
+    double* r;          // working right-hand side (scratch)
+    double* x;          // solution
+    double* sumsq;      // x.x accumulated block by block (or NULL)
+    long long n, ldl, j0;
+};
+
+__global__ __launch_bounds__(256) void trsv_init_kernel(const double* b, double shift, double* r, double* sumsq, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) r[i] = b[i] - shift;
+    if (sumsq && i == 0) *sumsq = 0.0;
+}
+
+__device__ __forceinline__ double trsv_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+template <int TRANS>
+__global__ __launch_bounds__(256) void trsv_step_kernel(TrsvStepArgs a) {
+    // four wavefronts: all of them request their 16 rows of the diagonal block AND of the workgroup's
+    // own off-diagonal block at once (one memory latency for both), wavefront 0 solves the diagonal
+    // block while the others wait, then each applies the solved block to its 16 rows
+    __shared__ double Lb[64][65];
+    __shared__ double zb[64];
+    __shared__ double part[4][64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long j0 = a.j0, n = a.n;
+    const int bs = (int)((n - j0) < 64 ? (n - j0) : 64);
+    const bool off = blockIdx.x != 0;
+    const long long i0 = TRANS ? j0 - 64 * (long long)blockIdx.x : j0 + 64 * (long long)blockIdx.x;
+    double dg[16], ob[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = 16 * w + q;
+        dg[q] = (r < bs && lane <= r) ? a.L[(j0 + r) * a.ldl + j0 + lane] : ((r == lane) ? 1.0 : 0.0);
+        // own block, the 16 k of this wavefront: forward element (row i0 + lane, column j0 + 16 w + q)
+        // -- one 128-byte line per lane --, transposed element (row j0 + 16 w + q, column i0 + lane)
+        if (!TRANS) ob[q] = (off && i0 + lane < n) ? a.L[(i0 + lane) * a.ldl + j0 + r] : 0.0;
+        else ob[q] = (off && r < bs) ? a.L[(j0 + r) * a.ldl + i0 + lane] : 0.0;
+    }
+    const double rj = (w == 0 && lane < bs) ? a.r[j0 + lane] : 0.0;
+    const double rown = (w == 0 && off && i0 + lane < n) ? a.r[i0 + lane] : 0.0;   // (the entries this workgroup updates: requested now)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Lb[16 * w + q][lane] = dg[q];                 // (coalesced: lane = column)
+    __syncthreads();
+    if (w == 0) {
+        double ri = rj;
+        const double inv = 1.0 / Lb[lane][lane];
+        double v[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) v[k] = TRANS ? Lb[k][lane] : Lb[lane][k];   // column / row `lane` of the block
+        if (!TRANS) {
+            trtri_static_for<64>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const double zk = trsv_bcast(ri, k) * trsv_bcast(inv, k);
+                ri = lane == k ? zk : (lane > k ? fma(-v[k], zk, ri) : ri);
+            });
+        } else {
+            trtri_static_for<64>([&](auto kc) {
+                constexpr int k = 63 - decltype(kc)::value;
+                const double xk = trsv_bcast(ri, k) * trsv_bcast(inv, k);
+                ri = lane == k ? xk : (lane < k ? fma(-v[k], xk, ri) : ri);   // (L^T)[lane][k] = L[k][lane]
+            });
+        }
+        zb[lane] = ri;
+        if (!off) {
+            if (lane < bs) a.x[j0 + lane] = ri;
+            if (a.sumsq) {
+                double ss = lane < bs ? ri * ri : 0.0;
+                for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+                if (lane == 0) *a.sumsq += ss;              // (one writer per launch, launches in stream order)
+            }
+        }
+    }
+    __syncthreads();
+    if (!off) return;
+    // forward: r_i -= L[i, j0 .. j0+63] . z (lane = row i); transposed: r_c -= sum_k L[j0 + k, c] x_k
+    // (lane = column c).  Either way 16 of the 64 k per wavefront, the four partial sums through LDS.
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = fma(ob[q], zb[16 * w + q], acc);
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && i0 + lane < n) a.r[i0 + lane] = rown - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+}
+
 extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
                          int trans, double* x, double* sumsq, void* stream) {
     APGP_CHECK_ARG(L && b && x, "null pointer");
     APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    hipStream_t st = (hipStream_t)stream;
+    if (n >= 768) {
+        // blocked form (trsv_step_kernel): one small launch per 64-row block (~10 us each, bound by the
+        // launch-to-launch dependency; the single-workgroup form below costs ~10 us per block at N = 512
+        // and 26 us per block at N = 4096).  Scratch and launches
+        // of one solve are taken as a unit: host threads sharing a stream share the scratch.
+        static std::mutex enqueue_mu;
+        std::lock_guard<std::mutex> enqueue_lock(enqueue_mu);
+        double* r = apgp_stream_scratch(1, st, (size_t)n);
+        if (!r) {
+            apgp_set_error("apgp_trsv: scratch allocation failed");
+            return -2;
+        }
+        hipLaunchKernelGGL(trsv_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b, shift, r, sumsq, (long long)n);
+        TrsvStepArgs sa;
+        sa.L = L; sa.r = r; sa.x = x; sa.sumsq = sumsq; sa.n = n; sa.ldl = ldl;
+        const long long nb = (n + 63) / 64;
+        if (!trans) {
+            for (long long jb = 0; jb < nb; ++jb) {
+                sa.j0 = jb * 64;
+                hipLaunchKernelGGL(trsv_step_kernel<0>, dim3((unsigned)(nb - jb)), dim3(256), 0, st, sa);
+            }
+        } else {
+            for (long long jb = nb - 1; jb >= 0; --jb) {
+                sa.j0 = jb * 64;
+                hipLaunchKernelGGL(trsv_step_kernel<1>, dim3((unsigned)(jb + 1)), dim3(256), 0, st, sa);
+            }
+        }
+        APGP_CHECK_LAUNCH();
+        return 0;
+    }
     APGP_CHECK_ARG(n <= 15360, "n <= 15360 (right-hand side is kept in LDS)");
     TrsvArgs a;
     a.L = L; a.b = b; a.x = x; a.sumsq = sumsq; a.n = n; a.ldl = ldl; a.shift = shift;
     a.trans = trans;
     size_t nr = (size_t)apgp_round_up(n, 64);
     size_t lds = (nr + TRSV_B * (TRSV_B + 1) + 16 * 64) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)trsv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        attr_set = true;
+    {
+        // per device, checked (the single-workgroup form keeps the right-hand side in LDS)
+        static std::mutex attr_mu;
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+            apgp_set_error("apgp_trsv: hipGetDevice failed");
+            return -2;
+        }
+        std::lock_guard<std::mutex> lock(attr_mu);
+        if (!attr_set[dev]) {
+            if (hipFuncSetAttribute((const void*)trsv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                apgp_set_error("apgp_trsv: hipFuncSetAttribute failed");
+                return -2;
+            }
+            attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL(trsv_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, a);
     APGP_CHECK_LAUNCH();

@@ -17,10 +17,9 @@
 // definite (first failing pivot).
 #include "apgp_common.h"
 #include "mma16.h"
+#include "scratch.h"
 #include <type_traits>
 #include <utility>
-#include <map>
-#include <mutex>
 
 // compile-time loop: the body sees its index as a constant expression, so the register
 // arrays below are indexed statically whatever hipcc's unroll heuristics decide
@@ -657,27 +656,6 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
     if (a.rhs && threadIdx.x < bs) a.rhs[j0 + threadIdx.x] = a.dscr[a.zoff + j0 + threadIdx.x];
 }
 
-// stream-ordered scratch for the diagonal blocks, kept per (device, stream) and grown on demand:
-// calls on one stream are serialised, so they can share it; calls on different streams cannot
-static double* potrf_scratch(hipStream_t s, size_t doubles) {
-    struct Scr { double* p; size_t doubles; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Scr> tab;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    Scr& e = tab[std::make_pair(dev, s)];
-    if (e.doubles < doubles) {
-        if (e.p) (void)hipFreeAsync(e.p, s);
-        e.p = nullptr; e.doubles = 0;
-        const size_t want = doubles + doubles / 2;
-        double* p = nullptr;
-        if (hipMallocAsync((void**)&p, want * sizeof(double), s) != hipSuccess) return nullptr;
-        e.p = p; e.doubles = want;
-    }
-    return e.p;
-}
-
 // `batch` matrices A + b * batch_A (right-hand sides y - shifts[b] -> z + b * n) factorised by
 // the same launches: gridDim.y = batch.  The Cholesky of one small matrix is a chain of
 // latency-bound steps that leaves most of the chip idle, so a batch costs little more than one.
@@ -687,7 +665,7 @@ static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t b
                      const double* shifts, double* z, int32_t* info_dev, hipStream_t s, bool pre_init = false,
                      double* out5 = nullptr) {
     // One factorisation's launches are enqueued as a unit: two host threads on the same stream (ctypes
-    // releases the GIL) must not interleave theirs -- they share the stream's scratch (potrf_scratch).
+    // releases the GIL) must not interleave theirs -- they share the stream's scratch (scratch.h).
     static std::mutex enqueue_mu;
     std::lock_guard<std::mutex> enqueue_lock(enqueue_mu);
     // info = UINT_MAX means "no failure yet"; normalised to 0 by the caller-visible finish kernel
@@ -707,7 +685,7 @@ static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t b
     // panel step of column jb + 1 (potrf_step_kernel)
     a.dscr = nullptr; a.zoff = nb * (long long)(PB * PB); a.batch_dscr = a.zoff + nb * PB;
     if (nb > 1) {
-        a.dscr = potrf_scratch(s, (size_t)a.batch_dscr * (size_t)batch);
+        a.dscr = apgp_stream_scratch(0, s, (size_t)a.batch_dscr * (size_t)batch);
         if (!a.dscr) {
             apgp_set_error("apgp_potrf: scratch allocation failed");
             return -2;

@@ -48,7 +48,7 @@ UTILITY_KINDS = {"agp": _lib.UTIL_AGP, "bape": _lib.UTIL_BAPE, "jones": _lib.UTI
 # overrides the choice for one object (tests); no environment variable is read.
 COND_SOLVE = 1.0e10
 # from this size on a missing L^-1 is formed before the first solve (gp._solve): apgp_trtri_pack is
-# 0.11 ms at N = 512 against 0.08 + 0.09 ms for the two triangular solves it replaces, 0.8 vs 3.2 ms at 4096
+# 0.11 ms at N = 512 against 0.08 + 0.09 ms for the two triangular solves it replaces, 0.8 vs 1.4 ms at 4096
 W_FIRST_MIN_N = 512
 
 
@@ -471,7 +471,7 @@ class GP(object):
                                                  ctypes.byref(ks), row.data_ptr(), n1, st), "apgp_kernel_cross")
                 if j == n0 and w_prev is not None:
                     # the previous fit's dense L^-1 is resident (a sweep ran on it): l = W k is an
-                    # HBM-rate matrix-vector product (18 us at N = 4096; the solve: 1.6 ms)
+                    # HBM-rate matrix-vector product (18 us at N = 4096; the solve: 0.7 ms)
                     _lib.check(lib.apgp_winv_apply(w_prev.data_ptr(), (n0 + 63) // 64 * 64, n0, row.data_ptr(), 0.0,
                                                    0, L[j].data_ptr(), ss.data_ptr(), None, st),
                                "apgp_winv_apply(append)")
@@ -591,7 +591,7 @@ class GP(object):
         need_solve = (not same or self._z is None) or (need_alpha and self._alpha is None)
         if trust_w and need_solve and self._work is None and n >= W_FIRST_MIN_N:
             # no inverse yet: L^-1 (0.8 ms at N = 4096) + a matrix-vector product per solve is cheaper
-            # than ONE single-workgroup triangular solve (1.6 ms), and the next sweep wants it anyway
+            # than the two triangular solves (0.7 ms each), and the next sweep wants it anyway
             self._ensure_linv()
         via_w = self._work is not None and trust_w
         np64 = (n + 63) // 64 * 64
