@@ -154,7 +154,9 @@ int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch,
  * Replaces BasicSolver.apply_inverse / dot_solve on a vector (scipy cho_solve;
  * george GP.log_likelihood and _compute_alpha; gpUtils.py:78, utility.py:131).
  * trans = 0: solve L x = (b - shift); trans = 1: solve L^T x = (b - shift).
- * If sumsq != NULL, *sumsq = x.x (device scalar).  x may alias b.  n <= 16384. */
+ * If sumsq != NULL, *sumsq = x.x (device scalar).  x may alias b.  From n = 768 the solve runs
+ * as one small launch per 64-row block with n doubles of stream-ordered scratch kept by the
+ * library per (device, stream) (hipMallocAsync); below that one workgroup, right-hand side in LDS. */
 int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
               int trans, double* x, double* sumsq, void* stream);
 
