@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libapgp.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_DIM = 16
 
 UTIL_AGP, UTIL_BAPE, UTIL_JONES, UTIL_NONE = 0, 1, 2, 3
@@ -64,7 +64,9 @@ SIGNATURES = {
     "apgp_acquire": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _I64, _KP, _F64, _I32,
                                     ctypes.POINTER(_F64), ctypes.POINTER(_F64), _P,
                                     _F64, _F64, _P, _P, _P, _P, _P, _P]),
-    "apgp_acquire_solve": (ctypes.c_int, [_P, _I64, _I64, _P, _I64, _P, _I64, _KP, _F64, _I32,
+    "apgp_packed_lsolve_len": (_I64, [_I64]),
+    "apgp_pack_lsolve": (ctypes.c_int, [_P, _I64, _I64, _P, _P]),
+    "apgp_acquire_solve": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _I64, _KP, _F64, _I32,
                                           ctypes.POINTER(_F64), ctypes.POINTER(_F64), _P,
                                           _F64, _F64, _P, _P, _P, _P, _P, _P]),
     "apgp_predict_mean": (ctypes.c_int, [_P, _I64, _P, _I64, _KP, _F64, _P, _P]),

@@ -28,6 +28,8 @@
 //     into a per-candidate sum; V is never stored.
 //   * mu is a VALU by-product of the generating tiles (every k exactly once).
 #include "apgp_common.h"
+#include "mma16.h"
+#include <mutex>
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>
@@ -69,7 +71,6 @@ struct SweepArgs {
     int ndim, nrb, kind, has_box, n, ncache, lin_order;
     double mean, amp, zeta, ybest, lin_coef;
     double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
-    unsigned long long* dbg;   // row-block time stamps (-DS2_PROFILE developer builds only)
 };
 
 __device__ __forceinline__ double util_value(int kind, double mu, double var, double zeta,
@@ -166,15 +167,12 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 #ifndef S2_SPREAD
 #define S2_SPREAD 1
 #endif
-#ifndef S2_X_IMGPIECES
-#define S2_X_IMGPIECES 8
-#endif
 #define S2_ROWS 256
 #define S2_TILE (S2_ROWS * SW_KC)        // doubles per tile image (32 KiB)
 #define S2_CPB (S2_ROWS / SW_KC)         // chunks per row-block width (16)
 #define S2_NP (S2_ROWS / 32)             // sub-block pairs per tile (8)
 
-template <int DPAD, bool LIN>
+template <int DPAD, bool LIN, bool SOLVE>
 __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     constexpr int XS = DPAD + 2;
     constexpr int NKK = SW_KC / 4;
@@ -240,9 +238,6 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         for (int r = 0; r < 4; ++r) lr[r] = (lane & 48) | ((lane + 4 * r) & 15);
         f64x2 av[2][2][2];
         auto load_a = [&](f64x2 (&dst)[2][2], int slot, int p) {
-#ifdef S2_X_NOA            // elimination build (results wrong): the A fragments are never re-read
-            if (p >= 0) return;
-#endif
             const f64x2* A2 = (const f64x2*)(Aring + slot * S2_TILE) + lane;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -256,9 +251,6 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         // B operands of the current tile in all four rotations; half 0 = k-steps 0-1, 1 = 2-3
         double brot[4][NKK];
         auto load_b = [&](int buf, int half) {
-#ifdef S2_X_NOB            // elimination build (results wrong): the B operands are never re-read
-            if (half >= 0) return;
-#endif
             const f64x2* Bw = (const f64x2*)(Bbuf + buf * 1024 + w * 256) + half * 64;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -268,17 +260,16 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         };
         load_a(av[0], 0, 0);
         load_b(0, 0);
-#ifdef S2_PROFILE
-        int s2_blkno = 0;      // row-block time stamps of the third candidate block of workgroup 0
-#endif
+        // SOLVE: the solved blocks V are parked by the matrix wavefronts themselves (same slot
+        // layout the feeders of the inverse form write: [half][wavefront][lane] x 16 B)
+        const __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.kcache + (long long)blockIdx.x * a.ncache * SW_BCH), 0, (int)a.kslot_bytes, 0x00020000);
         for (long long blk = blk0; blk < a.blk_end; blk += blk_step) {
             double qtot = 0.0;
-#ifdef S2_PROFILE
-            if (a.dbg && blockIdx.x == 0 && t == 0 && s2_blkno == 2) a.dbg[40] = __builtin_amdgcn_s_memtime();
-#endif
             for (int jb = jb_lo; jb < jb_hi; ++jb) {
                 const int nkc = nkc_of(jb);
                 const int ndiag0 = S2_CPB * jb;
+                double qmic = 0.0;                // SOLVE: sum V^2 of the 16-row blocks solved on the diagonal
                 double acc[2 * NP][4];
 #pragma unroll
                 for (int s_ = 0; s_ < 2 * NP; ++s_)
@@ -306,7 +297,12 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                         const bool act = !PRED || (pr >= p0 && pr < p1);
                         if (act) mfma_pair(pr, 0);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (pr == 4) __syncthreads();          // barrier i: tile i+1 is complete
+                        if (pr == 4) {
+                            // (SOLVE: the park stores of the last diagonal tile are acknowledged before this
+                            // wavefront arrives -- their readers request them >= 14 barriers later)
+                            if constexpr (SOLVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();                    // barrier i: tile i+1 is complete
+                        }
                         if (pr + 1 < NP) {
                             // (first pair: the k-step 2-3 half of this tile's B operands; its
                             // registers were still in use when the 0-1 half was prefetched)
@@ -356,7 +352,118 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 };
                 const int nstraight = (a.n - S2_ROWS * jb >= S2_ROWS) ? ndiag0 : 0;
                 for (; kc < nstraight; ++kc) do_tile(std::false_type{});
-                for (; kc < nkc; ++kc) do_tile(std::true_type{});
+                if constexpr (!SOLVE) {
+                    for (; kc < nkc; ++kc) do_tile(std::true_type{});
+                } else {
+                    for (; kc < ndiag0 && kc < nkc; ++kc) do_tile(std::true_type{});   // (partial last row block)
+                    // ---- diagonal tiles of the substitution form ---------------------------------
+                    // Tile (jb, 16 jb + c): the image holds -L (rows below the 16 x 16 diagonal block c) and,
+                    // in sub-block slot c, that block prepared for a 4 x 4-blocked solve (pack_lsolve_kernel):
+                    //   Ts[(4 q + q') 16 + 4 i + k] = -L_c[4q+i][4q'+k] (q' < q), inverse of the 4 x 4 diagonal
+                    //   block (q' = q).  With acc[c] = -sum_{j<c} L_cj V_j from the tiles so far,
+                    //   V_c = L_cc^-1 (K*_c + acc[c]) is solved in registers, four rows at a time, on the
+                    //   four-block MFMA with the blocks used as CANDIDATE groups (A replicated, B/D lane
+                    //   = cand + 16 row): the D fragment of one step is the B fragment of the next, and
+                    //   V_c in that layout is, lane for lane, the tile's B operand (rotation 0) -- the other
+                    //   three rotations are DPP moves, the parked copy two 16-byte stores.  No LDS round trip.
+                    auto do_diag = [&]() {
+                        const int nslot = slot == 2 ? 0 : slot + 1;
+                        const int c = kc - ndiag0;
+                        int s1 = (a.n - S2_ROWS * jb + 15) >> 4;
+                        if (s1 > 2 * NP) s1 = 2 * NP;
+                        load_b(bpar, 1);                        // K*_c, k-steps 2-3 (0-1: prefetched)
+                        double ta[10];
+                        {
+                            const double* Ts = Aring + slot * S2_TILE + c * 256 + (lane & 3) * 4 + (lane >> 4);
+                            int e = 0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int q2 = 0; q2 <= q; ++q2) ta[e++] = Ts[(q * 4 + q2) * 16];
+                        }
+                        const bool park_now = a.ncache > 0 && jb + 1 < nrb2;
+                        auto half = [&](int pr, int h, int kk) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc[2 * pr + h][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                                    av[pr & 1][h][kk >> 1][kk & 1], brot[r][kk], acc[2 * pr + h][r], 0, 0, 0);
+                        };
+                        auto micro = [&](int S) {     // (S is a constant after the pair loop is unrolled)
+                            // rows 4 q + i of sub-block S sit in lane block q of the four rotation registers
+                            // (candidate group (q + r) & 3): ror 4 r brings group b' to lane block b'
+                            double rot[4];
+                            rot[0] = acc[S][0];
+                            rot[1] = apgp_row_ror4<1>(acc[S][1]);
+                            rot[2] = apgp_row_ror4<2>(acc[S][2]);
+                            rot[3] = apgp_row_ror4<3>(acc[S][3]);
+                            const int bb = (lane >> 2) & 3;
+                            double R[4], V[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int rr = (bb - q) & 3;
+                                R[q] = (rr == 0 ? rot[0] : rr == 1 ? rot[1] : rr == 2 ? rot[2] : rot[3]) + brot[0][q];
+                            }
+                            V[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[0], R[0], 0.0, 0, 0, 0);
+                            R[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[1], V[0], R[1], 0, 0, 0);
+                            R[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[3], V[0], R[2], 0, 0, 0);
+                            R[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[6], V[0], R[3], 0, 0, 0);
+                            V[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[2], R[1], 0.0, 0, 0, 0);
+                            R[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[4], V[1], R[2], 0, 0, 0);
+                            R[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[7], V[1], R[3], 0, 0, 0);
+                            V[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[5], R[2], 0.0, 0, 0, 0);
+                            R[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[8], V[2], R[3], 0, 0, 0);
+                            V[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[9], R[3], 0.0, 0, 0, 0);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                brot[0][q] = V[q];
+                                brot[1][q] = apgp_row_ror4<3>(V[q]);     // lane l <- lane l + 4
+                                brot[2][q] = apgp_row_ror4<2>(V[q]);
+                                brot[3][q] = apgp_row_ror4<1>(V[q]);
+                                qmic = fma(V[q], V[q], qmic);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[S][r] = 0.0;    // (counted through qmic)
+                            if (park_now) {
+                                const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
+                                const unsigned voff = (unsigned)(w * 64 + lane) * 16u;
+                                f64x2 q0, q1;
+                                q0.x = V[0]; q0.y = V[1]; q1.x = V[2]; q1.y = V[3];
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_kv, voff, soff, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_kv, voff, soff + 4096u, 0);
+                            }
+                        };
+#pragma unroll
+                        for (int pr = 0; pr < NP; ++pr) {
+                            if (2 * pr == c) micro(2 * pr);
+                            if (2 * pr + 1 == c) micro(2 * pr + 1);
+                            const bool a0 = 2 * pr > c && 2 * pr < s1, a1 = 2 * pr + 1 > c && 2 * pr + 1 < s1;
+                            if (a0) half(pr, 0, 0);
+                            if (a1) half(pr, 1, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (pr == 4) {
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                __syncthreads();                // barrier i: tile i+1 is complete
+                            }
+                            if (pr + 1 < NP) {
+                                load_a(av[(pr + 1) & 1], slot, pr + 1);
+                                if (a0) { half(pr, 0, 1); half(pr, 0, 2); half(pr, 0, 3); }
+                                if (a1) { half(pr, 1, 1); half(pr, 1, 2); half(pr, 1, 3); }
+                            } else {
+                                load_a(av[0], nslot, 0);
+                                if (a0) half(pr, 0, 1);
+                                if (a1) half(pr, 1, 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                                load_b(bpar ^ 1, 0);
+                                if (a0) { half(pr, 0, 2); half(pr, 0, 3); }
+                                if (a1) { half(pr, 1, 2); half(pr, 1, 3); }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        slot = nslot;
+                        bpar ^= 1;
+                    };
+                    for (; kc < nkc; ++kc) do_diag();
+                }
                 // this row block's share of sum V^2: rotation r's accumulators belong to the
                 // candidate of lane lr[r]; gather them back, reduce over the 4 row-lanes
                 double qr[4];
@@ -369,16 +476,11 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 double qs = qr[0];
 #pragma unroll
                 for (int r = 1; r < 4; ++r) qs += __shfl(qr[r], (lane & 48) | ((lane - 4 * r) & 15));
+                if constexpr (SOLVE) qs += qmic;  // (lane = candidate + 16 row there as well)
                 qs += __shfl_xor(qs, 16);
                 qs += __shfl_xor(qs, 32);
                 qtot += qs;
-#ifdef S2_PROFILE
-                if (a.dbg && blockIdx.x == 0 && t == 0 && s2_blkno == 2 && jb < 40) a.dbg[jb] = __builtin_amdgcn_s_memtime();
-#endif
             }
-#ifdef S2_PROFILE
-            ++s2_blkno;
-#endif
             if (kq == 0) Shq[w * 16 + cl] = qtot;
             __syncthreads();                      // E1: sums visible to the feeders
             __syncthreads();                      // E2: block result written
@@ -450,7 +552,6 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 lsum[kk] = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;
                 al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
             }
-#ifndef S2_X_NOGEN         // (elimination build, results wrong: no distance sums, no exponential)
 #pragma unroll
             for (int d = 0; d < DPAD; d += 2)
 #pragma unroll
@@ -466,16 +567,10 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                         lsum[kk] += q0 + q1;
                     }
                 }
-#endif
             double ex[NKK];
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) ex[kk] = -(s2[kk] + s3[kk]);
-#if defined(S2_X_NOEXP) || defined(S2_X_NOGEN)          // elimination build (results wrong): no exponential
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) bfv[kk] = ex[kk];
-#else
             apgp_exp4(ex, bfv, Etab);
-#endif
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) bfv[kk] = LIN ? fma(a.lin_coef, lsum[kk], bfv[kk] * a.amp) : bfv[kk] * a.amp;
             if (kc >= S2_CPB * jb) {
@@ -490,7 +585,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                     mu_tot += m;
                     mu_cur = 0.0;
                 }
-                if (park && jb + 1 < nrb2) {
+                if (!SOLVE && park && jb + 1 < nrb2) {
                     const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
                     f64x2 q0, q1;
                     q0.x = bfv[0]; q0.y = bfv[1]; q1.x = bfv[2]; q1.y = bfv[3];
@@ -565,18 +660,18 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         double* dst = Aring + slot * S2_TILE + hw_s * 128;
         const unsigned toffs = tile_off(jb, kc);
 #pragma unroll
-        for (int q = 0; q < S2_X_IMGPIECES; ++q)     // (< 8: elimination build, results wrong)
+        for (int q = 0; q < 8; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + q * 512), 16, (unsigned)lane * 16u,
                                                      toffs + (unsigned)(q * 4096) + (unsigned)hw_s * 1024u, 0, 0);
     };
     auto dma_parked = [&](int par, int c) {
-#ifdef S2_X_NOPARKDMA          // elimination build (results wrong): parked operands are not fetched
-        if (c >= 0) return;
-#endif
         double* dst = Bbuf + par * 1024 + hw_s * 256;
         const unsigned soff = (unsigned)c * (unsigned)(SW_BCH * 8) + (unsigned)hw_s * 1024u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)dst, 16, (unsigned)lane * 16u, soff, 0, SW_KAUX);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, SW_KAUX);
+        // (SOLVE: the parked blocks were stored by the matrix wavefronts of this workgroup: sc1 = served by
+        // the L2, never by a line this CU's vector cache kept from the previous candidate block)
+        constexpr int kaux = SOLVE ? 16 : SW_KAUX;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)dst, 16, (unsigned)lane * 16u, soff, 0, kaux);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, kaux);
     };
     auto is_gen = [&](const Pos& p) { return !park || p.kc >= S2_CPB * p.jb; };
     // ---- prologue: tile 0 and its operands, x chunks of tiles 0 and 1, requests for tile 1 ----
@@ -617,7 +712,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         // register load hipcc tracks itself).  They are the LAST requests issued, and gfx9 VMEM
         // completes in issue order, so "at most n outstanding" still means the images and parked
         // operands of tile i+1 have landed -- without the ~1-2 k cycles of store acknowledgement.
-        int n_pend = (is_gen(p1) && park && p1.kc >= S2_CPB * p1.jb && p1.jb + 1 < nrb2) ? 2 : 0;
+        int n_pend = (!SOLVE && is_gen(p1) && park && p1.kc >= S2_CPB * p1.jb && p1.jb + 1 < nrb2) ? 2 : 0;
         if (is_gen(p3)) { xq = x_fetch(p3.kc); ++n_pend; }
         last_m2 = last_m1;
         last_m1 = (p1.jb == jb_hi - 1 && p1.kc == nkc_of(p1.jb) - 1);
@@ -704,17 +799,25 @@ static constexpr size_t s2_lds_bytes() {
 template <int DPAD>
 static int s2_prepare_device() {
     static bool done[64] = {false};
+    static std::mutex mu;                 // (ctypes releases the GIL: host threads may race here)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
         apgp_set_error("apgp_acquire: hipGetDevice failed");
         return -2;
     }
+    std::lock_guard<std::mutex> lock(mu);
     if (done[dev]) return 0;
     const int lds = (int)s2_lds_bytes<DPAD>();
-    hipError_t e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false>,
+    hipError_t e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true>,
+        e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
         apgp_set_error("apgp_acquire: hipFuncSetAttribute(%d B of LDS) failed on device %d: %s", lds, dev,
@@ -726,7 +829,7 @@ static int s2_prepare_device() {
 }
 
 template <int DPAD>
-static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
+static int launch_sweep(const SweepArgs& a0, hipStream_t s, bool solve) {
     const int rc = s2_prepare_device<DPAD>();
     if (rc != 0) return rc;
     SweepArgs a = a0;
@@ -734,37 +837,26 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s) {
     const long long ncb = (a.m + SW_CAND - 1) / SW_CAND;
     const int nrb2 = s2_nrb(a.n);
     a.nrb = nrb2;
-#ifdef S2_PROFILE
-    static unsigned long long* dbg2 = nullptr;
-    if (!dbg2) (void)hipMalloc(&dbg2, 64 * sizeof(unsigned long long));
-    a.dbg = dbg2;
-#endif
     auto launch = [&](unsigned grid) {
-        if (a.lin_coef != 0.0)
-            hipLaunchKernelGGL((sweep2_kernel<DPAD, true>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+        if (solve) {
+            if (a.lin_coef != 0.0)
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, true, true>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+            else
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, false, true>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+        } else if (a.lin_coef != 0.0)
+            hipLaunchKernelGGL((sweep2_kernel<DPAD, true, false>), dim3(grid), dim3(S2_THREADS), lds, s, a);
         else
-            hipLaunchKernelGGL((sweep2_kernel<DPAD, false>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+            hipLaunchKernelGGL((sweep2_kernel<DPAD, false, false>), dim3(grid), dim3(S2_THREADS), lds, s, a);
     };
-    // full rounds on the persistent grid, then the remainder split by row block
+    // full rounds on the persistent grid, then the remainder split by row block (the substitution
+    // form cannot split: its row blocks depend on each other -- the last round just runs short)
     long long rest = ncb % SW_GRID;
-    if (nrb2 < 2 || rest > S2_SPLIT_MAX || a.sp_q == NULL) rest = 0;
+    if (solve || nrb2 < 2 || rest > S2_SPLIT_MAX || a.sp_q == NULL) rest = 0;
     const long long full = ncb - rest;
     if (full > 0) {
         a.blk_begin = 0; a.blk_end = full; a.split = 0;
         launch((unsigned)(full < SW_GRID ? full : SW_GRID));
     }
-#ifdef S2_PROFILE
-    if (full > 0) {
-        // cycles per row block of one steady-state candidate block: T(jb) = a + b jb with
-        // b = 16 x (cycles per straight tile), a = the 16 diagonal (generating) tiles + fold
-        unsigned long long h[64];
-        (void)hipMemcpyAsync(h, dbg2, sizeof(h), hipMemcpyDeviceToHost, s);
-        (void)hipStreamSynchronize(s);
-        fprintf(stderr, "[sweep2 profile] row-block cycles:");
-        for (int jb = 0; jb < nrb2 && jb < 40; ++jb) fprintf(stderr, " %llu", h[jb] - (jb ? h[jb - 1] : h[40]));
-        fprintf(stderr, "\n");
-    }
-#endif
     if (rest > 0) {
         a.blk_begin = full; a.blk_end = ncb; a.split = 1;
         a.ncache = 0;                             // no parking across workgroups
@@ -784,22 +876,23 @@ extern "C" int64_t apgp_acquire_work_len(int64_t m, int64_t n) {
     return 2 * ncb + slots * s2_ncache(n) * SW_BCH + 2 * (long long)S2_SPLIT_MAX * SW_CAND * s2_nrb(n);
 }
 
-extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
-                            const double* xs, int64_t n, const apgp_kernel_t* kern, double mean,
-                            int32_t kind, const double* lo, const double* hi, const uint8_t* mask,
-                            double zeta, double ybest, double* mu, double* var, double* u, void* part,
-                            apgp_best_t* best, void* stream) {
+static int acquire_impl(bool solve, const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
+                        const double* xs, int64_t n, const apgp_kernel_t* kern, double mean,
+                        int32_t kind, const double* lo, const double* hi, const uint8_t* mask,
+                        double zeta, double ybest, double* mu, double* var, double* u, void* part,
+                        apgp_best_t* best, void* stream) {
     APGP_CHECK_ARG(T && packed_linv && xs && kern, "null pointer");
     APGP_CHECK_ARG(m >= 1 && n >= 1, "m >= 1 and n >= 1 required");
     APGP_CHECK_ARG(kind >= APGP_UTIL_AGP && kind <= APGP_UTIL_NONE, "unknown utility kind");
     APGP_CHECK_ARG(kind == APGP_UTIL_NONE || best, "best required for an acquisition");
     APGP_CHECK_ARG(part || (kind == APGP_UTIL_NONE && n <= S2_ROWS),
                    "part (apgp_acquire_work_len doubles) required");
+    (void)solve;
     APGP_CHECK_ARG((lo == NULL) == (hi == NULL), "lo and hi must be given together");
     KernConst kc;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
     SweepArgs a;
-    a.T = T; a.linv = packed_linv; a.xs = xs; a.mask = mask; a.dbg = NULL;
+    a.T = T; a.linv = packed_linv; a.xs = xs; a.mask = mask;
     a.mu = mu; a.var = var; a.u = u;
     const long long nblk = (m + SW_CAND - 1) / SW_CAND;
     const long long slots = nblk < SW_GRID ? nblk : SW_GRID;
@@ -832,10 +925,10 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (kc.dpad) {
-        case 2: rc = launch_sweep<2>(a, s); break;
-        case 4: rc = launch_sweep<4>(a, s); break;
-        case 8: rc = launch_sweep<8>(a, s); break;
-        default: rc = launch_sweep<16>(a, s); break;
+        case 2: rc = launch_sweep<2>(a, s, solve); break;
+        case 4: rc = launch_sweep<4>(a, s, solve); break;
+        case 8: rc = launch_sweep<8>(a, s, solve); break;
+        default: rc = launch_sweep<16>(a, s, solve); break;
     }
     if (rc != 0) return rc;
     if (kind != APGP_UTIL_NONE)
@@ -844,168 +937,92 @@ extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, cons
     return 0;
 }
 
-// ---------------------------------------------------------------------------
-// Solve-based variant of the sweep for ill-conditioned factors.
-// The explicit-inverse contraction above is as accurate as a triangular solve
-// while cond(K) <~ 1e10; beyond that (the reference's own fitAmp=True optimum
-// reaches cond ~ 8e15) only the solve-based form keeps the
-// error at the level of george's cho_solve.  Here one wavefront owns one
-// candidate: k* lives in LDS, v = L^-1 k* by forward substitution against the
-// row-major factor (row i read coalesced, one wave reduction per row), then
-// sigma^2 = amp - |v|^2.  O(N^2/64) cycles per candidate and the factor is
-// re-read from L2 for every candidate, so this is a correctness path for the
-// small, badly conditioned training sets that need it, not a throughput path.
-// ---------------------------------------------------------------------------
-struct SolveArgs {
-    const double* T;
-    const double* L;
-    const double* xs;
-    const unsigned char* mask;
-    double* mu;
-    double* var;
-    double* u;
-    double* part_u;
-    long long* part_i;
-    long long m, idx_offset, ldl;
-    int ndim, n, kind, has_box, lin_order;
-    double mean, amp, zeta, ybest, lin_coef;
-    double sc[APGP_MAX_DIM], lo[APGP_MAX_DIM], hi[APGP_MAX_DIM], lw[APGP_MAX_DIM];
-};
+extern "C" int apgp_acquire(const double* T, int64_t m, int64_t idx_offset, const double* packed_linv,
+                            const double* xs, int64_t n, const apgp_kernel_t* kern, double mean,
+                            int32_t kind, const double* lo, const double* hi, const uint8_t* mask,
+                            double zeta, double ybest, double* mu, double* var, double* u, void* part,
+                            apgp_best_t* best, void* stream) {
+    return acquire_impl(false, T, m, idx_offset, packed_linv, xs, n, kern, mean, kind, lo, hi, mask, zeta, ybest,
+                        mu, var, u, part, best, stream);
+}
 
-template <int DPAD>
-__global__ __launch_bounds__(256) void sweep_solve_kernel(SolveArgs a) {
-    constexpr int XS = DPAD + 2;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double etab[APGP_EXP_TAB_N];
-    __shared__ double red_u[4];
-    __shared__ long long red_i[4];
-    apgp_exp_tab_load(etab);
-    __syncthreads();
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    double* v = smem + (size_t)w * a.n;
-    const long long crow = (long long)blockIdx.x * 4 + w;
-    const bool inb = crow < a.m;
-    bool adm = inb, has_nan = false;
-    double tt[DPAD];
-#pragma unroll
-    for (int d = 0; d < DPAD; ++d) {
-        double x = 0.0;
-        if (inb && d < a.ndim) {
-            x = a.T[crow * a.ndim + d];
-            if (a.has_box && !(x >= a.lo[d] && x <= a.hi[d])) adm = false;
-            if (x != x) has_nan = true;
-        }
-        tt[d] = x * a.sc[d];
-    }
-    if (inb && a.mask && a.mask[crow] == 0) adm = false;
-    double bu = INFINITY;
-    long long bi = -1;
-    if (inb) {
-        double mup = 0.0;
-        for (int k = lane; k < a.n; k += 64) {
-            const double* xr = a.xs + (long long)k * XS;
-            double s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int d = 0; d < DPAD; d += 2) {
-                const double df0 = tt[d] - xr[d], df1 = tt[d + 1] - xr[d + 1];
-                s2 = fma(df0, df0, s2);
-                s3 = fma(df1, df1, s3);
+// ---------------------------------------------------------------------------
+// Substitution form of the sweep: sigma^2 = amp - |v|^2 with v = L^-1 k* by BLOCKED FORWARD
+// SUBSTITUTION against the factor itself (what george's cho_solve does, utility.py:131,178,224)
+// instead of a product with the explicit inverse -- the only trustworthy formulation once
+// cond(K) approaches 1e16 (the reference's own fitAmp=True optimum), and
+// the same matrix-core stream otherwise: sweep2_kernel<.., SOLVE = true> reads the tiles of
+// apgp_pack_lsolve (-L off the diagonal 16 x 16 blocks, those blocks prepared for a 4 x 4-blocked
+// in-register solve), its B operands are the solved blocks V_j parked by the matrix wavefronts,
+// and k* enters once per 16-row block.  No n limit beyond the inverse form's.
+// ---------------------------------------------------------------------------
+extern "C" int apgp_acquire_solve(const double* T, int64_t m, int64_t idx_offset, const double* packed_lsolve,
+                                  const double* xs, int64_t n, const apgp_kernel_t* kern, double mean,
+                                  int32_t kind, const double* lo, const double* hi, const uint8_t* mask,
+                                  double zeta, double ybest, double* mu, double* var, double* u, void* part,
+                                  apgp_best_t* best, void* stream) {
+    return acquire_impl(true, T, m, idx_offset, packed_lsolve, xs, n, kern, mean, kind, lo, hi, mask, zeta, ybest,
+                        mu, var, u, part, best, stream);
+}
+
+// Packed tiles of the substitution form, same geometry as apgp_trtri_pack's (512 x 16 tiles, MFMA
+// A-fragment order, row block ib holds chunks 0 .. 32 (ib + 1) - 1):
+//   * below the diagonal 16 x 16 block of a chunk: -L;
+//   * sub-block slot of the diagonal block C itself (rows 16 C .. 16 C + 15 of chunk C): 256 doubles
+//     Ts[(4 q + q') 16 + 4 i + k] = -L[16C+4q+i][16C+4q'+k] for q' < q, (L_qq)^-1[i][k] for q' = q, 0 above --
+//     the 4 x 4 diagonal blocks are inverted by substitution with reciprocal pivots; rows / columns
+//     past n are zero (so the padded rows of V are exact zeros).
+// 4 x 4 is the largest diagonal block whose explicit inverse keeps the solve in cho_solve's error
+// class at cond 8.5e15 (8 x 8: borderline, 16 x 16: 10-100x worse; tools/cond_blocking_study.py).
+__global__ __launch_bounds__(256) void pack_lsolve_kernel(const double* L, long long ldl, long long n,
+                                                          double* packed) {
+    constexpr int CPB = APGP_ROW_BLOCK / APGP_K_CHUNK;
+    const long long tile = blockIdx.x;
+    long long ib = (long long)((sqrt(8.0 * (double)tile / CPB + 1.0) - 1.0) * 0.5);
+    while (CPB * (ib + 1) * (ib + 2) / 2 <= tile) ++ib;
+    while (CPB * ib * (ib + 1) / 2 > tile) --ib;
+    const long long kc = tile - CPB * ib * (ib + 1) / 2;
+    double* out = packed + tile * (long long)(APGP_ROW_BLOCK * APGP_K_CHUNK);
+    const long long sdiag = kc - ib * CPB;                 // sub-block slot of the diagonal block (if in this tile)
+    for (int e = threadIdx.x; e < APGP_ROW_BLOCK * APGP_K_CHUNK; e += 256) {
+        const int s = e >> 8;
+        double v = 0.0;
+        if (s == sdiag) {
+            const int f = e & 255, q = f >> 6, q2 = (f >> 4) & 3, i = (f >> 2) & 3, k = f & 3;
+            const long long r0 = kc * APGP_K_CHUNK + 4 * q, c0 = kc * APGP_K_CHUNK + 4 * q2;
+            if (q2 < q) {
+                if (r0 + i < n) v = -L[(r0 + i) * ldl + c0 + k];
+            } else if (q2 == q && k <= i && r0 + i < n) {
+                // column k of the inverse of the 4 x 4 lower-triangular block, rows k .. i
+                double x[4] = {0.0, 0.0, 0.0, 0.0};
+                x[k] = 1.0 / L[(r0 + k) * ldl + r0 + k];
+                for (int r = k + 1; r <= i; ++r) {
+                    double sacc = 0.0;
+                    for (int c = k; c < r; ++c) sacc = fma(L[(r0 + r) * ldl + r0 + c], x[c], sacc);
+                    x[r] = -sacc * (1.0 / L[(r0 + r) * ldl + r0 + r]);
+                }
+                v = x[i];
             }
-            double kv = a.amp * apgp_exp(-(s2 + s3), etab);
-            if (a.lin_coef != 0.0) {
-                double ls;
-                APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, tt[d_] * xr[d_] * a.lw[d_]);
-                kv = fma(a.lin_coef, ls, kv);
-            }
-            v[k] = kv;
-            mup = fma(kv, xr[DPAD], mup);
+        } else {
+            const int q = e & 1, lane = (e >> 1) & 63, kp = (e >> 7) & 1;
+            const int kk = 2 * kp + q;
+            const long long row = ib * APGP_ROW_BLOCK + 16 * s + (lane & 15);
+            const long long col = kc * APGP_K_CHUNK + 4 * kk + (lane >> 4);
+            if (row < n && (col >> 4) < (row >> 4)) v = -L[row * ldl + col];
         }
-        for (int o = 32; o > 0; o >>= 1) mup += __shfl_xor(mup, o);
-        double q = 0.0;
-        for (int i = 0; i < a.n; ++i) {
-            const double* lrow = a.L + (long long)i * a.ldl;
-            double p = 0.0;
-            for (int j = lane; j < i; j += 64) p = fma(lrow[j], v[j], p);
-            for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
-            const double vi = (v[i] - p) / lrow[i];
-            if (lane == 0) v[i] = vi;       // same wavefront: LDS ops are ordered
-            q = fma(vi, vi, q);
-        }
-        double mu = mup + a.mean;
-        double ktt = a.amp;                       // k(t,t): no white noise (george predict)
-        if (a.lin_coef != 0.0) {
-            double ls;
-            APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, tt[d_] * tt[d_] * a.lw[d_]);
-            ktt = fma(a.lin_coef, ls, ktt);
-        }
-        double var = ktt - q;
-        if (has_nan) { mu = NAN; var = NAN; }
-        if (lane == 0) {
-            if (a.mu) a.mu[crow] = mu;
-            if (a.var) a.var[crow] = var;
-            if (a.kind != APGP_UTIL_NONE) {
-                const double uu = adm ? util_value(a.kind, mu, var, a.zeta, a.ybest) : INFINITY;
-                if (a.u) a.u[crow] = uu;
-                best_merge(bu, bi, uu, a.idx_offset + crow);
-            }
-        }
-    }
-    if (a.kind == APGP_UTIL_NONE) return;
-    if (lane == 0) { red_u[w] = bu; red_i[w] = bi; }
-    __syncthreads();
-    if (t == 0) {
-        for (int i = 1; i < 4; ++i) best_merge(bu, bi, red_u[i], red_i[i]);
-        a.part_u[blockIdx.x] = bu;
-        a.part_i[blockIdx.x] = bi;
+        out[e] = v;
     }
 }
 
-extern "C" int apgp_acquire_solve(const double* T, int64_t m, int64_t idx_offset, const double* L,
-                                  int64_t ldl, const double* xs, int64_t n, const apgp_kernel_t* kern,
-                                  double mean, int32_t kind, const double* lo, const double* hi,
-                                  const uint8_t* mask, double zeta, double ybest, double* mu, double* var,
-                                  double* u, void* part, apgp_best_t* best, void* stream) {
-    APGP_CHECK_ARG(T && L && xs && kern, "null pointer");
-    APGP_CHECK_ARG(m >= 1 && n >= 1 && ldl >= n, "m >= 1, n >= 1 and ldl >= n required");
-    APGP_CHECK_ARG(n <= 4096, "solve-based sweep keeps k* in LDS: n <= 4096");
-    APGP_CHECK_ARG(kind >= APGP_UTIL_AGP && kind <= APGP_UTIL_NONE, "unknown utility kind");
-    APGP_CHECK_ARG(kind == APGP_UTIL_NONE || (part && best), "part/best required for an acquisition");
-    APGP_CHECK_ARG((lo == NULL) == (hi == NULL), "lo and hi must be given together");
-    KernConst kc;
-    APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
-    SolveArgs a;
-    a.T = T; a.L = L; a.xs = xs; a.mask = mask; a.mu = mu; a.var = var; a.u = u;
-    const long long nblk = (m + 3) / 4;
-    a.part_u = (double*)part;
-    a.part_i = part ? (long long*)((double*)part + nblk) : NULL;
-    a.m = m; a.idx_offset = idx_offset; a.ldl = ldl;
-    a.ndim = kc.ndim; a.n = (int)n; a.kind = kind; a.has_box = lo != NULL;
-    a.mean = mean; a.amp = kc.amp; a.zeta = zeta; a.ybest = ybest;
-    a.lin_coef = kc.lin_coef; a.lin_order = kc.lin_order;
-    for (int d = 0; d < APGP_MAX_DIM; ++d) {
-        a.sc[d] = kc.sc[d];
-        a.lw[d] = kc.lw[d];
-        a.lo[d] = (lo && d < kc.ndim) ? lo[d] : 0.0;
-        a.hi[d] = (hi && d < kc.ndim) ? hi[d] : 0.0;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)4 * n * sizeof(double);
-    dim3 grid((unsigned)nblk), block(256);
-#define APGP_LAUNCH_SOLVE(DP)                                                                           \
-    do {                                                                                                \
-        (void)hipFuncSetAttribute((const void*)sweep_solve_kernel<DP>,                                  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);              \
-        hipLaunchKernelGGL(sweep_solve_kernel<DP>, grid, block, lds, s, a);                             \
-    } while (0)
-    switch (kc.dpad) {
-        case 2: APGP_LAUNCH_SOLVE(2); break;
-        case 4: APGP_LAUNCH_SOLVE(4); break;
-        case 8: APGP_LAUNCH_SOLVE(8); break;
-        default: APGP_LAUNCH_SOLVE(16); break;
-    }
-#undef APGP_LAUNCH_SOLVE
-    if (kind != APGP_UTIL_NONE)
-        hipLaunchKernelGGL(argmin_final_kernel, dim3(1), dim3(1024), 0, s, a.part_u, a.part_i, nblk, best);
+extern "C" int64_t apgp_packed_lsolve_len(int64_t n) { return apgp_packed_linv_len(n); }
+
+extern "C" int apgp_pack_lsolve(const double* L, int64_t n, int64_t ldl, double* packed, void* stream) {
+    APGP_CHECK_ARG(L && packed, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
+    const long long ntiles = (APGP_ROW_BLOCK / APGP_K_CHUNK) * nrb * (nrb + 1) / 2;
+    hipLaunchKernelGGL(pack_lsolve_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, L,
+                       (long long)ldl, (long long)n, packed);
     APGP_CHECK_LAUNCH();
     return 0;
 }

@@ -44,19 +44,22 @@ def combine_best(pairs):
     return best_i, best_u
 
 
-def sharded_acquire(local_acquire, idx_offset, group=None, device=None):
+def sharded_acquire(local_acquire, idx_offset, group=None, device=None, records=None):
     """Run ``local_acquire(idx_offset) -> (best_global_index, best_u)`` on this
     rank's shard and all-gather the winners.
 
     ``local_acquire`` is typically
     ``lambda off: gp.acquire(y, T_local, kind, bounds=..., idx_offset=off)``.
-    Returns the same (index, u) on every rank.
+    Returns the same (index, u) on every rank.  ``records`` (a list) receives the gathered
+    per-rank (u, index) pairs in rank order -- one per rank the collective actually saw.
     """
     import torch
     import torch.distributed as dist
 
     bi, bu = local_acquire(idx_offset)
     if not (dist.is_available() and dist.is_initialized()):
+        if records is not None:
+            records[:] = [(float(bu), int(bi))]
         return combine_best([(bu, bi)])
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) \
@@ -72,6 +75,8 @@ def sharded_acquire(local_acquire, idx_offset, group=None, device=None):
     for g in gathered:
         h = g.cpu().numpy()
         pairs.append((float(h[0:1].view(np.float64)[0]), int(h[1])))
+    if records is not None:
+        records[:] = pairs
     return combine_best(pairs)
 
 

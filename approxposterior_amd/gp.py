@@ -313,6 +313,7 @@ class GP(object):
         self._z = None
         self._alpha = None
         self._packed = None       # packed L^-1 tiles
+        self._packed_solve = None  # packed tiles of the substitution form (apgp_pack_lsolve)
         self._work = None         # trtri work (dense L^-1 in first panel)
         self._xs = None           # packed training stream (depends on alpha)
         self._xs_key = None
@@ -429,6 +430,17 @@ class GP(object):
             return
         self._factor(None, upload_x=not same_x)
 
+    def _trust_inverse(self):
+        """True when the explicit L^-1 (sweep contraction, alpha by matrix-vector products, row
+        appends) may stand in for triangular solves: forced by ``variance_mode``, otherwise by the
+        condition estimate against COND_SOLVE."""
+        mode = (self.variance_mode or "").lower()
+        if mode == "inverse":
+            return True
+        if mode == "solve":
+            return False
+        return self.cond_estimate is not None and self.cond_estimate <= COND_SOLVE
+
     def _factor_key(self):
         return (tuple(self.kernel.get_parameter_vector().tolist()), float(self.white_noise.value),
                 float(self._yerr2))
@@ -451,8 +463,7 @@ class GP(object):
         torch, dev, lib = self._rt()
         ks = self._kernel_struct()
         w_prev = None
-        if (getattr(prev, "_work", None) is not None and (prev.variance_mode or "") != "solve"
-                and prev.cond_estimate is not None and prev.cond_estimate <= COND_SOLVE):
+        if getattr(prev, "_work", None) is not None and prev._trust_inverse():
             w_prev = prev._work
         self._reset_device_state()
         self._computed = False
@@ -586,12 +597,13 @@ class GP(object):
         n = len(y)
         same = (self._alpha_y is not None and self._alpha_mean == self.mean.value
                 and np.array_equal(self._alpha_y, y))
-        trust_w = ((self.variance_mode or "") != "solve" and self.cond_estimate is not None
-                   and self.cond_estimate <= COND_SOLVE)
+        trust_w = self._trust_inverse()
         need_solve = (not same or self._z is None) or (need_alpha and self._alpha is None)
-        if trust_w and need_solve and self._work is None and n >= W_FIRST_MIN_N:
-            # no inverse yet: L^-1 (0.8 ms at N = 4096) + a matrix-vector product per solve is cheaper
-            # than the two triangular solves (0.7 ms each), and the next sweep wants it anyway
+        if trust_w and need_solve and need_alpha and self._work is None and n >= W_FIRST_MIN_N:
+            # alpha wanted (a sweep, a gradient or the sampler follows) and no inverse yet: L^-1
+            # (0.8 ms at N = 4096) + two matrix-vector products beat the two triangular solves
+            # (0.7 ms each), and the sweep / gradient needs W anyway.  A bare log_likelihood on a new
+            # y (need_alpha False) keeps the ONE forward solve: it is cheaper than the O(N^3) inverse.
             self._ensure_linv()
         via_w = self._work is not None and trust_w
         np64 = (n + 63) // 64 * 64
@@ -718,6 +730,18 @@ class GP(object):
             _lib.check(lib.apgp_trtri_pack(self._L.data_ptr(), n, n, self._work.data_ptr(),
                                            self._packed.data_ptr(), None, st), "apgp_trtri_pack")
 
+    def _ensure_lsolve(self):
+        """Tiles of the substitution form of the sweep: one O(N^2) pass over the factor."""
+        torch, dev, lib = self._rt()
+        if self._packed_solve is not None:
+            return
+        n = len(self._x)
+        with torch.cuda.device(dev):
+            st = self._stream(torch)
+            self._packed_solve = torch.empty(lib.apgp_packed_lsolve_len(n), dtype=torch.float64, device=dev)
+            _lib.check(lib.apgp_pack_lsolve(self._L.data_ptr(), n, n, self._packed_solve.data_ptr(), st),
+                       "apgp_pack_lsolve")
+
     def _ensure_xs(self, y):
         torch, dev, lib = self._rt()
         self._solve(y, need_alpha=True)
@@ -781,13 +805,13 @@ class GP(object):
         n = len(self._x)
         need_var = kind is not None or "var" in want
         ks = self._kernel_struct()
-        mode = (self.variance_mode or "").lower()
-        use_solve = need_var and ((mode == "solve") or (mode != "inverse" and self.cond_estimate is not None
-                                                        and self.cond_estimate > COND_SOLVE and n <= 4096))
+        use_solve = need_var and not self._trust_inverse()
         with torch.cuda.device(dev):
             st = self._stream(torch)
             if need_var and not use_solve:
                 self._ensure_linv()     # first: with W resident alpha is two matrix-vector products
+            elif need_var:
+                self._ensure_lsolve()
             self._ensure_xs(y)
             if not need_var and cand_device is None and 0 < len(cand) <= 4096:
                 # latency-bound mean-only call (the sampler's _gpll batches): host buffers
@@ -818,7 +842,7 @@ class GP(object):
             mu = torch.empty(m, dtype=torch.float64, device=dev) if "mu" in want else None
             var = torch.empty(m, dtype=torch.float64, device=dev) if "var" in want else None
             u = torch.empty(m, dtype=torch.float64, device=dev) if "u" in want else None
-            nwork = 2 * ((m + 3) // 4) if use_solve else int(lib.apgp_acquire_work_len(m, n))
+            nwork = int(lib.apgp_acquire_work_len(m, n))
             part = torch.empty(max(nwork, 2), dtype=torch.float64, device=dev)
             best = torch.empty(2, dtype=torch.float64, device=dev)
             lo = hi = None
@@ -847,7 +871,7 @@ class GP(object):
                       u.data_ptr() if u is not None else None,
                       part.data_ptr(), best.data_ptr(), st)
             if use_solve:
-                _lib.check(lib.apgp_acquire_solve(T.data_ptr(), m, int(idx_offset), self._L.data_ptr(), n,
+                _lib.check(lib.apgp_acquire_solve(T.data_ptr(), m, int(idx_offset), self._packed_solve.data_ptr(),
                                                   self._xs.data_ptr(), n, *common), "apgp_acquire_solve")
             else:
                 _lib.check(lib.apgp_acquire(T.data_ptr(), m, int(idx_offset), self._packed.data_ptr(),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define APGP_ABI_VERSION 4
+#define APGP_ABI_VERSION 5
 #define APGP_MAX_DIM 16          /* feature dimension D supported by the kernels */
 #define APGP_ROW_BLOCK 512       /* rows per packed L^-1 row block (sweep tile)  */
 #define APGP_K_CHUNK 16          /* contraction depth per packed tile            */
@@ -228,14 +228,25 @@ int apgp_acquire(const double* T, int64_t m, int64_t idx_offset,
                  double* mu, double* var, double* u,
                  void* part, apgp_best_t* best, void* stream);
 
-/* ---- solve-based variant of apgp_acquire for ill-conditioned factors --------
- * Same semantics and outputs, but sigma^2 = amp - |L^-1 k*|^2 is obtained by a
- * forward substitution against the factor L itself (what george's cho_solve
- * does) instead of the packed explicit inverse: use when the condition estimate
- * from apgp_logdet, (out[2]/out[1])^2, exceeds ~1e10.  n <= 4096.
- * part: 2 * ceil(m/4) doubles.                                               */
+/* ---- substitution form of apgp_acquire (no explicit inverse) ------------------
+ * Same semantics, outputs, scratch (apgp_acquire_work_len) and arg-min contract as
+ * apgp_acquire, but sigma^2 = amp - |L^-1 k*|^2 comes from a BLOCKED FORWARD
+ * SUBSTITUTION against the factor L itself -- what george's cho_solve does
+ * (BasicSolver.apply_inverse, reached from utility.py:131,178,224) -- instead of
+ * a product with the packed explicit inverse.  Use it when the condition
+ * estimate of apgp_fit_summary, (out[2]/out[1])^2, exceeds ~1e10 (the reference's
+ * own fitAmp=True optimum, tests/test_OptimizeGP.py:50, has cond(K) 8.5e15: the
+ * explicit inverse is 200x off there, this form stays in cho_solve's error
+ * class); it runs on the same matrix-core stream at about the same rate, for any n
+ * the inverse form takes.
+ * apgp_pack_lsolve writes the tiles it streams (apgp_packed_lsolve_len(n) doubles,
+ * same geometry as the packed inverse): -L below the diagonal 16 x 16 blocks, and
+ * those blocks prepared for the in-register solve (their 4 x 4 diagonal blocks
+ * inverted, the rest negated).  One O(n^2) pass, no triangular inversion.     */
+int64_t apgp_packed_lsolve_len(int64_t n);
+int apgp_pack_lsolve(const double* L, int64_t n, int64_t ldl, double* packed, void* stream);
 int apgp_acquire_solve(const double* T, int64_t m, int64_t idx_offset,
-                       const double* L, int64_t ldl, const double* xs, int64_t n,
+                       const double* packed_lsolve, const double* xs, int64_t n,
                        const apgp_kernel_t* kern /*host*/, double mean, int32_t kind,
                        const double* lo /*host*/, const double* hi /*host*/,
                        const uint8_t* mask, double zeta, double ybest,

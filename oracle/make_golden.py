@@ -355,9 +355,94 @@ def d8_truth(ncand=30, dps=50):
         abs(float(d["ll"]) - float(ll))))
 
 
+def _mp_truth_amp2d(theta, y, p, cands, dps=60):
+    """mu / sigma^2 / alpha of a 2-D amplitude * ExpSquared GP (white noise e^-12) in
+    ``dps``-digit mpmath arithmetic, straight from SURVEY.md Appendix A.2-A.7 (LU solves on
+    the Gram matrix; no code shared with the oracle or the HIP path)."""
+    import mpmath as mp
+    mp.mp.dps = dps
+    amp = mp.mpf(2) * mp.exp(mp.mpf(float(p[1])))
+    w = [mp.exp(-mp.mpf(float(v))) for v in p[2:]]
+    wn = mp.exp(mp.mpf(-12))
+    X = [[mp.mpf(float(v)) for v in row] for row in theta]
+
+    def kfun(a, b):
+        return amp * mp.exp(-mp.mpf(1) / 2 * sum(w[d] * (a[d] - b[d]) ** 2 for d in range(2)))
+    n = len(X)
+    K = mp.matrix(n, n)
+    for i in range(n):
+        for j in range(n):
+            K[i, j] = kfun(X[i], X[j]) + (wn if i == j else 0)
+    r = mp.matrix([mp.mpf(float(v)) - mp.mpf(float(p[0])) for v in y])
+    alpha = mp.lu_solve(K, r)
+    mu_t, var_t = [], []
+    for c in cands:
+        cc = [mp.mpf(float(v)) for v in c]
+        ks = mp.matrix([kfun(cc, X[i]) for i in range(n)])
+        sol = mp.lu_solve(K, ks)
+        mu_t.append(float(sum(ks[i] * alpha[i] for i in range(n)) + mp.mpf(float(p[0]))))
+        var_t.append(float(amp - sum(ks[i] * sol[i] for i in range(n))))
+    return np.array(mu_t), np.array(var_t), np.array([float(a) for a in alpha])
+
+
+def cond_ladder(targets=(1e8, 1e11, 1e13)):
+    """Conditioning ladder (VERDICT round 2, item 1b): the reference's own 2-D Rosenbrock
+    training set (N = 50, fitAmp=True) at hyper-parameters on the straight line between
+    ``defaultGP``'s initial vector and the reference's optimum (test_OptimizeGP.py:50, true
+    cond(K) 8.5e15), stopped where the TRUE 2-norm condition number of K reaches 1e8 / 1e11 /
+    1e13.  Each fixture carries the oracle's outputs through the reference's scalar utilities
+    and a 60-digit mpmath truth for mu, sigma^2 and alpha, so that both variance formulations
+    of the HIP path (explicit L^-1 contraction and blocked substitution) can be judged against
+    exact arithmetic between the well-conditioned fixtures (cond <= 4.7e6) and the optimum."""
+    from scipy.optimize import brentq
+    with open(os.path.join(OUT, "pins.json")) as fh:
+        pins = json.load(fh)
+    with open(os.path.join(OUT, "meta.json")) as fh:
+        meta = json.load(fh)
+    popt = np.array(pins["harness_replay"]["optgp_amp"]["p"])
+    np.random.seed(57)
+    theta, y = rosen_set(50)
+    gp = gpUtils.defaultGP(theta, y, fitAmp=True)
+    p0 = gp.get_parameter_vector().copy()
+
+    def cond_at(s):
+        gp.set_parameter_vector(p0 + s * (popt - p0))
+        K = gp.kernel.get_value(theta)
+        K[np.diag_indices_from(K)] += np.exp(gp.white_noise.value)
+        return float(np.linalg.cond(K))
+    cands = np.random.RandomState(4321).uniform(-5.0, 5.0, size=(24, 2))
+    for tgt in targets:
+        s = brentq(lambda v: np.log10(cond_at(v)) - np.log10(tgt), 0.2, 1.0, xtol=1e-8)
+        p = p0 + s * (popt - p0)
+        gp.set_parameter_vector(p)
+        gp.recompute()
+        name = "rosen2d_n50_amp_cond1e%d" % int(round(np.log10(tgt)))
+        sweep_case(name, theta, y, gp, cands, [-5, -5], [5, 5], meta)
+        mu_t, var_t, alpha_t = _mp_truth_amp2d(theta, y, p, cands)
+        d = dict(np.load(os.path.join(OUT, name + ".npz")))
+        d["mu_truth"], d["var_truth"], d["alpha_truth"] = mu_t, var_t, alpha_t
+        d["path_s"] = np.array(s)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        rel = np.abs(d["var"] - var_t) / np.abs(var_t)
+        print("%s: cond %.3e  oracle var rel err vs truth median %.2e max %.2e; alpha %.2e" % (
+            name, d["cond"], np.median(rel), rel.max(),
+            np.abs(d["alpha"] - alpha_t).max() / np.abs(alpha_t).max()))
+    # the optimum's fixture gets its alpha truth too
+    name = "rosen2d_n50_amp_opt_illcond"
+    d = dict(np.load(os.path.join(OUT, name + ".npz")))
+    if "alpha_truth" not in d:
+        _, _, d["alpha_truth"] = _mp_truth_amp2d(d["theta"], d["y"], d["p"], d["cands"][:1])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    with open(os.path.join(OUT, "meta.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+
+
 if __name__ == "__main__":
     if "--d8-truth" in sys.argv:
         d8_truth()          # (augments the committed fixture; needs no reference import)
+    elif "--cond-ladder" in sys.argv:
+        cond_ladder()       # (adds the three mid-conditioning fixtures; leaves the others alone)
     else:
         main()
         d8_truth()
+        cond_ladder()

@@ -29,11 +29,12 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_abi_version_and_sizes():
     lib = _lib.load()
-    assert lib.apgp_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.apgp_abi_version() == _lib.ABI_VERSION == 5
     assert lib.apgp_npad(1) == 512 and lib.apgp_npad(512) == 512 and lib.apgp_npad(513) == 1024
     # packed L^-1: row block ib holds (ib+1)*32 tiles of 512 x 16 doubles
     for n, nrb in ((100, 1), (4096, 8), (4097, 9)):
         assert lib.apgp_packed_linv_len(n) == 32 * nrb * (nrb + 1) // 2 * 512 * 16
+        assert lib.apgp_packed_lsolve_len(n) == lib.apgp_packed_linv_len(n)
     assert lib.apgp_packed_train_len(4096, 8) == 4096 * 10
     assert lib.apgp_packed_train_len(100, 3) == 512 * 6
     assert lib.apgp_trtri_work_len(100) == 2 * 128 * 128
@@ -59,3 +60,6 @@ def test_bad_arguments_are_refused_without_a_gpu():
     assert lib.apgp_grad_loglik(None, None, None, 64, 4, ctypes.byref(ks), None, None, None) == -1
     assert lib.apgp_acquire(None, 1, 0, None, None, 4, ctypes.byref(ks), 0.0, 0, None, None, None,
                             0.01, 0.0, None, None, None, None, None, None) == -1
+    assert lib.apgp_acquire_solve(None, 1, 0, None, None, 4, ctypes.byref(ks), 0.0, 0, None, None, None,
+                                  0.01, 0.0, None, None, None, None, None, None) == -1
+    assert lib.apgp_pack_lsolve(None, 4, 4, None, None) == -1

@@ -4,8 +4,8 @@ known-answer constants reproduced ON THE HIP PATH (VERDICT round 1, items 1 and 
   C2  Rosenbrock 2-D, N_train = 1024, 1e5 candidates, BAPE           (configs[1])
   C4  D = 8, N = 4096, 1e7 candidates in 8 shards with idx_offset     (configs[3], emulated
       on one GPU: shard r = rows [r M/8, (r+1) M/8) of the one NumPy seed-1 draw)
-  C5  ApproxPosterior.run, D = 8, m0 = 512, m = 64, 64 walkers x 2e4  (configs[4]; nmax = 2
-      here, and the device sampler separately at N = 1152 = 512 + 10 x 64)
+  C5  ApproxPosterior.run, D = 8, m0 = 512, m = 64, nmax = 10, 64 walkers x 2e4 (configs[4];
+      optGPEveryN = m here -- see the test -- and the device sampler separately at N = 1152)
   a6  gpUtils.optimizeGP        vs test_OptimizeGP.py:91   (reference constant) + pins.json
   a12 ApproxPosterior.findNextPoint vs test_findNewPoint.py:107 (reference constant)
   f2  the 2-D Bayesian-optimisation test of the reference (test_2DBayesOpt.py:55-73)
@@ -159,20 +159,25 @@ def _oracle_twin(gp, theta):
     return o
 
 
-def test_c5_run_loop_d8(tmp_path, monkeypatch):
-    """BASELINE.json configs[4] shape: ApproxPosterior.run at D = 8, m0 = 512, m = 64,
-    nCandidates = 1e6 (the fused sweep is the point search), 64 walkers x 2e4 iterations with
-    the on-device sampler, nmax = 2 (approx.py:229-524).  Checked against the oracle:
-      * every appended design point: (mu, sigma^2, u) of the sweep winner at the GP state that
+def test_c5_run_loop_d8_nmax10_optgp_every_m(tmp_path, monkeypatch):
+    """BASELINE.json configs[4]: ApproxPosterior.run at D = 8, m0 = 512, m = 64, **nmax = 10**
+    (N grows 512 -> 1152), 64 walkers x 2e4 iterations on the on-device sampler,
+    nCandidates = 1e6 (the fused sweep is the point search), untruncated Powell re-optimisation
+    of the hyper-parameters (approx.py:229-524).  ONE deviation from the reference's defaults,
+    stated in the name: ``optGPEveryN = m`` (one ``optGP`` per outer iteration, 10 in all)
+    instead of the default 1 (640 optimisations of 1-2 s each = ~17 min, beyond the suite's time
+    limit; ``tools/run_configs.py --c5-as-written`` runs exactly that once per round and logs it
+    under gpurun_out/ / profiles/).  Checked against the oracle:
+      * appended design points: (mu, sigma^2, u) of the sweep winner at the GP state that
         selected it (hyper-parameters + training set at that moment) -- approx.py:648-691;
-      * the factor after the incremental appends of an iteration == a full oracle refit
+      * the factor after the incremental appends of the last iteration == a full oracle refit
         (log-likelihood and predictions) -- approx.py:693-717;
       * the device sampler's log-probabilities == oracle GP mean at the sampled coordinates;
       * the host (batched) sampler on the same surrogate: same check on its chain."""
     monkeypatch.chdir(tmp_path)
     from scipy.optimize import rosen
     from approxposterior_amd import approx, gpUtils, utility as ut
-    D, m0, m = 8, 512, 64
+    D, m0, m, nmax = 8, 512, 64, 10
     lnprior, sample, bounds = _box(D)
     lnlike = lambda t, *a, **k: -rosen(np.asarray(t).ravel()) / 100.0   # noqa: E731
     np.random.seed(11)
@@ -192,13 +197,12 @@ def test_c5_run_loop_d8(tmp_path, monkeypatch):
         return best, u
     monkeypatch.setattr(ut, "sweepObjective", spy)
     with np.errstate(all="ignore"):
-        ap.run(m=m, nmax=2, nCandidates=1_000_000, optGPEveryN=m, nGPRestarts=1, cache=False,
+        ap.run(m=m, nmax=nmax, nCandidates=1_000_000, optGPEveryN=m, nGPRestarts=1, cache=False,
                verbose=False, onDevice=True, estBurnin=True, thinChains=True,
-               mcmcKwargs={"iterations": 20000}, samplerKwargs={"nwalkers": 64},
-               gpOptions={"maxiter": 3, "xtol": 1e-2, "ftol": 1e-3})
-    assert len(picks) == 2 * m and len(ap.y) == m0 + 2 * m and ap.gp._x.shape == (m0 + 2 * m, D)
+               mcmcKwargs={"iterations": 20000}, samplerKwargs={"nwalkers": 64})
+    assert len(picks) == nmax * m and len(ap.y) == m0 + nmax * m == 1152 and ap.gp._x.shape == (1152, D)
     go, _ = _mods()
-    for best, u, mu, var, p, Xs, ys in picks[::4] + picks[-3:]:
+    for best, u, mu, var, p, Xs, ys in picks[::16] + picks[-3:]:
         o = go.GP(kernel=go.ExpSquaredKernel(np.exp(p[1:]), ndim=D), fit_mean=True, mean=float(p[0]),
                   white_noise=-12.0, fit_white_noise=False)
         o.compute(Xs)
@@ -217,7 +221,7 @@ def test_c5_run_loop_d8(tmp_path, monkeypatch):
     assert np.abs(mu - mo).max() <= 1e-9 * asum and np.abs(var - vo).max() <= 1e-9
     # device sampler: log-probability == oracle mean at the sampled coordinates
     chain, logp = ap.sampler.get_chain(), ap.sampler.get_log_prob()
-    assert chain.shape == (20000, 64, D) and len(ap.iburns) == 2
+    assert chain.shape == (20000, 64, D) and len(ap.iburns) == nmax
     for it in (0, 9999, 19999):
         assert np.abs(logp[it] - twin.predict(ap.y, chain[it], return_cov=False)).max() <= 1e-9 * asum
         assert np.all(np.abs(chain[it]) <= 5.0)

@@ -352,6 +352,81 @@ def test_oracle_parity_seeded(n, d, m, metric, lib_loaded):
         assert bi == -1
 
 
+@pytest.mark.parametrize("n,d,m,metric", [(1024, 2, 3000, 2.0), (700, 8, 1500, 8.0), (513, 3, 777, 1.0),
+                                           (64, 16, 200, 30.0), (1, 1, 5, 1.0), (17, 4, 1, 4.0),
+                                           (1300, 8, 20000, 8.0), (255, 2, 333, 2.0), (271, 5, 16500, 6.0)])
+def test_substitution_sweep_oracle_parity(n, d, m, metric, lib_loaded):
+    """The substitution form of the sweep (apgp_pack_lsolve + apgp_acquire_solve: blocked
+    forward substitution against L on the matrix cores, what george's cho_solve computes --
+    utility.py:131,178,224) vs the oracle at the same ragged sizes as the inverse form: one
+    and several 256-row blocks, partial last block / last 16-row and 4-row group, D = 1 .. 16,
+    more candidate blocks than CUs (several rounds of the persistent grid, parked V re-used),
+    the three utilities' arg-min.  Same tolerances as the inverse form."""
+    go, agp = _mods()
+    X, y = _synthetic(n, d)
+    cands = np.random.RandomState(1).uniform(-5.2, 5.2, size=(m, d))
+    gpo = go.GP(kernel=go.ExpSquaredKernel(np.full(d, metric), ndim=d), fit_mean=True, mean=np.median(y),
+                white_noise=-12, fit_white_noise=False)
+    gpo.compute(X)
+    gp = agp.GP(kernel=agp.ExpSquaredKernel(np.full(d, metric), ndim=d), fit_mean=True, mean=np.median(y),
+                white_noise=-12, fit_white_noise=False)
+    gp.variance_mode = "solve"
+    gp.compute(X)
+    K = gpo.kernel.get_value(gpo._x)
+    K[np.diag_indices_from(K)] += np.exp(-12.0)
+    tol = max(1e-13, 200 * np.linalg.cond(K) * EPS)
+    mo, vo = gpo.predict(y, cands, return_var=True)
+    mu, var = gp.predict(y, cands, return_var=True)
+    assert gp._packed_solve is not None and gp._packed is None      # no inverse was formed
+    alpha = gpo._compute_alpha(y, False)
+    assert np.abs(mu - mo).max() <= tol * max(np.abs(alpha).sum(), 1e-300)
+    assert np.abs(var - vo).max() <= tol
+    inside = np.all(np.abs(cands) <= 5, axis=1)
+    with np.errstate(all="ignore"):
+        uo = {"agp": -(mo + 0.5 * np.log(2 * np.pi * np.e * vo)),
+              "bape": -((2 * mo + vo) + (vo + np.log(1.0 - np.exp(-vo))))}
+    for kind in ("agp", "bape"):
+        want = np.where(inside, uo[kind], np.inf)
+        bi, bu, u, mu2, var2 = gp.acquire(y, cands, kind, bounds=[(-5, 5)] * d, return_all=True)
+        assert np.array_equal(mu2, mu) and np.array_equal(var2, var)     # same kernel, same bits
+        if np.isfinite(want).any():
+            ri = int(np.nanargmin(want))
+            assert bi == ri or abs(want[bi] - want[ri]) <= 1e-9 * max(1.0, abs(want[ri]))
+            fin = np.where(np.isfinite(u), u, np.inf)
+            assert bu == u[bi] and bi == int(np.argmin(fin))
+        else:
+            assert bi == -1
+
+
+@pytest.mark.parametrize("n,d,m", [(1152, 8, 30000), (2100, 5, 9000), (4096, 8, 40000)])
+def test_substitution_sweep_deterministic_and_matches_inverse(n, d, m, lib_loaded):
+    """The substitution form parks the solved blocks V from the MATRIX wavefronts and reads them
+    back through the feeders' LDS-DMA a row block later: a missing wait / stale line would show
+    as run-to-run differences.  Six launches bit-identical; and against the inverse form on
+    the same well-conditioned factor the two formulations agree to the conditioning bound."""
+    go, agp = _mods()
+    X, y = _synthetic(n, d)
+    def make(mode):
+        g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(d, 8.0), ndim=d), fit_mean=True, mean=np.median(y),
+                   white_noise=-12, fit_white_noise=False)
+        g.variance_mode = mode
+        g.compute(X)
+        return g
+    gs, gi = make("solve"), make("inverse")
+    T = np.random.RandomState(8).uniform(-5, 5, size=(m, d))
+    ref = gs.acquire(y, T, "bape", bounds=[(-5, 5)] * d, return_all=True)
+    for _ in range(5):
+        out = gs.acquire(y, T, "bape", bounds=[(-5, 5)] * d, return_all=True)
+        assert out[0] == ref[0] and out[1] == ref[1]
+        for a, b in zip(out[2:], ref[2:]):
+            assert np.array_equal(a, b, equal_nan=True)
+    inv = gi.acquire(y, T, "bape", bounds=[(-5, 5)] * d, return_all=True)
+    tol = max(1e-13, 200 * gs.cond_estimate * 100 * EPS)
+    assert np.abs(ref[4] - inv[4]).max() <= tol                     # sigma^2
+    assert np.abs(ref[3] - inv[3]).max() <= 1e-9 * np.abs(inv[3]).max()   # mu (alpha by trsv vs W)
+    assert ref[0] == inv[0] or abs(ref[1] - inv[1]) <= 1e-9 * abs(inv[1])
+
+
 @pytest.mark.parametrize("n,d", [(700, 8), (1100, 3), (50, 2), (129, 5)])
 def test_alpha_through_resident_inverse(n, d, lib_loaded):
     """K3 both ways: z = L^-1 r, alpha = L^-T z by the triangular solves (apgp_trsv) and, once
@@ -663,6 +738,47 @@ def test_illconditioned_uses_solve_path(golden_dir, lib_loaded):
     bi, bu = gp.acquire(g["y"], g["cands"], "bape", bounds=bounds)
     u_true = -((2 * mt + vt) + (vt + np.log(-np.expm1(-vt))))
     assert u_true[bi] <= u_true.min() + 0.3 * abs(u_true.min())
+
+
+LADDER = ["rosen2d_n50_amp_cond1e8", "rosen2d_n50_amp_cond1e11", "rosen2d_n50_amp_cond1e13"]
+
+
+@pytest.mark.parametrize("mode", ["inverse", "solve", None])
+@pytest.mark.parametrize("name", LADDER)
+def test_conditioning_ladder(golden_dir, name, mode, lib_loaded):
+    """Between the well-conditioned fixtures (cond <= 4.7e6) and the reference's fitAmp=True
+    optimum (8.5e15): the reference's own N = 50 Rosenbrock set at true cond(K) = 1e8 / 1e11 /
+    1e13 (oracle/make_golden.py cond_ladder), each with a 60-digit mpmath truth.  BOTH variance
+    formulations -- the explicit L^-1 contraction and the blocked substitution -- and the
+    automatic choice must stay in george's own error class against exact arithmetic: median
+    relative error of sigma^2 <= 3x the oracle's (cho_solve), largest absolute error <= 2x the
+    oracle's; alpha (through apgp_winv_apply resp. apgp_trsv) and mu likewise.  This is what
+    pins COND_SOLVE: the Cholesky-diagonal estimate under-reads the true condition number by
+    2-3 orders here (4e5 / 3e8 / 2.9e10 for 1e8 / 1e11 / 1e13), so the gate at 1e10 *estimated*
+    hands over between the 1e11 and 1e13 rungs, and the inverse is asserted good on both sides
+    of it (at 8.5e15 it is 200x off: test_illconditioned_uses_solve_path)."""
+    go, agp = _mods()
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    gp = build(agp, g)
+    gp.variance_mode = mode
+    est = gp.cond_estimate
+    assert est < g["cond"]                                   # the estimate is a lower bound
+    if mode is None:
+        assert gp._trust_inverse() == (est <= agp.COND_SOLVE)
+    mu, var = gp.predict(g["y"], g["cands"], return_var=True)
+    vt, mt, at = g["var_truth"], g["mu_truth"], g["alpha_truth"]
+    mine, ref = np.abs(var - vt), np.abs(g["var"] - vt)
+    assert np.median(mine / np.abs(vt)) <= 3.0 * np.median(ref / np.abs(vt)), (np.median(mine / np.abs(vt)), np.median(ref / np.abs(vt)))
+    assert mine.max() <= 2.0 * ref.max(), (mine.max(), ref.max())
+    alpha = gp._alpha.cpu().numpy()
+    assert np.abs(alpha - at).max() <= 3.0 * np.abs(g["alpha"] - at).max(), (np.abs(alpha - at).max(), np.abs(g["alpha"] - at).max())
+    assert np.abs(mu - mt).max() <= 3.0 * np.abs(g["mu"] - mt).max() + 1e-13 * np.abs(mt).max()
+    # the acquisition picks a candidate whose TRUE utility is the best one's (to the noise level)
+    bounds = list(zip(g["lo"], g["hi"]))
+    for kind, u_true in (("bape", -((2 * mt + vt) + (vt + np.log(-np.expm1(-vt))))),
+                         ("agp", -(mt + 0.5 * np.log(2 * np.pi * np.e * vt)))):
+        bi, bu = gp.acquire(g["y"], g["cands"], kind, bounds=bounds)
+        assert u_true[bi] <= u_true.min() + 1e-3 * abs(u_true.min())
 
 
 def make_full_logdet(make, X):
