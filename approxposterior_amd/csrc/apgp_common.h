@@ -195,3 +195,32 @@ __device__ __forceinline__ void apgp_exp4(const double (&xin)[4], double (&out)[
         out[i] = __hiloint2double(hi, __double2loint(res[i]));
     }
 }
+
+// ---------------------------------------------------------------------------
+// One Gram-matrix entry K(row, col) from the scaled coordinates of the two points (xi = row point,
+// xc = column point; xi may live in LDS).  Shared by gram_kernel and the fused small-N _nll kernel
+// (potrf.hip) so that both produce the same bits: explicit fma()s, contraction of the remaining
+// operations switched off (with -ffp-contract=fast hipcc would otherwise be free to fuse
+// amp * e + diag_add in one kernel and not in the other).
+// ---------------------------------------------------------------------------
+template <int DPAD, class XI>
+__device__ __forceinline__ double apgp_gram_value(const XI& xi, const double (&xc)[DPAD], const KernConst& kc,
+                                                  bool diagonal, const double* etab) {
+#pragma clang fp contract(off)
+    double s = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DPAD; d += 2) {
+        const double df0 = xi[d] - xc[d];
+        const double df1 = xi[d + 1] - xc[d + 1];
+        s = fma(df0, df0, s);
+        s3 = fma(df1, df1, s3);
+    }
+    double k = kc.amp * apgp_exp(-(s + s3), etab);
+    if (kc.lin_coef != 0.0) {
+        double ls;
+        APGP_LIN_SUM(ls, DPAD, kc.ndim, kc.lin_order, (xi[d_] * xc[d_]) * kc.lw[d_]);
+        k = fma(kc.lin_coef, ls, k);
+    }
+    if (diagonal) k = k + kc.diag_add;
+    return k;
+}

@@ -72,22 +72,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     for (int q = 0; q < 16; ++q) {
         const int r = g + 4 * q;
         const long long gi = i0 + r;
-        // same association as the sweep / mean kernels: two interleaved sums
-        double s = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int d = 0; d < DPAD; d += 2) {
-            double df0 = xi[r][d] - xc[d];
-            double df1 = xi[r][d + 1] - xc[d + 1];
-            s = fma(df0, df0, s);
-            s3 = fma(df1, df1, s3);
-        }
-        double k = a.kc.amp * apgp_exp(-(s + s3), etab);
-        if (a.kc.lin_coef != 0.0) {
-            double ls;
-            APGP_LIN_SUM(ls, DPAD, a.kc.ndim, a.kc.lin_order, xi[r][d_] * xc[d_] * a.kc.lw[d_]);
-            k = fma(a.kc.lin_coef, ls, k);
-        }
-        if (gi == gj) k += a.kc.diag_add;
+        // (same association as the sweep / mean kernels: two interleaved sums -- apgp_gram_value)
+        const double k = apgp_gram_value<DPAD>(xi[r], xc, a.kc, gi == gj, etab);
         if (gi < a.n && gj < a.n) a.K[gi * a.ldk + gj] = k;
     }
 }

@@ -428,6 +428,121 @@ __global__ __launch_bounds__(192) void potrf_panel_kernel(PotrfArgs a) {
     panel_solve_wave(a, j0, row, has_row, lane, x, Ls, invd, zblk, &prog, wb_index);
 }
 
+// ---------------------------------------------------------------------------
+// One gpUtils._nll evaluation (gpUtils.py:46-80) of a training set of n <= 64 points as ONE
+// single-workgroup launch: Gram block -> LDS (never through memory), the register-resident
+// factorisation of the panel step with the forward solve riding along (panel_factor_wave +
+// panel_helper_wave, exactly the code and operation order of the blocked path), and the
+// 5-value fit summary in potrf_finish_kernel's reduction order -- so the values are the bits
+// the three-launch path (gram + panel + finish) produces, without its two launch boundaries
+// (~7 us each) and with K never leaving the CU.  This is where the README
+// configuration (C1: N = 50 .. 90, 722-3,122 evaluations per optimizeGP) lives.
+// ---------------------------------------------------------------------------
+struct NllSmallArgs {
+    const double* X;
+    const double* y;
+    double* K;           // n x n (ld n): the factor on return (lower triangle)
+    double* z;           // n: L^-1 (y - shift)
+    int* info;
+    double* out5;
+    long long n;
+    double shift;
+    KernConst kc;
+};
+
+template <int DPAD>
+__global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
+    __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];
+    __shared__ __attribute__((aligned(16))) double invd[PB];
+    __shared__ double zblk[PB];
+    __shared__ int prog, hflag;
+    __shared__ double xs[PB][DPAD + 1];
+    __shared__ double etab[APGP_EXP_TAB_N];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int bs = (int)q.n;
+    apgp_exp_tab_load(etab);
+    if (t == 0) { prog = 0; hflag = 0; *(unsigned int*)q.info = 0xffffffffu; }
+    for (int e = t; e < PB * DPAD; e += 192) {
+        const int r = e / DPAD, d = e % DPAD;
+        xs[r][d] = (r < bs && d < q.kc.ndim) ? q.X[(long long)r * q.kc.ndim + d] * q.kc.sc[d] : 0.0;
+    }
+    __syncthreads();
+    // Gram block, lower triangle (zero above it and past n): thread = (column c, rows r = g, g + 3, ...)
+    {
+        const int c = lane, g = wv;
+        double xc[DPAD];
+#pragma unroll
+        for (int d = 0; d < DPAD; ++d) xc[d] = xs[c][d];
+        for (int r = g; r < PB; r += 3) {
+            double k = 0.0;
+            if (r < bs && c <= r) k = apgp_gram_value<DPAD>(xs[r], xc, q.kc, r == c, etab);
+            Ls[r][c] = k;
+        }
+    }
+    __syncthreads();
+    if (wv == 1) return;
+    if (wv == 2) {
+        panel_helper_wave(bs, lane, Ls, &prog, &hflag);
+        return;
+    }
+    PotrfArgs a;
+    a.A = q.K; a.rhs = q.z; a.n = q.n; a.lda = q.n; a.j0 = 0; a.shift = 0.0; a.info = q.info; a.out5 = nullptr;
+    a.dscr = nullptr; a.batch_dscr = 0; a.zoff = 0; a.batch_A = 0; a.batch_rhs = 0;
+    double ar[PB];
+    const double ri = lane < bs ? q.y[lane] - q.shift : 0.0;
+#pragma unroll
+    for (int k = 0; k < PB; k += 2) {
+        const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
+        ar[k] = (lane < bs && k <= lane) ? v.x : ((k == lane) ? 1.0 : 0.0);
+        ar[k + 1] = (lane < bs && k + 1 <= lane) ? v.y : ((k + 1 == lane) ? 1.0 : 0.0);
+    }
+    panel_factor_wave(a, 0, bs, lane, ar, ri, Ls, invd, zblk, &prog, &hflag, 0, 1);
+    // fit summary (potrf_finish_kernel's operations in its order: one element per lane, the
+    // butterfly over the wavefront; its sum over sixteen wavefront partials adds zeros here)
+    double sl = 0.0, mn = INFINITY, mx = -INFINITY, zz = 0.0;
+    if (lane < bs) {
+        const double d = Ls[lane][lane];
+        sl += log(d);
+        mn = fmin(mn, d);
+        mx = fmax(mx, d);
+        zz = fma(zblk[lane], zblk[lane], zz);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sl += __shfl_xor(sl, o);
+        zz += __shfl_xor(zz, o);
+        mn = fmin(mn, __shfl_xor(mn, o));
+        mx = fmax(mx, __shfl_xor(mx, o));
+    }
+    if (lane == 0) {
+        int inf = *q.info;                      // (this lane's own atomicMin, if any, precedes the read)
+        if ((unsigned int)inf == 0xffffffffu) inf = 0;
+        *q.info = inf;
+        q.out5[0] = 2.0 * sl;
+        q.out5[1] = mn;
+        q.out5[2] = mx;
+        q.out5[3] = zz;
+        q.out5[4] = (double)inf;
+    }
+}
+
+static int nll_small_launch(const double* X, int64_t n, const apgp_kernel_t* kern, const double* y, double mean,
+                            double* K, double* z, int32_t* info_dev, double* out5_dev, hipStream_t s) {
+    NllSmallArgs q;
+    if (apgp_make_kernconst(kern, &q.kc) != 0) {
+        apgp_set_error("apgp_nll_eval: bad argument: kernel parameters");
+        return -1;
+    }
+    q.X = X; q.y = y; q.K = K; q.z = z; q.info = info_dev; q.out5 = out5_dev; q.n = n; q.shift = mean;
+    switch (q.kc.dpad) {
+        case 2: hipLaunchKernelGGL(nll_small_kernel<2>, dim3(1), dim3(192), 0, s, q); break;
+        case 4: hipLaunchKernelGGL(nll_small_kernel<4>, dim3(1), dim3(192), 0, s, q); break;
+        case 8: hipLaunchKernelGGL(nll_small_kernel<8>, dim3(1), dim3(192), 0, s, q); break;
+        default: hipLaunchKernelGGL(nll_small_kernel<16>, dim3(1), dim3(192), 0, s, q); break;
+    }
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
 // One launch per block step after the first: the trailing update of block column j AND the panel
 // step of block column j + 1 (look-ahead).  Workgroups 0 .. tb-1 own the first trailing tile
 // column -- the next diagonal block (workgroup 0) and the next panel rows (workgroups 1 ..) -- and
@@ -727,13 +842,20 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
                              void* stream) {
     APGP_CHECK_ARG(X && kern && y && K && z && info_dev && out5_dev && out5_host, "null pointer");
     APGP_CHECK_ARG(n >= 1, "n >= 1 required");
-    // three launches fewer than the separate calls: the Gram launch initialises the right-hand side
-    // and the info word, the Cholesky's last launch writes the summary
-    int rc = apgp_gram_with_rhs(X, n, kern, K, n, y, mean, z, info_dev, stream);
-    if (rc != 0) return rc;
     hipStream_t s = (hipStream_t)stream;
-    rc = potrf_run(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, out5_dev);
-    if (rc != 0) return rc;
+    int rc;
+    if (n <= PB) {
+        // one single-workgroup launch (nll_small_kernel): same values, two launch boundaries fewer
+        rc = nll_small_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s);
+        if (rc != 0) return rc;
+    } else {
+        // three launches fewer than the separate calls: the Gram launch initialises the right-hand side
+        // and the info word, the Cholesky's last launch writes the summary
+        rc = apgp_gram_with_rhs(X, n, kern, K, n, y, mean, z, info_dev, stream);
+        if (rc != 0) return rc;
+        rc = potrf_run(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, out5_dev);
+        if (rc != 0) return rc;
+    }
     if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         apgp_set_error("apgp_nll_eval: D2H copy failed");
