@@ -14,6 +14,7 @@
 // Only a box prior can be evaluated on the device (arbitrary Python priors
 // cannot): the caller asserts lnprior == const inside [lo, hi], -inf outside.
 #include "apgp_common.h"
+#include <mutex>
 
 struct EnsArgs {
     const double* xs;      // packed training stream: Npad x (DPAD+2): scaled x | alpha | 0
@@ -273,21 +274,41 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
     dim3 grid((unsigned)nensembles), block(1024);
     const size_t xbytes = (size_t)a.n * (kc.dpad + 2) * sizeof(double);
     const bool xlds = xbytes <= 96 * 1024;
-#define APGP_LAUNCH_ENS(DP)                                                                            \
+    // the LDS-resident form needs > 64 KiB of dynamic LDS: per-device attribute, set and CHECKED once per
+    // device and instantiation
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        apgp_set_error("apgp_ensemble_sample: hipGetDevice failed");
+        return -2;
+    }
+    static std::mutex attr_mu;
+    static bool attr_done[4][64] = {{false}};
+#define APGP_LAUNCH_ENS(DP, SLOT)                                                                      \
     do {                                                                                               \
         if (xlds) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)ensemble_kernel<DP, true>,                          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);          \
+            {                                                                                          \
+                std::lock_guard<std::mutex> lock(attr_mu);                                             \
+                if (!attr_done[SLOT][dev]) {                                                           \
+                    const hipError_t e_ = hipFuncSetAttribute((const void*)ensemble_kernel<DP, true>,  \
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+                    if (e_ != hipSuccess) {                                                            \
+                        apgp_set_error("apgp_ensemble_sample: hipFuncSetAttribute(96 KiB of LDS) failed on device %d: %s", \
+                                       dev, hipGetErrorString(e_));                                    \
+                        return -2;                                                                     \
+                    }                                                                                  \
+                    attr_done[SLOT][dev] = true;                                                       \
+                }                                                                                      \
+            }                                                                                          \
             hipLaunchKernelGGL((ensemble_kernel<DP, true>), grid, block, xbytes, s, a);                \
         } else {                                                                                       \
             hipLaunchKernelGGL((ensemble_kernel<DP, false>), grid, block, 0, s, a);                    \
         }                                                                                              \
     } while (0)
     switch (kc.dpad) {
-        case 2: APGP_LAUNCH_ENS(2); break;
-        case 4: APGP_LAUNCH_ENS(4); break;
-        case 8: APGP_LAUNCH_ENS(8); break;
-        default: APGP_LAUNCH_ENS(16); break;
+        case 2: APGP_LAUNCH_ENS(2, 0); break;
+        case 4: APGP_LAUNCH_ENS(4, 1); break;
+        case 8: APGP_LAUNCH_ENS(8, 2); break;
+        default: APGP_LAUNCH_ENS(16, 3); break;
     }
 #undef APGP_LAUNCH_ENS
     APGP_CHECK_LAUNCH();

@@ -39,6 +39,10 @@ extern "C" int64_t apgp_trtri_work_len(int64_t n) {
     return 2 * np * np;
 }
 
+extern "C" int apgp_release_scratch(void* stream) {
+    return apgp_stream_scratch_release((hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------
 // K2: logdet + diagonal range.  One workgroup; the diagonal is N doubles.
 // ---------------------------------------------------------------------------
@@ -323,8 +327,7 @@ extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* 
         // launch-to-launch dependency; the single-workgroup form below costs ~10 us per block at N = 512
         // and 26 us per block at N = 4096).  Scratch and launches
         // of one solve are taken as a unit: host threads sharing a stream share the scratch.
-        static std::mutex enqueue_mu;
-        std::lock_guard<std::mutex> enqueue_lock(enqueue_mu);
+        std::lock_guard<std::mutex> enqueue_lock(apgp_stream_lock(st));   // (per device and stream)
         double* r = apgp_stream_scratch(1, st, (size_t)n);
         if (!r) {
             apgp_set_error("apgp_trsv: scratch allocation failed");

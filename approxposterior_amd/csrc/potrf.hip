@@ -480,7 +480,12 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
         }
     }
     __syncthreads();
-    if (wv == 1) return;
+    if (wv == 1) {
+        // (otherwise idle: the strict upper triangle of the factor in memory is written as zeros)
+        for (int r = 0; r < bs; ++r)
+            if (lane > r && lane < bs) q.K[(long long)r * q.n + lane] = 0.0;
+        return;
+    }
     if (wv == 2) {
         panel_helper_wave(bs, lane, Ls, &prog, &hflag);
         return;
@@ -760,15 +765,17 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
             a.out5[4] = (double)sinfo;
         }
     }
-    if (!a.dscr) return;
+    // the strict upper part of the diagonal block (Gram values / trailing-update leftovers, never read by
+    // the library) is cleared, so that a caller who allocated A zeroed holds a clean lower-triangular L
     const long long j0 = (long long)blockIdx.x * PB;
     const int bs = (int)((a.n - j0) < PB ? (a.n - j0) : PB);
-    const double* src = a.dscr + (long long)blockIdx.x * (PB * PB);
+    const double* src = a.dscr ? a.dscr + (long long)blockIdx.x * (PB * PB) : nullptr;
     for (int e = threadIdx.x; e < PB * PB; e += 256) {
         const int r = e >> 6, c = e & 63;
-        if (r < bs && c <= r) a.A[(j0 + r) * a.lda + j0 + c] = src[e];
+        if (r < bs && c <= r) { if (src) a.A[(j0 + r) * a.lda + j0 + c] = src[e]; }
+        else if (r < bs && c < bs) a.A[(j0 + r) * a.lda + j0 + c] = 0.0;
     }
-    if (a.rhs && threadIdx.x < bs) a.rhs[j0 + threadIdx.x] = a.dscr[a.zoff + j0 + threadIdx.x];
+    if (a.dscr && a.rhs && threadIdx.x < bs) a.rhs[j0 + threadIdx.x] = a.dscr[a.zoff + j0 + threadIdx.x];
 }
 
 // `batch` matrices A + b * batch_A (right-hand sides y - shifts[b] -> z + b * n) factorised by
@@ -781,8 +788,8 @@ static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t b
                      double* out5 = nullptr) {
     // One factorisation's launches are enqueued as a unit: two host threads on the same stream (ctypes
     // releases the GIL) must not interleave theirs -- they share the stream's scratch (scratch.h).
-    static std::mutex enqueue_mu;
-    std::lock_guard<std::mutex> enqueue_lock(enqueue_mu);
+    // (one lock per (device, stream): other streams and devices enqueue concurrently)
+    std::lock_guard<std::mutex> enqueue_lock(apgp_stream_lock(s));
     // info = UINT_MAX means "no failure yet"; normalised to 0 by the caller-visible finish kernel
     if (!pre_init && hipMemsetAsync(info_dev, 0xff, sizeof(int32_t) * batch, s) != hipSuccess) {
         apgp_set_error("apgp_potrf: memset failed");

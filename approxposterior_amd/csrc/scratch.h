@@ -1,21 +1,45 @@
 // Stream-ordered device scratch kept per (device, stream, slot) and grown on demand (hipMallocAsync /
 // hipFreeAsync): calls on one stream are serialised, so they can share a buffer; calls on different
 // streams cannot.  Slots: 0 = Cholesky (factored diagonal blocks), 1 = blocked triangular solve
-// (working right-hand side).  One definition for the whole library (inline function, static locals).
+// (working right-hand side).  One definition for the whole library (inline functions, static locals).
+//   * The device is the STREAM's (hipStreamGetDevice), not the caller's current device.
+//   * Entries live until apgp_release_scratch(stream) (include/apgp.h) or process exit: call it before
+//     destroying a stream -- a recycled stream handle would otherwise inherit the dead stream's entry.
+//   * Growing allocates (hipMallocAsync): the entry points that use scratch -- apgp_potrf / apgp_nll_eval*
+//     for n > 64, apgp_trsv for n >= 768 -- must not be called during stream capture.
+//   * apgp_stream_lock(stream): one mutex per (device, stream).  The launches of one factorisation /
+//     blocked solve share the stream's scratch and are enqueued as a unit under it; calls on different
+//     streams or devices do not serialise each other (round 2 had one process-wide mutex).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 
-inline double* apgp_stream_scratch(int slot, hipStream_t s, size_t doubles) {
-    struct Scr { double* p; size_t doubles; };
-    static std::mutex mu;
-    static std::map<std::tuple<int, hipStream_t, int>, Scr> tab;
+struct ApgpScratchTable {
+    struct Scr { double* p = nullptr; size_t doubles = 0; };
+    std::mutex mu;
+    std::map<std::tuple<int, hipStream_t, int>, Scr> tab;
+    std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::mutex>> locks;
+};
+inline ApgpScratchTable& apgp_scratch_table() {
+    static ApgpScratchTable t;
+    return t;
+}
+inline int apgp_stream_device(hipStream_t s) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    Scr& e = tab[std::make_tuple(dev, s, slot)];
+    if (s != nullptr && hipStreamGetDevice(s, &dev) == hipSuccess) return dev;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+
+inline double* apgp_stream_scratch(int slot, hipStream_t s, size_t doubles) {
+    ApgpScratchTable& t = apgp_scratch_table();
+    const int dev = apgp_stream_device(s);
+    if (dev < 0) return nullptr;
+    std::lock_guard<std::mutex> lock(t.mu);
+    ApgpScratchTable::Scr& e = t.tab[std::make_tuple(dev, s, slot)];
     if (e.doubles < doubles) {
         if (e.p) (void)hipFreeAsync(e.p, s);
         e.p = nullptr; e.doubles = 0;
@@ -25,4 +49,30 @@ inline double* apgp_stream_scratch(int slot, hipStream_t s, size_t doubles) {
         e.p = p; e.doubles = want;
     }
     return e.p;
+}
+
+inline std::mutex& apgp_stream_lock(hipStream_t s) {
+    ApgpScratchTable& t = apgp_scratch_table();
+    const int dev = apgp_stream_device(s);
+    std::lock_guard<std::mutex> lock(t.mu);
+    std::unique_ptr<std::mutex>& m = t.locks[std::make_pair(dev, s)];
+    if (!m) m.reset(new std::mutex());
+    return *m;             // (entries are never erased: the reference stays valid)
+}
+
+// frees (stream-ordered) every scratch buffer of `s`; returns the number of buffers released
+inline int apgp_stream_scratch_release(hipStream_t s) {
+    ApgpScratchTable& t = apgp_scratch_table();
+    const int dev = apgp_stream_device(s);
+    std::lock_guard<std::mutex> lock(t.mu);
+    int n = 0;
+    for (auto it = t.tab.begin(); it != t.tab.end();) {
+        if (std::get<0>(it->first) == dev && std::get<1>(it->first) == s) {
+            if (it->second.p) { (void)hipFreeAsync(it->second.p, s); ++n; }
+            it = t.tab.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return n;
 }

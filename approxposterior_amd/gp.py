@@ -305,7 +305,9 @@ class GP(object):
 
     # -- device plumbing -------------------------------------------------------
     def _reset_device_state(self):
-        self._L = None            # (N,N) lower Cholesky factor (device)
+        self._L = None            # (N,N) lower Cholesky factor (device); a view of _L_store["buf"] after appends
+        self._L_store = None      # growable store shared along a chain of appended GPs (compute(previous=))
+        self._ld = None           # leading dimension of _L in memory
         self._alpha_y = None      # host copy of the y alpha/z were computed for
         self._alpha_mean = None
         self._y_d = None
@@ -465,13 +467,26 @@ class GP(object):
         w_prev = None
         if getattr(prev, "_work", None) is not None and prev._trust_inverse():
             w_prev = prev._work
+        prev_L, prev_store = prev._L, getattr(prev, "_L_store", None)
         self._reset_device_state()
         self._computed = False
         with torch.cuda.device(dev):
             st = self._stream(torch)
             self._x_d = torch.from_numpy(self._x).to(dev)
-            L = torch.zeros((n1, n1), dtype=torch.float64, device=dev)
-            L[:n0, :n0].copy_(prev._L[:n0, :n0])
+            # The factor lives in a growable store shared along the chain of GP objects findNextPoint
+            # creates (approx.py:712-717: a new GP per appended point): rows are appended IN PLACE while
+            # the store has room and nobody else has appended to it (``used`` == the previous size: a
+            # second child of the same parent gets its own copy); otherwise a 1.5x larger zeroed store
+            # is allocated and the old factor copied once -- not an n x n allocation + copy per point.
+            if prev_store is not None and prev_store["used"] == n0 and prev_store["buf"].shape[0] >= n1:
+                store = prev_store
+            else:
+                cap = ((max(n1 + 63, int(1.5 * n1)) + 63) // 64) * 64
+                store = {"buf": torch.zeros((cap, cap), dtype=torch.float64, device=dev), "used": n0}
+                store["buf"][:n0, :n0].copy_(prev_L[:n0, :n0])
+            buf = store["buf"]
+            ld = buf.shape[1]
+            L = buf[:n1, :n1]
             row = torch.empty(n1, dtype=torch.float64, device=dev)
             ss = torch.empty(1, dtype=torch.float64, device=dev)
             info = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -487,21 +502,25 @@ class GP(object):
                                                    0, L[j].data_ptr(), ss.data_ptr(), None, st),
                                "apgp_winv_apply(append)")
                 else:
-                    _lib.check(lib.apgp_trsv(L.data_ptr(), j, n1, row.data_ptr(), 0.0, 0, L[j].data_ptr(),
+                    _lib.check(lib.apgp_trsv(L.data_ptr(), j, ld, row.data_ptr(), 0.0, 0, L[j].data_ptr(),
                                              ss.data_ptr(), st), "apgp_trsv(append)")
                 kxx = ks.amp            # k(x_new, x_new): amplitude + the linear term's sum_d (x_d^2)^P
                 if ks.lin_coef != 0.0:
                     kxx += ks.lin_coef * float(np.sum((self._x[j] * self._x[j]) ** ks.lin_order))
                 _lib.check(lib.apgp_append_diag(L[j, j:].data_ptr(), ss.data_ptr(), kxx + ks.diag_add,
                                                 info.data_ptr(), j + 1, st), "apgp_append_diag")
+            store["used"] = n1
             out5 = torch.empty(5, dtype=torch.float64, device=dev)
-            _lib.check(lib.apgp_fit_summary(L.data_ptr(), n1, n1, None, info.data_ptr(), out5.data_ptr(), st),
+            _lib.check(lib.apgp_fit_summary(L.data_ptr(), n1, ld, None, info.data_ptr(), out5.data_ptr(), st),
                        "apgp_fit_summary")
             o = out5.cpu().numpy()          # the only synchronisation of the extension
         if int(o[4]) != 0 or not np.isfinite(o[0]):
+            store["used"] = -1            # (the failed rows stay in the store: nobody may append to it again)
             self._reset_device_state()
             raise LinAlgError("%d-th leading minor of the array is not positive definite" % int(o[4]))
         self._L = L
+        self._L_store = store
+        self._ld = ld
         self.log_determinant = float(o[0])
         self.cond_estimate = float((o[2] / o[1]) ** 2)
         self._const = -0.5 * (n1 * np.log(2.0 * np.pi) + self.log_determinant)
@@ -527,7 +546,10 @@ class GP(object):
         with torch.cuda.device(dev):
             st = self._stream(torch)
             self._x_d = keep_x if keep_x is not None else torch.from_numpy(x).to(dev)
-            K = torch.empty((n, n), dtype=torch.float64, device=dev)
+            # zeroed: the library writes the lower triangle (Gram tiles on / below the diagonal, factor in
+            # place) and clears the diagonal blocks' upper parts, so what is kept as the factor is a clean
+            # lower-triangular L.  (n <= 64 with y: the fused kernel writes the whole n x n itself.)
+            K = (torch.empty if (yv is not None and n <= 64) else torch.zeros)((n, n), dtype=torch.float64, device=dev)
             z = None
             if yv is not None:
                 # the whole _nll evaluation as one library call and one synchronisation
@@ -561,6 +583,7 @@ class GP(object):
         if not np.isfinite(o[0]):
             raise LinAlgError("non-finite log-determinant")
         self._L = L
+        self._ld = n
         self.log_determinant = float(o[0])
         self.cond_estimate = float((o[2] / o[1]) ** 2)
         self._const = -0.5 * (n * np.log(2.0 * np.pi) + self.log_determinant)
@@ -618,7 +641,7 @@ class GP(object):
                                                    float(self.mean.value), 0, self._z.data_ptr(),
                                                    ztz.data_ptr(), None, st), "apgp_winv_apply(forward)")
                 else:
-                    _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, self._y_d.data_ptr(),
+                    _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, self._ld, self._y_d.data_ptr(),
                                              float(self.mean.value), 0, self._z.data_ptr(),
                                              ztz.data_ptr(), st), "apgp_trsv(forward)")
                 self._ztz_host = float(ztz.item())
@@ -634,7 +657,7 @@ class GP(object):
                                                    self._alpha.data_ptr(), None, wk.data_ptr(), st),
                                "apgp_winv_apply(backward)")
                 else:
-                    _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, n, self._z.data_ptr(), 0.0, 1,
+                    _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, self._ld, self._z.data_ptr(), 0.0, 1,
                                              self._alpha.data_ptr(), None, st), "apgp_trsv(backward)")
                 self._xs = None
         return self._ztz_host
@@ -727,7 +750,7 @@ class GP(object):
             st = self._stream(torch)
             self._work = torch.empty(lib.apgp_trtri_work_len(n), dtype=torch.float64, device=dev)
             self._packed = torch.empty(lib.apgp_packed_linv_len(n), dtype=torch.float64, device=dev)
-            _lib.check(lib.apgp_trtri_pack(self._L.data_ptr(), n, n, self._work.data_ptr(),
+            _lib.check(lib.apgp_trtri_pack(self._L.data_ptr(), n, self._ld, self._work.data_ptr(),
                                            self._packed.data_ptr(), None, st), "apgp_trtri_pack")
 
     def _ensure_lsolve(self):
@@ -739,7 +762,7 @@ class GP(object):
         with torch.cuda.device(dev):
             st = self._stream(torch)
             self._packed_solve = torch.empty(lib.apgp_packed_lsolve_len(n), dtype=torch.float64, device=dev)
-            _lib.check(lib.apgp_pack_lsolve(self._L.data_ptr(), n, n, self._packed_solve.data_ptr(), st),
+            _lib.check(lib.apgp_pack_lsolve(self._L.data_ptr(), n, self._ld, self._packed_solve.data_ptr(), st),
                        "apgp_pack_lsolve")
 
     def _ensure_xs(self, y):

@@ -128,6 +128,14 @@ int apgp_logdet(const double* L, int64_t n, int64_t ldl, double* out5, void* str
 int apgp_fit_summary(const double* L, int64_t n, int64_t ldl, const double* z,
                      const int32_t* info_dev, double* out5, void* stream);
 
+/* ---- stream scratch ------------------------------------------------------------
+ * apgp_potrf / apgp_nll_eval* (n > 64) and apgp_trsv (n >= 768) keep stream-ordered
+ * device scratch per (device of the stream, stream), grown with hipMallocAsync -- so
+ * they must not be called while the stream is being captured into a graph.
+ * apgp_release_scratch frees (stream-ordered) what `stream` holds and returns the
+ * number of buffers released: call it before destroying a stream.               */
+int apgp_release_scratch(void* stream);
+
 /* ---- one gpUtils._nll evaluation (gpUtils.py:46-80) in one call ---------------
  * apgp_gram -> apgp_potrf (z = L^-1 (y - mean) riding along) -> apgp_fit_summary ->
  * 40-byte D2H into out5_host -> one stream synchronisation.  K: n x n work (holds
