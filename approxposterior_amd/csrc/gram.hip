@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
         const long long gi = i0 + r;
         // (same association as the sweep / mean kernels: two interleaved sums -- apgp_gram_value)
         const double k = apgp_gram_value<DPAD>(xi[r], xc, a.kc, gi == gj, etab);
-        if (gi < a.n && gj < a.n) a.K[gi * a.ldk + gj] = k;
+        if (gi < a.n && gj <= gi) a.K[gi * a.ldk + gj] = k;      // (lower triangle only: LAPACK-style, as apgp_potrf)
     }
 }
 

@@ -765,17 +765,15 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
             a.out5[4] = (double)sinfo;
         }
     }
-    // the strict upper part of the diagonal block (Gram values / trailing-update leftovers, never read by
-    // the library) is cleared, so that a caller who allocated A zeroed holds a clean lower-triangular L
+    if (!a.dscr) return;
     const long long j0 = (long long)blockIdx.x * PB;
     const int bs = (int)((a.n - j0) < PB ? (a.n - j0) : PB);
-    const double* src = a.dscr ? a.dscr + (long long)blockIdx.x * (PB * PB) : nullptr;
+    const double* src = a.dscr + (long long)blockIdx.x * (PB * PB);
     for (int e = threadIdx.x; e < PB * PB; e += 256) {
         const int r = e >> 6, c = e & 63;
-        if (r < bs && c <= r) { if (src) a.A[(j0 + r) * a.lda + j0 + c] = src[e]; }
-        else if (r < bs && c < bs) a.A[(j0 + r) * a.lda + j0 + c] = 0.0;
+        if (r < bs && c <= r) a.A[(j0 + r) * a.lda + j0 + c] = src[e];
     }
-    if (a.dscr && a.rhs && threadIdx.x < bs) a.rhs[j0 + threadIdx.x] = a.dscr[a.zoff + j0 + threadIdx.x];
+    if (a.rhs && threadIdx.x < bs) a.rhs[j0 + threadIdx.x] = a.dscr[a.zoff + j0 + threadIdx.x];
 }
 
 // `batch` matrices A + b * batch_A (right-hand sides y - shifts[b] -> z + b * n) factorised by

@@ -172,24 +172,28 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 #define S2_CPB (S2_ROWS / SW_KC)         // chunks per row-block width (16)
 #define S2_NP (S2_ROWS / 32)             // sub-block pairs per tile (8)
 
+// which form of the feeder loop an instantiation gets (see the feeder role)
+static constexpr bool s2_structured_feeder(int dpad, bool solve) { return solve ? dpad == 2 : dpad != 8; }
+
 template <int DPAD, bool LIN, bool SOLVE>
 __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     constexpr int XS = DPAD + 2;
     constexpr int NKK = SW_KC / 4;
     constexpr int NP = S2_NP;
-    constexpr int XCHUNK16 = SW_KC * XS / 2;          // 16-byte pieces of one x chunk
-    constexpr int XPIECES = (XCHUNK16 + 63) / 64;     // ... per lane of ONE wavefront (burst)
+    constexpr int XCHUNK16 = SW_KC * XS / 2;
+    // doubles between two x buffers: the chunk itself, or (structured feeder: whole-wavefront LDS-DMA
+    // pieces of 1 KiB, ring of three buffers) the chunk rounded up to 1 KiB
+    constexpr bool SF = s2_structured_feeder(DPAD, SOLVE);
+    constexpr int XSTRIDE = SF ? (SW_KC * XS * 8 + 1023) / 1024 * 128 : SW_KC * XS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Aring = smem;                         // 3 tile images
     double* Bbuf = Aring + 3 * S2_TILE;           // 2 x 4 wavefronts x [2][64] x 16 B
-    double* Xbuf = Bbuf + 2 * 4 * 256;            // 2 x SW_KC x XS (split mode: shared by the feeders)
-    double* Xwall = Xbuf + 2 * SW_KC * XS;        // 8 wavefronts x 2 x SW_KC x XS (burst: private staging)
-    double* Etab = Xwall + 8 * 2 * SW_KC * XS;
+    double* Xbuf = Bbuf + 2 * 4 * 256;            // 2 x SW_KC x XS
+    double* Etab = Xbuf + (SF ? 3 : 2) * XSTRIDE;
     double* Shq = Etab + APGP_EXP_TAB_N;          // sum V^2 per candidate (matrix -> feeder)
-    double* Smu = Shq + SW_CAND;                  // burst: mu shares of the even | odd row blocks per candidate
-    double* red_u = Smu + 2 * SW_CAND;
+    double* red_u = Shq + SW_CAND;
     long long* red_i = (long long*)(red_u + 4);
-    double* Cst = red_u + 8;                      // sc | lo | hi | lw (4 x APGP_MAX_DIM)
+    double* Cst = red_u + 8;                      // sc | lo | hi | lw (4 x APGP_MAX_DIM), feeder only
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cl = lane & 15, kq = lane >> 4;
     apgp_exp_tab_load(Etab);
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         const unsigned tile = (unsigned)((SW_ROWS / SW_KC) * ib * (ib + 1) / 2 + kc);
         return tile * (unsigned)(SW_TILE * 8) + (unsigned)((jb & 1) * S2_TILE * 8);
     };
+    // (jb, kc, block) -> successor in the stream: next chunk, next row block, next candidate block
     // work of this workgroup: row blocks jb_lo .. jb_hi-1 of candidate blocks blk0, blk0 +
     // blk_step, ...  Persistent mode: every row block of every gridDim-th candidate block.
     // Split mode (short last round / small launches): ONE (candidate block, row block) item,
@@ -225,105 +230,10 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         jb_hi = jb_lo + 1;
         blk_step = a.blk_end;
     }
-    int ntile_blk = 0;                            // tiles of one candidate block of this workgroup
-    for (int jb = jb_lo; jb < jb_hi; ++jb) ntile_blk += nkc_of(jb);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, (int)a.xs_bytes, 0x00020000);
-    // parked B operands of this workgroup's slot: [chunk][half][wavefront group][lane] x 16 B
-    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.kcache + (long long)blockIdx.x * a.ncache * SW_BCH), 0, (int)a.kslot_bytes, 0x00020000);
-
-    // k*(t, x_k) for this lane's candidate (scaled coordinates tt) and the four rows 4 kk + kq of the x
-    // chunk staged at Xb, with their alpha: the B operand values of one chunk.  ONE definition for the
-    // burst and for the split mode's on-the-fly generation: same bits either way.
-    auto gen_values = [&](const double* Xb, const double (&tt)[DPAD], double (&bfv)[NKK], double (&al)[NKK]) {
-        double s2[NKK], s3[NKK], lsum[NKK];
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            s2[kk] = 0.0; s3[kk] = 0.0;
-            lsum[kk] = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;
-            al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
-        }
-#pragma unroll
-        for (int d = 0; d < DPAD; d += 2)
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const f64x2 xa = *(const f64x2*)(Xb + (kk * 4 + kq) * XS + d);
-                const double df0 = tt[d] - xa.x, df1 = tt[d + 1] - xa.y;
-                s2[kk] = fma(df0, df0, s2[kk]);
-                s3[kk] = fma(df1, df1, s3[kk]);
-                if (LIN && a.lin_order > 0) {
-                    const double p0_ = tt[d] * xa.x * Cst[3 * APGP_MAX_DIM + d], p1_ = tt[d + 1] * xa.y * Cst[3 * APGP_MAX_DIM + d + 1];
-                    double q0 = p0_, q1 = p1_;
-                    for (int e = 1; e < a.lin_order; ++e) { q0 *= p0_; q1 *= p1_; }
-                    lsum[kk] += q0 + q1;
-                }
-            }
-        double ex[NKK];
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) ex[kk] = -(s2[kk] + s3[kk]);
-        apgp_exp4(ex, bfv, Etab);
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) bfv[kk] = LIN ? fma(a.lin_coef, lsum[kk], bfv[kk] * a.amp) : bfv[kk] * a.amp;
-    };
-
-    // ---- burst (persistent mode, ALL EIGHT wavefronts, once per candidate block) -------------------
-    // k* of every chunk for the block's 64 candidates -> this workgroup's parked slot, and mu.
-    // Wavefront w takes candidate group w & 3 (16 candidates) and the row blocks of parity w >> 2 --
-    // matrix wavefronts the even ones, feeders the odd ones --, chunk after chunk: x chunk staged in
-    // the wavefront's own LDS buffer (next chunk's pieces in flight meanwhile), 4 values per lane, two
-    // 16-byte stores.  Round 2 generated a chunk on its first visit INSIDE the tile stream: next to a
-    // saturated MFMA stream the feeder's ~170 dependent fp64 instructions took 3-4 k cycles per chunk
-    // and every diagonal tile waited for them (5.6 % of the cycles at N = 4096, 20 % at N = 1024).
-    // Here the same arithmetic runs at the full fp64 rate with nothing else on the SIMDs (the DP pipe
-    // time is the same: the matrix cores share it), and every tile of the stream that follows takes
-    // its B operands from the parked slot.  A row block's share of mu is the same per-lane chain as in
-    // the split mode (gen order, then the two lane butterflies); even and odd shares are summed
-    // separately, in order, and added at the end -- sweep_finish_kernel adds split shares the same way.
-    auto burst = [&](const double (&tt)[DPAD]) {
-        const int g = w & 3, par0 = w >> 2;
-        double* Xw = Xwall + w * (2 * SW_KC * XS);
-        const unsigned voff = (unsigned)(g * 64 + lane) * 16u;
-        double mu_acc = 0.0;
-        f64x2 xr[XPIECES];
-        auto x_req = [&](int kc) {
-#pragma unroll
-            for (int j = 0; j < XPIECES; ++j)
-                xr[j] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(
-                    rs_x, (unsigned)(lane + 64 * j) * 16u, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0));
-        };
-        auto x_stage = [&](int buf) {
-#pragma unroll
-            for (int j = 0; j < XPIECES; ++j)
-                if (lane + 64 * j < XCHUNK16) *((f64x2*)(Xw + buf * SW_KC * XS) + lane + 64 * j) = xr[j];
-        };
-        int buf = 0;
-        if (par0 < nrb2) { x_req(S2_CPB * par0); x_stage(0); }
-        for (int jb = par0; jb < nrb2; jb += 2) {
-            const int kend = nkc_of(jb);
-            double mu_cur = 0.0;
-            for (int kc = S2_CPB * jb; kc < kend; ++kc) {
-                // next chunk of this wavefront (the first of its next row block after the last of this one)
-                const int kn = kc + 1 < kend ? kc + 1 : S2_CPB * (jb + 2);
-                const bool more = kn < kc_lim && (kc + 1 < kend || jb + 2 < nrb2);
-                if (more) x_req(kn);
-                double bfv[NKK], al[NKK];
-                gen_values(Xw + buf * SW_KC * XS, tt, bfv, al);
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) mu_cur = fma(bfv[kk], al[kk], mu_cur);
-                const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
-                f64x2 q0, q1;
-                q0.x = bfv[0]; q0.y = bfv[1]; q1.x = bfv[2]; q1.y = bfv[3];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_k, voff, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_k, voff, soff + 4096u, 0);
-                if (more) x_stage(buf ^ 1);
-                buf ^= 1;
-            }
-            double m = mu_cur;
-            m += __shfl_xor(m, 16);
-            m += __shfl_xor(m, 32);
-            mu_acc += m;
-        }
-        if (kq == 0) Smu[par0 * SW_CAND + g * 16 + cl] = mu_acc;
+    auto successor = [&](int& jb, int& kc, long long& blk) {
+        ++kc;
+        if (kc >= nkc_of(jb)) { ++jb; kc = 0; }
+        if (jb >= jb_hi) { jb = jb_lo; blk += blk_step; }
     };
 
     if (w < 4) {
@@ -341,6 +251,10 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
 #pragma unroll
                 for (int kp = 0; kp < 2; ++kp) dst[h][kp] = A2[((p * 2 + h) * 2 + kp) * 64];
         };
+        __syncthreads();                          // C : constants staged
+        __syncthreads();                          // P0: x chunks staged (feeders)
+        __syncthreads();                          // P : tile 0 published
+        int slot = 0, bpar = 0;
         // B operands of the current tile in all four rotations; half 0 = k-steps 0-1, 1 = 2-3
         double brot[4][NKK];
         auto load_b = [&](int buf, int half) {
@@ -351,25 +265,13 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                 brot[r][2 * half] = bv.x; brot[r][2 * half + 1] = bv.y;
             }
         };
-        __syncthreads();                          // C : constants staged
+        load_a(av[0], 0, 0);
+        load_b(0, 0);
+        // SOLVE: the solved blocks V are parked by the matrix wavefronts themselves (same slot
+        // layout the feeders of the inverse form write: [half][wavefront][lane] x 16 B)
+        const __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.kcache + (long long)blockIdx.x * a.ncache * SW_BCH), 0, (int)a.kslot_bytes, 0x00020000);
         for (long long blk = blk0; blk < a.blk_end; blk += blk_step) {
-            if (!a.split) {
-                // this lane's candidate in scaled coordinates (the feeders keep the flags)
-                double tt[DPAD];
-                const long long crow = blk * SW_CAND + w * 16 + cl;
-#pragma unroll
-                for (int d = 0; d < DPAD; ++d)
-                    tt[d] = (crow < a.m && d < a.ndim) ? a.T[crow * a.ndim + d] * Cst[d] : 0.0;
-                burst(tt);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                  // G : the block's k* are parked
-            } else {
-                __syncthreads();                  // P0: x chunks staged (feeders)
-            }
-            __syncthreads();                      // P : tile 0 published
-            int slot = 0, bpar = 0;
-            load_a(av[0], 0, 0);
-            load_b(0, 0);
             double qtot = 0.0;
             for (int jb = jb_lo; jb < jb_hi; ++jb) {
                 const int nkc = nkc_of(jb);
@@ -486,7 +388,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
 #pragma unroll
                                 for (int q2 = 0; q2 <= q; ++q2) ta[e++] = Ts[(q * 4 + q2) * 16];
                         }
-                        const bool park_now = jb + 1 < nrb2;     // (a later row block reads V_c)
+                        const bool park_now = a.ncache > 0 && jb + 1 < nrb2;
                         auto half = [&](int pr, int h, int kk) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
@@ -533,8 +435,8 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                                 const unsigned voff = (unsigned)(w * 64 + lane) * 16u;
                                 f64x2 q0, q1;
                                 q0.x = V[0]; q0.y = V[1]; q1.x = V[2]; q1.y = V[3];
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_k, voff, soff, 0);
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_k, voff, soff + 4096u, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_kv, voff, soff, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_kv, voff, soff + 4096u, 0);
                             }
                         };
 #pragma unroll
@@ -595,23 +497,30 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
 
     // ================================= feeder role =================================
     const int hw = w - 4, ht = t - 256;
+    const unsigned hoff = (unsigned)ht * 16u;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.linv, 0, (int)a.linv_bytes, 0x00020000);
-    const unsigned xoff = ht < XCHUNK16 ? (unsigned)ht * 16u : 0u;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, (int)a.xs_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.kcache + (long long)blockIdx.x * a.ncache * SW_BCH), 0, (int)a.kslot_bytes, 0x00020000);
+    const unsigned xoff = ht < XCHUNK16 ? hoff : 0u;
     auto x_fetch = [&](int kc) {
         return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0));
     };
     auto x_put = [&](int xb, f64x2 v) {
         if (ht < XCHUNK16) {
             if (xb == 0) *((f64x2*)Xbuf + ht) = v;
-            else *((f64x2*)(Xbuf + SW_KC * XS) + ht) = v;
+            else *((f64x2*)(Xbuf + XSTRIDE) + ht) = v;
         }
     };
-    // per-candidate state of the block being fed
+    const bool park = a.ncache > 0;
+    // per-candidate state of the block being fed (cur) and of the finished one (fin)
     double tt[DPAD];
-    double ktt_cur = a.amp, mu_cur = 0.0, mu_tot = 0.0;
-    int fl_cur = 0;
-    long long blk_cur = -1;
+    double ktt_cur = a.amp, ktt_fin = a.amp, mu_cur = 0.0, mu_tot = 0.0, mu_fin = 0.0;
+    int fl_cur = 0, fl_fin = 0;
+    long long blk_cur = -1, blk_fin = -1;
     auto load_candidates = [&](long long blk) {
+        // snapshot the finished block, then set up the new one
+        mu_fin = mu_tot; ktt_fin = ktt_cur; fl_fin = fl_cur; blk_fin = blk_cur;
         blk_cur = blk; mu_cur = 0.0; mu_tot = 0.0;
         const long long crow = blk * SW_CAND + hw * 16 + cl;
         const bool inb = blk < a.blk_end && crow < a.m;
@@ -637,49 +546,88 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         fl_cur = (adm ? 1 : 0) | (has_nan ? 2 : 0) | (inb ? 4 : 0);
         ktt_cur = LIN ? fma(a.lin_coef, ktl, a.amp) : a.amp;
     };
-    // split mode: generate the B operands of tile (jb, kc) on the fly -> LDS buffer bb, and (diagonal
-    // chunks) this row block's share of mu
+    // generate the B operands of tile (jb, kc) of the current block -> LDS buffer bb (and, on
+    // the chunk's first visit, the parked stream and this row block's share of mu)
     auto produce_b = [&](int jb, int kc, int bb, int xb) {
-        double bfv[NKK], al[NKK];
-        gen_values(Xbuf + xb * SW_KC * XS, tt, bfv, al);
-        if (kc >= S2_CPB * jb) {
+        double bfv[NKK];
+        {
+            const double* Xb = Xbuf + xb * XSTRIDE;
+            double s2[NKK], s3[NKK], al[NKK], lsum[NKK];
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) mu_cur = fma(bfv[kk], al[kk], mu_cur);
-            if (kc == nkc_of(jb) - 1) {
-                double m = mu_cur;
-                m += __shfl_xor(m, 16);
-                m += __shfl_xor(m, 32);
-                mu_tot += m;
-                mu_cur = 0.0;
+            for (int kk = 0; kk < NKK; ++kk) {
+                s2[kk] = 0.0; s3[kk] = 0.0;
+                lsum[kk] = (LIN && a.lin_order == 0) ? (double)a.ndim : 0.0;
+                al[kk] = Xb[(kk * 4 + kq) * XS + DPAD];
             }
+#pragma unroll
+            for (int d = 0; d < DPAD; d += 2)
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const f64x2 xa = *(const f64x2*)(Xb + (kk * 4 + kq) * XS + d);
+                    const double df0 = tt[d] - xa.x, df1 = tt[d + 1] - xa.y;
+                    s2[kk] = fma(df0, df0, s2[kk]);
+                    s3[kk] = fma(df1, df1, s3[kk]);
+                    if (LIN && a.lin_order > 0) {
+                        const double p0_ = tt[d] * xa.x * Cst[3 * APGP_MAX_DIM + d], p1_ = tt[d + 1] * xa.y * Cst[3 * APGP_MAX_DIM + d + 1];
+                        double q0 = p0_, q1 = p1_;
+                        for (int e = 1; e < a.lin_order; ++e) { q0 *= p0_; q1 *= p1_; }
+                        lsum[kk] += q0 + q1;
+                    }
+                }
+            double ex[NKK];
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) ex[kk] = -(s2[kk] + s3[kk]);
+            apgp_exp4(ex, bfv, Etab);
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) bfv[kk] = LIN ? fma(a.lin_coef, lsum[kk], bfv[kk] * a.amp) : bfv[kk] * a.amp;
+            if (kc >= S2_CPB * jb) {
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) mu_cur = fma(bfv[kk], al[kk], mu_cur);
+                if (kc == nkc_of(jb) - 1) {
+                    // row block complete: its share of mu, reduced over the 4 k-lanes, joins the
+                    // total in row-block order (the order sweep_finish_kernel adds split shares)
+                    double m = mu_cur;
+                    m += __shfl_xor(m, 16);
+                    m += __shfl_xor(m, 32);
+                    mu_tot += m;
+                    mu_cur = 0.0;
+                }
+                if (!SOLVE && park && jb + 1 < nrb2) {
+                    const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
+                    f64x2 q0, q1;
+                    q0.x = bfv[0]; q0.y = bfv[1]; q1.x = bfv[2]; q1.y = bfv[3];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_k, hoff, soff, SW_KAUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_k, hoff, soff + 256 * 16, SW_KAUX);
+                }
+            }
+            f64x2 o0, o1;
+            o0.x = bfv[0]; o0.y = bfv[1]; o1.x = bfv[2]; o1.y = bfv[3];
+            if (bb == 0) { f64x2* Bw = (f64x2*)(Bbuf + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
+            else { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
         }
-        f64x2 o0, o1;
-        o0.x = bfv[0]; o0.y = bfv[1]; o1.x = bfv[2]; o1.y = bfv[3];
-        if (bb == 0) { f64x2* Bw = (f64x2*)(Bbuf + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
-        else { f64x2* Bw = (f64x2*)(Bbuf + 1024 + hw * 256); Bw[lane] = o0; Bw[64 + lane] = o1; }
     };
     auto epilogue = [&]() {
         __syncthreads();                          // E1
         if (a.split) {
             if (kq == 0) {
-                const long long e = ((blk_cur - a.blk_begin) * SW_CAND + hw * 16 + cl) * nrb2 + jb_lo;
+                const long long e = ((blk_fin - a.blk_begin) * SW_CAND + hw * 16 + cl) * nrb2 + jb_lo;
                 a.sp_q[e] = Shq[hw * 16 + cl];
-                a.sp_mu[e] = mu_tot;
+                a.sp_mu[e] = mu_fin;
             }
             __syncthreads();                      // E2
             return;
         }
         double bu = INFINITY;
         long long bi = -1;
-        const long long crow = blk_cur * SW_CAND + hw * 16 + cl;
-        if (kq == 0 && (fl_cur & 4)) {
-            double mu = (Smu[hw * 16 + cl] + Smu[SW_CAND + hw * 16 + cl]) + a.mean;
-            double var = ktt_cur - Shq[hw * 16 + cl];
-            if (fl_cur & 2) { mu = NAN; var = NAN; }
+        const long long crow = blk_fin * SW_CAND + hw * 16 + cl;
+        if (kq == 0 && (fl_fin & 4)) {
+            double mu = mu_fin + a.mean;
+            double var = ktt_fin - Shq[hw * 16 + cl];
+            if (fl_fin & 2) { mu = NAN; var = NAN; }
             if (a.mu) a.mu[crow] = mu;
             if (a.var) a.var[crow] = var;
             if (a.kind != APGP_UTIL_NONE) {
-                const double uu = (fl_cur & 1) ? util_value(a.kind, mu, var, a.zeta, a.ybest) : INFINITY;
+                const double uu = (fl_fin & 1) ? util_value(a.kind, mu, var, a.zeta, a.ybest) : INFINITY;
                 if (a.u) a.u[crow] = uu;
                 best_merge(bu, bi, uu, a.idx_offset + crow);
             }
@@ -693,8 +641,8 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         __syncthreads();                          // E2
         if (ht == 0 && a.kind != APGP_UTIL_NONE) {
             for (int i = 1; i < 4; ++i) best_merge(bu, bi, red_u[i], red_i[i]);
-            a.part_u[blk_cur] = bu;
-            a.part_i[blk_cur] = bi;
+            a.part_u[blk_fin] = bu;
+            a.part_i[blk_fin] = bi;
         }
     };
 
@@ -702,84 +650,193 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     // Next to a saturated MFMA stream every feeder instruction waits for an issue slot (~10
     // cycles for a scalar one, ~100 for one that reads or writes VGPRs; tools/mfma_pair.hip),
     // so the per-tile work is a handful of LDS-DMA requests (buffer_load ... lds: no data
-    // VGPRs, no ds_write) and scalar bookkeeping.  Tile i+1's image and B operands are
+    // VGPRs, no ds_write) and scalar bookkeeping.  Tile i+1's image and parked operands are
     // requested right after barrier i-1 into slot (i+1) % 3 / buffer (i+1) & 1 -- both free
-    // since barrier i-1 -- and the vmcnt wait in front of barrier i publishes them.
-    struct Pos { int jb, kc; };
-    auto next_of = [&](const Pos& p) {
-        Pos q = p;
-        ++q.kc;
-        if (q.kc >= nkc_of(q.jb)) { ++q.jb; q.kc = 0; }
-        if (q.jb >= jb_hi) q.jb = jb_lo;          // (past the block's last tile: a harmless valid position)
-        return q;
-    };
-    const int hw_s = __builtin_amdgcn_readfirstlane(hw);
-    typedef __attribute__((address_space(3))) void lds_void;
-    // image of tile (jb, kc): 8 pieces of 4 KiB = the 8 sub-block pairs (32 rows each), a quarter
-    // of each piece per feeder wavefront.
-    auto dma_tile = [&](int slot, int jb, int kc) {
-        double* dst = Aring + slot * S2_TILE + hw_s * 128;
-        const unsigned toffs = tile_off(jb, kc);
+    // since barrier i-1 -- and the vmcnt(0) hipcc places in front of barrier i publishes them.
+    // Two forms of the feeder loop, chosen per instantiation by same-box A/B (profiles/r03g): next to a
+    // saturated MFMA stream the feeder's cost is a matter of how hipcc allocates this loop's scalars (a
+    // spilled one read back with v_readlane costs 30-100 cycles), and that differs between the DPAD
+    // instantiations.  Structured: +8-13 % at N = 1024-2048 for DPAD 2 / 4 / 16 (inverse form) and for
+    // DPAD 2 (substitution form); the single loop is 1.5-2.5 % faster for DPAD 8 (C3, C5).
+    if constexpr (SF) {
+        const int hw_s = __builtin_amdgcn_readfirstlane(hw);
+        typedef __attribute__((address_space(3))) void lds_void;
+        // image of tile (jb, kc): 8 pieces of 4 KiB = the 8 sub-block pairs (32 rows each), a quarter
+        // of each piece per feeder wavefront.  (Requesting only the non-zero pairs q >= (kc - 16 jb) / 2
+        // of a lower-triangular diagonal tile -- 288 instead of 512 KiB per row block -- changes
+        // nothing, 248.9 vs 247.4 ms: the diagonal tiles do not wait for the image stream.)
+        auto dma_tile = [&](int slot, int jb, int kc) {
+            double* dst = Aring + slot * S2_TILE + hw_s * 128;
+            const unsigned toffs = tile_off(jb, kc);
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + q * 512), 16, (unsigned)lane * 16u,
-                                                     toffs + (unsigned)(q * 4096) + (unsigned)hw_s * 1024u, 0, 0);
-    };
-    // parked B operands of chunk c -> B buffer `par`: sc1 = served by the L2 (the slot was written by all
-    // eight wavefronts of this workgroup -- and, SOLVE, rewritten by its matrix wavefronts --, never by a
-    // line this CU's vector cache kept from the previous candidate block)
-    auto dma_parked = [&](int par, int c) {
-        double* dst = Bbuf + par * 1024 + hw_s * 256;
-        const unsigned soff = (unsigned)c * (unsigned)(SW_BCH * 8) + (unsigned)hw_s * 1024u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)dst, 16, (unsigned)lane * 16u, soff, 0, 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, 16);
-    };
-    __syncthreads();                              // C : constants visible
-    for (long long blk = blk0; blk < a.blk_end; blk += blk_step) {
-        load_candidates(blk);
-        Pos p1 = next_of(Pos{jb_lo, 0}), p2 = next_of(p1), p3 = next_of(p2);
-        f64x2 xq = {0.0, 0.0};
-        dma_tile(0, jb_lo, 0);                    // (lands during the burst)
-        if (!a.split) {
-            burst(tt);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                      // G : the block's k* are parked
-            dma_parked(0, 0);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        } else {
-            x_put(0, x_fetch(0));
-            x_put(1, x_fetch(p1.kc));
-            __syncthreads();                      // P0
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + q * 512), 16, (unsigned)lane * 16u,
+                                                         toffs + (unsigned)(q * 4096) + (unsigned)hw_s * 1024u, 0, 0);
+        };
+        auto dma_parked = [&](int par, int c) {
+            double* dst = Bbuf + par * 1024 + hw_s * 256;
+            const unsigned soff = (unsigned)c * (unsigned)(SW_BCH * 8) + (unsigned)hw_s * 1024u;
+            // (SOLVE: the parked blocks were stored by the matrix wavefronts of this workgroup: sc1 = served by
+            // the L2, never by a line this CU's vector cache kept from the previous candidate block)
+            constexpr int kaux = SOLVE ? 16 : SW_KAUX;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)dst, 16, (unsigned)lane * 16u, soff, 0, kaux);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, kaux);
+        };
+        // x chunk kc of the packed training stream straight into x buffer xb by LDS-DMA (whole wavefronts
+        // only: the chunk is rounded up to 1 KiB pieces, the extra lanes fetch the bytes that follow it in
+        // the stream -- zeros past its end -- into the buffer's padding)
+        auto x_dma = [&](int xb, int kc) {
+            if (hw_s * 128 < XSTRIDE)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(Xbuf + xb * XSTRIDE + hw_s * 128), 16,
+                                                         (unsigned)ht * 16u, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0, 0);
+        };
+        auto nd0_of = [&](int jb) { const int v = S2_CPB * jb, n = nkc_of(jb); return park ? (v < n ? v : n) : 0; };
+        auto next_gen = [&](int& jb, int& kc) {
+            if (kc + 1 < nkc_of(jb)) { ++kc; return; }
+            jb = jb + 1 < jb_hi ? jb + 1 : jb_lo;
+            kc = nd0_of(jb);
+        };
+        const bool xw = hw_s * 128 < XSTRIDE;
+#define S2_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+        __syncthreads();                              // C : constants visible
+        load_candidates(blk0);
+        dma_tile(0, jb_lo, 0);
+        {
+            int gj = jb_lo, gk = 0;
+            x_dma(0, gk);
+            next_gen(gj, gk);
+            x_dma(1, gk);
+            next_gen(gj, gk);
+            x_dma(2, gk);
+            __syncthreads();                          // P0 (vmcnt(0): image 0 and the x chunks have landed)
             produce_b(jb_lo, 0, 0, 0);
-            xq = x_fetch(p2.kc);
         }
-        __syncthreads();                          // P : tile 0 published
-        int slot = 1, par = 1;
-        for (int i = 0; i < ntile_blk; ++i) {
-            // ---- produce tile i+1 = p1 (the matrix wavefronts have just passed barrier i-1) ----
-            int n_pend = 0;
-            if (i + 1 < ntile_blk) {
-                if (a.split) __builtin_amdgcn_s_setprio(3);
-                dma_tile(slot, p1.jb, p1.kc);
-                if (a.split) {
-                    produce_b(p1.jb, p1.kc, par, par);
-                    x_put(par ^ 1, xq);           // x chunk of tile i+2
-                    xq = x_fetch(p3.kc);          // (tile i+3; a register load hipcc tracks itself)
-                    n_pend = 1;
-                } else {
-                    dma_parked(par, p1.kc);
+        __syncthreads();                              // P
+        int slot = 1, par = 1, gpar = 1;
+        bool first_tile = true;
+        for (long long blk = blk0; blk < a.blk_end; blk += blk_step) {
+            for (int jb = jb_lo; jb < jb_hi; ++jb) {
+                const int nkc = nkc_of(jb), nd0 = nd0_of(jb);
+                // ---- run of parked tiles: image + parked operands by LDS-DMA, nothing else ----
+                for (int kc = 0; kc < nd0; ++kc) {
+                    dma_tile(slot, jb, kc);
+                    dma_parked(par, kc);
+                    slot = slot == 2 ? 0 : slot + 1;
+                    par ^= 1;
+                    S2_BARRIER(0);
+                }
+                // ---- run of generating tiles ----
+                for (int kc = nd0; kc < nkc; ++kc) {
+                    if (first_tile) { first_tile = false; continue; }      // T_0: the prologue's
+                    const bool newblk = (jb == jb_lo && kc == 0);
+                    __builtin_amdgcn_s_setprio(3);
+                    dma_tile(slot, jb, kc);
+                    if (newblk) load_candidates(blk);
+                    int xk = kc;                      // chunk of the generating tile after next
+                    {
+                        int gj = jb;
+                        next_gen(gj, xk);
+                        next_gen(gj, xk);
+                    }
+                    const bool stores = !SOLVE && park && kc >= S2_CPB * jb && jb + 1 < nrb2;
+                    produce_b(jb, kc, par, gpar);
+                    x_dma(gpar == 0 ? 2 : gpar - 1, xk);
+                    slot = slot == 2 ? 0 : slot + 1;
+                    par ^= 1;
+                    gpar = gpar == 2 ? 0 : gpar + 1;
+                    __builtin_amdgcn_s_setprio(0);
+                    if (stores) { if (xw) S2_BARRIER(3); else S2_BARRIER(2); }
+                    else { if (xw) S2_BARRIER(1); else S2_BARRIER(0); }
+                    // the matrix wavefronts have passed the barrier of the previous block's last tile
+                    if (newblk) epilogue();
                 }
             }
-            p1 = p2; p2 = p3; p3 = next_of(p3);
+        }
+        load_candidates(a.blk_end);                   // (no next block: only snapshots the finished one)
+        S2_BARRIER(0);                                // barrier of the last tile
+        epilogue();
+#undef S2_BARRIER
+    } else {
+        struct Pos { int jb, kc; long long bl; };
+        Pos p0 = {jb_lo, 0, blk0}, p1, p2, p3;
+        auto next_of = [&](const Pos& p) { Pos q = p; successor(q.jb, q.kc, q.bl); return q; };
+        p1 = next_of(p0); p2 = next_of(p1); p3 = next_of(p2);
+        const int hw_s = __builtin_amdgcn_readfirstlane(hw);
+        typedef __attribute__((address_space(3))) void lds_void;
+        // image of tile (jb, kc): 8 pieces of 4 KiB = the 8 sub-block pairs (32 rows each), a quarter
+        // of each piece per feeder wavefront.  (Requesting only the non-zero pairs q >= (kc - 16 jb) / 2
+        // of a lower-triangular diagonal tile -- 288 instead of 512 KiB per row block -- changes
+        // nothing, 248.9 vs 247.4 ms: the diagonal tiles do not wait for the image stream.)
+        auto dma_tile = [&](int slot, int jb, int kc) {
+            double* dst = Aring + slot * S2_TILE + hw_s * 128;
+            const unsigned toffs = tile_off(jb, kc);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + q * 512), 16, (unsigned)lane * 16u,
+                                                         toffs + (unsigned)(q * 4096) + (unsigned)hw_s * 1024u, 0, 0);
+        };
+        auto dma_parked = [&](int par, int c) {
+            double* dst = Bbuf + par * 1024 + hw_s * 256;
+            const unsigned soff = (unsigned)c * (unsigned)(SW_BCH * 8) + (unsigned)hw_s * 1024u;
+            // (SOLVE: the parked blocks were stored by the matrix wavefronts of this workgroup: sc1 = served by
+            // the L2, never by a line this CU's vector cache kept from the previous candidate block)
+            constexpr int kaux = SOLVE ? 16 : SW_KAUX;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)dst, 16, (unsigned)lane * 16u, soff, 0, kaux);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(dst + 128), 16, (unsigned)lane * 16u, soff + 4096u, 0, kaux);
+        };
+        auto is_gen = [&](const Pos& p) { return !park || p.kc >= S2_CPB * p.jb; };
+        // ---- prologue: tile 0 and its operands, x chunks of tiles 0 and 1, requests for tile 1 ----
+        __syncthreads();                              // C : constants visible
+        load_candidates(p0.bl);
+        dma_tile(0, p0.jb, p0.kc);
+        x_put(0, x_fetch(p0.kc));
+        x_put(1, x_fetch(p1.kc));
+        __syncthreads();                              // P0
+        produce_b(p0.jb, p0.kc, 0, 0);
+        f64x2 xq = x_fetch(p2.kc);
+        __syncthreads();                              // P
+        // total tiles of this workgroup
+        long long ntile_blk = 0;
+        for (int jb = jb_lo; jb < jb_hi; ++jb) ntile_blk += nkc_of(jb);
+        long long nblk_mine = 0;
+        for (long long b = blk0; b < a.blk_end; b += blk_step) ++nblk_mine;
+        const long long ntot = ntile_blk * nblk_mine;
+        bool last_m1 = (ntile_blk == 1), last_m2 = false;
+        int slot = 1, par = 1;
+        for (long long i = 0;; ++i) {
+            // the matrix wavefronts have just passed barrier i-1: if tile i-1 closed a candidate
+            // block, finish that block
+            if (last_m2) epilogue();
+            if (i == ntot) break;
+            // ---- produce tile i+1 = p1 ----
+            // (a generating iteration is what the matrix wavefronts wait for on the diagonal tiles: it
+            // runs at raised priority -- same box, alternating, 244.4 vs 245.5 ms; raising it for the
+            // image requests only is neutral)
+            if (is_gen(p1)) __builtin_amdgcn_s_setprio(3);
+            dma_tile(slot, p1.jb, p1.kc);
+            if (p1.jb == jb_lo && p1.kc == 0) load_candidates(p1.bl);
+            if (is_gen(p1)) produce_b(p1.jb, p1.kc, par, par);
+            else dma_parked(par, p1.kc);
+            x_put(par ^ 1, xq);                       // x chunk of tile i+2
+            // VMEM requests of this iteration that barrier i need NOT wait for: the park stores of a
+            // first-visit tile (read back a row block later) and the x chunk fetched for tile i+3 (a
+            // register load hipcc tracks itself).  They are the LAST requests issued, and gfx9 VMEM
+            // completes in issue order, so "at most n outstanding" still means the images and parked
+            // operands of tile i+1 have landed -- without the ~1-2 k cycles of store acknowledgement.
+            int n_pend = (!SOLVE && is_gen(p1) && park && p1.kc >= S2_CPB * p1.jb && p1.jb + 1 < nrb2) ? 2 : 0;
+            if (is_gen(p3)) { xq = x_fetch(p3.kc); ++n_pend; }
+            last_m2 = last_m1;
+            last_m1 = (p1.jb == jb_hi - 1 && p1.kc == nkc_of(p1.jb) - 1);
+            p0 = p1; p1 = p2; p2 = p3; p3 = next_of(p3);
             slot = slot == 2 ? 0 : slot + 1;
             par ^= 1;
             __builtin_amdgcn_s_setprio(0);
-            // barrier i.  (gfx9 VMEM completes in issue order: "at most one outstanding" = the x chunk
-            // requested last, the image and operands of tile i+1 have landed)
+            // barrier i
             if (n_pend == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (n_pend == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (n_pend == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        epilogue();
     }
 }
 
@@ -811,15 +868,9 @@ __global__ __launch_bounds__(64) void sweep_finish_kernel(SweepArgs a) {
         }
         if (a.mask && a.mask[crow] == 0) adm = false;
         const long long e0 = ((long long)blockIdx.x * SW_CAND + c) * a.nrb;
-        // (mu: even and odd row blocks' shares summed separately, in order, then added -- the order of
-        // the persistent path, whose burst splits the row blocks between two wavefronts by parity)
-        double q = 0.0, mue = 0.0, muo = 0.0;
-        for (int ib = 0; ib < a.nrb; ++ib) {
-            q += a.sp_q[e0 + ib];
-            if (ib & 1) muo += a.sp_mu[e0 + ib];
-            else mue += a.sp_mu[e0 + ib];
-        }
-        double mu = (mue + muo) + a.mean;
+        double q = 0.0, mup = 0.0;
+        for (int ib = 0; ib < a.nrb; ++ib) { q += a.sp_q[e0 + ib]; mup += a.sp_mu[e0 + ib]; }
+        double mu = mup + a.mean;
         double var = fma(a.lin_coef, ktl, a.amp) - q;
         if (has_nan) { mu = NAN; var = NAN; }
         if (a.mu) a.mu[crow] = mu;
@@ -844,13 +895,13 @@ __global__ __launch_bounds__(64) void sweep_finish_kernel(SweepArgs a) {
 #define S2_SPLIT_MAX 184
 
 static inline int s2_nrb(int64_t n) { return (int)((n + S2_ROWS - 1) / S2_ROWS); }
-// chunks per workgroup slot: the burst parks the B operands of every chunk of a candidate block
-static inline long long s2_ncache(int64_t n) { return (long long)S2_CPB * s2_nrb(n); }
+// chunks per workgroup slot whose B operands are revisited by a later 256-row block
+static inline long long s2_ncache(int64_t n) { return (long long)S2_CPB * (s2_nrb(n) - 1); }
 
 // dynamic LDS of sweep2_kernel<DPAD, *>
 template <int DPAD>
-static constexpr size_t s2_lds_bytes() {
-    return (3 * S2_TILE + 2 * 4 * 256 + (2 + 16) * SW_KC * (DPAD + 2) + APGP_EXP_TAB_N + 3 * SW_CAND + 8 +
+static constexpr size_t s2_lds_bytes() {      // (the larger of the two feeder forms' x staging)
+    return (3 * S2_TILE + 2 * 4 * 256 + 3 * ((SW_KC * (DPAD + 2) * 8 + 1023) / 1024 * 128) + APGP_EXP_TAB_N + SW_CAND + 8 +
             4 * APGP_MAX_DIM) * sizeof(double);
 }
 
@@ -946,7 +997,9 @@ static int acquire_impl(bool solve, const double* T, int64_t m, int64_t idx_offs
     APGP_CHECK_ARG(m >= 1 && n >= 1, "m >= 1 and n >= 1 required");
     APGP_CHECK_ARG(kind >= APGP_UTIL_AGP && kind <= APGP_UTIL_NONE, "unknown utility kind");
     APGP_CHECK_ARG(kind == APGP_UTIL_NONE || best, "best required for an acquisition");
-    APGP_CHECK_ARG(part, "part (apgp_acquire_work_len doubles) required");
+    APGP_CHECK_ARG(part || (kind == APGP_UTIL_NONE && n <= S2_ROWS),
+                   "part (apgp_acquire_work_len doubles) required");
+    (void)solve;
     APGP_CHECK_ARG((lo == NULL) == (hi == NULL), "lo and hi must be given together");
     KernConst kc;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
@@ -958,14 +1011,15 @@ static int acquire_impl(bool solve, const double* T, int64_t m, int64_t idx_offs
     a.part_u = (double*)part;
     a.part_i = part ? (long long*)((double*)part + nblk) : NULL;
     a.ncache = (int)s2_ncache(n);
-    a.kcache = (double*)part + 2 * nblk;
+    // N <= 256: nothing is parked; the descriptor then points at the factor (never dereferenced)
+    a.kcache = a.ncache > 0 ? (double*)part + 2 * nblk : (double*)packed_linv;
     // row-block shares of the split last round (after the parked-operand slots)
     a.sp_q = part ? (double*)part + 2 * nblk + slots * s2_ncache(n) * SW_BCH : NULL;
     a.sp_mu = a.sp_q ? a.sp_q + (long long)S2_SPLIT_MAX * SW_CAND * s2_nrb(n) : NULL;
     a.blk_begin = 0; a.blk_end = nblk; a.split = 0;
     {
         const long long wb = apgp_packed_linv_len(n) * 8, xb = apgp_packed_train_len(n, kc.ndim) * 8;
-        const long long kb = (long long)a.ncache * SW_BCH * 8;
+        const long long kb = (long long)(a.ncache > 0 ? a.ncache : 1) * SW_BCH * 8;
         APGP_CHECK_ARG(wb < (1ll << 31) && kb < (1ll << 31), "n too large for the sweep's 32-bit stream offsets");
         a.linv_bytes = (unsigned)wb; a.xs_bytes = (unsigned)xb; a.kslot_bytes = (unsigned)kb;
     }

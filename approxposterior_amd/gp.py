@@ -546,9 +546,9 @@ class GP(object):
         with torch.cuda.device(dev):
             st = self._stream(torch)
             self._x_d = keep_x if keep_x is not None else torch.from_numpy(x).to(dev)
-            # zeroed: the library writes the lower triangle (Gram tiles on / below the diagonal, factor in
-            # place) and clears the diagonal blocks' upper parts, so what is kept as the factor is a clean
-            # lower-triangular L.  (n <= 64 with y: the fused kernel writes the whole n x n itself.)
+            # zeroed: the library reads and writes the lower triangle only (Gram, factor in place -- LAPACK's
+            # dpotrf contract), so what is kept as the factor is a clean lower-triangular L.
+            # (n <= 64 with y: the fused kernel writes the whole n x n itself.)
             K = (torch.empty if (yv is not None and n <= 64) else torch.zeros)((n, n), dtype=torch.float64, device=dev)
             z = None
             if yv is not None:

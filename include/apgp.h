@@ -88,9 +88,10 @@ int64_t apgp_trtri_work_len(int64_t n);
  * Replaces george ``kernel.get_value(X)`` + the diagonal update inside
  * ``GP.compute`` (called from gpUtils.py:178,244,254; approx.py:717 and every
  * _nll evaluation, gpUtils.py:74-78).  Writes the LOWER triangle of the symmetric
- * N x N matrix K (leading dimension ldk >= N) -- whole 64 x 64 tiles on and below the
- * diagonal; tiles strictly above it are left untouched: apgp_potrf, the only consumer,
- * reads the lower triangle only, and half the HBM writes is half the kernel's time.   */
+ * N x N matrix K (leading dimension ldk >= N), diagonal included; nothing above the
+ * diagonal is touched (allocate K zeroed if a dense lower-triangular array is wanted):
+ * apgp_potrf, the only consumer, reads the lower triangle only, and half the HBM writes
+ * is half the kernel's time.                                                          */
 int apgp_gram(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
               double* K, int64_t ldk, void* stream);
 

@@ -14,6 +14,11 @@ shapes = [(1024, 2, 100000, "bape"), (512, 8, 1000000, "agp"), (1152, 8, 1000000
           (2048, 8, 1000000, "agp"), (4096, 8, 1000000, "agp")]
 if "--quick" in sys.argv:
     shapes = [(1024, 2, 100000, "bape"), (1152, 8, 1000000, "agp"), (4096, 8, 1000000, "agp")]
+if "--extra" in sys.argv:
+    shapes = [(1024, 2, 100000, "bape"), (1024, 8, 100000, "bape"), (1024, 2, 1000000, "bape"), (1152, 2, 1000000, "agp"),
+              (1152, 8, 1000000, "agp"), (4096, 8, 1000000, "agp")]
+if "--dsweep" in sys.argv:
+    shapes = [(n, d, 1000000, "agp") for d in (2, 4, 8, 16) for n in (1024, 1152, 2048)]
 reps = 5
 out = []
 for n, d, m, kind in shapes:
