@@ -32,6 +32,7 @@
 #include <mutex>
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 #include <string.h>
 
 #define SW_ROWS APGP_ROW_BLOCK       // 512 rows of W per tile
@@ -171,12 +172,31 @@ __global__ __launch_bounds__(1024) void argmin_final_kernel(const double* part_u
 #define S2_TILE (S2_ROWS * SW_KC)        // doubles per tile image (32 KiB)
 #define S2_CPB (S2_ROWS / SW_KC)         // chunks per row-block width (16)
 #define S2_NP (S2_ROWS / 32)             // sub-block pairs per tile (8)
+// substitution form: the statically unrolled diagonal tiles are used up to this many 256-row blocks
+// (N <= 2048), the run-time-indexed body above that (see the matrix role)
+#define S2_STATIC_DIAG_NRB 8
+
+// compile-time loop (the body sees its index as a constant expression)
+template <int... Is, class F>
+__device__ __forceinline__ void s2_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void s2_static_for(F&& f) {
+    s2_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 // which form of the feeder loop an instantiation gets (see the feeder role)
 static constexpr bool s2_structured_feeder(int dpad, bool solve) { return solve ? dpad == 2 : dpad != 8; }
 
-template <int DPAD, bool LIN, bool SOLVE>
+// MODE 0: inverse form (A = packed L^-1); 1: substitution form; 2: substitution form with the statically
+// unrolled diagonal tiles (N <= 256 S2_STATIC_DIAG_NRB) -- a separate instantiation: the 65 KiB of
+// unrolled code slowed the run-time-indexed path of the SAME kernel by 20 % at N = 4096 (333 vs 276 ms;
+// identical hot loops, only their placement differs), so large N run the kernel that does not contain it.
+template <int DPAD, bool LIN, int MODE>
 __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
+    constexpr bool SOLVE = MODE != 0;
+    constexpr bool STATIC_DIAG = MODE == 2;
     constexpr int XS = DPAD + 2;
     constexpr int NKK = SW_KC / 4;
     constexpr int NP = S2_NP;
@@ -469,6 +489,125 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                         slot = nslot;
                         bpar ^= 1;
                     };
+                    // The same tile with the chunk index C a compile-time constant, for a complete row block (its
+                    // sixteen diagonal tiles always come in order): only the sub-blocks below the diagonal block
+                    // are touched -- no predicated pairs, no A-fragment reads or joins for the inactive ones, acc[C]
+                    // indexed statically --, the first active pair's fragments land during the in-register solve.
+                    // Generic form above: ~123 k cycles per row block (the inverse form's diagonal phase: 66 k) --
+                    // the substitution form's whole deficit; static form: ~75 k at N = 512.  But the sixteen bodies
+                    // are 65 KiB of straight-line code executed once per row block: once the workgroups have
+                    // drifted apart and stop sharing instruction-cache lines the phase is fetch-bound (N = 4096:
+                    // 310 ms against 276 ms for the generic form; N = 2048: 74 vs 77 ms; N = 1152: 27 vs 31 ms;
+                    // N = 512: 5.9 vs 8.5 ms), so it is used up to S2_STATIC_DIAG_NRB row blocks.  (A version
+                    // templated on the pair index only, parity as a uniform branch -- a third of the code --
+                    // made hipcc spill the accumulators at the join: 2,900 scratch accesses.)
+                    auto diag_c = [&](auto c_) {
+                        constexpr int C = decltype(c_)::value;
+                        constexpr int PF = (C + 1) >> 1;            // first pair with a sub-block below block C
+                        const int nslot = slot == 2 ? 0 : slot + 1;
+                        load_b(bpar, 1);                            // K*_C, k-steps 2-3 (0-1: prefetched)
+                        double ta[10];
+                        {
+                            const double* Ts = Aring + slot * S2_TILE + C * 256 + (lane & 3) * 4 + (lane >> 4);
+                            int e = 0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int q2 = 0; q2 <= q; ++q2) ta[e++] = Ts[(q * 4 + q2) * 16];
+                        }
+                        if constexpr (C < 15) load_a(av[PF & 1], slot, PF);
+                        {
+                            double rot[4];
+                            rot[0] = acc[C][0];
+                            rot[1] = apgp_row_ror4<1>(acc[C][1]);
+                            rot[2] = apgp_row_ror4<2>(acc[C][2]);
+                            rot[3] = apgp_row_ror4<3>(acc[C][3]);
+                            const int bb = (lane >> 2) & 3;
+                            double R[4], V[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int rr = (bb - q) & 3;
+                                R[q] = (rr == 0 ? rot[0] : rr == 1 ? rot[1] : rr == 2 ? rot[2] : rot[3]) + brot[0][q];
+                            }
+                            V[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[0], R[0], 0.0, 0, 0, 0);
+                            R[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[1], V[0], R[1], 0, 0, 0);
+                            R[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[3], V[0], R[2], 0, 0, 0);
+                            R[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[6], V[0], R[3], 0, 0, 0);
+                            V[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[2], R[1], 0.0, 0, 0, 0);
+                            R[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[4], V[1], R[2], 0, 0, 0);
+                            R[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[7], V[1], R[3], 0, 0, 0);
+                            V[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[5], R[2], 0.0, 0, 0, 0);
+                            R[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[8], V[2], R[3], 0, 0, 0);
+                            V[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ta[9], R[3], 0.0, 0, 0, 0);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                brot[0][q] = V[q];
+                                brot[1][q] = apgp_row_ror4<3>(V[q]);
+                                brot[2][q] = apgp_row_ror4<2>(V[q]);
+                                brot[3][q] = apgp_row_ror4<1>(V[q]);
+                                qmic = fma(V[q], V[q], qmic);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[C][r] = 0.0;
+                            if (jb + 1 < nrb2) {
+                                const unsigned soff = (unsigned)kc * (unsigned)(SW_BCH * 8);
+                                const unsigned voff = (unsigned)(w * 64 + lane) * 16u;
+                                f64x2 q0, q1;
+                                q0.x = V[0]; q0.y = V[1]; q1.x = V[2]; q1.y = V[3];
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs_kv, voff, soff, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs_kv, voff, soff + 4096u, 0);
+                            }
+                        }
+                        auto half = [&](int pr, int h, int kk) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc[2 * pr + h][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                                    av[pr & 1][h][kk >> 1][kk & 1], brot[r][kk], acc[2 * pr + h][r], 0, 0, 0);
+                        };
+                        // (the two park stores of THIS tile may stay in flight at its barrier -- VMEM completes in
+                        // issue order, "at most two outstanding" = the previous tile's are acknowledged; their
+                        // readers request them >= 14 barriers later)
+                        constexpr int PBAR = PF > 4 ? PF : 4;       // pair after whose first k-step the tile's barrier stands
+                        if constexpr (C == 15) {
+                            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                            __syncthreads();                        // barrier i: tile i+1 is complete
+                            load_a(av[0], nslot, 0);
+                            load_b(bpar ^ 1, 0);
+                        }
+                        s2_static_for<NP>([&](auto pr_) {
+                            constexpr int pr = decltype(pr_)::value;
+                            if constexpr (pr >= PF && C < 15) {
+                                constexpr bool a0 = 2 * pr > C;
+                                if constexpr (a0) half(pr, 0, 0);
+                                half(pr, 1, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if constexpr (pr == PBAR) {
+                                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                                    __syncthreads();                // barrier i: tile i+1 is complete
+                                }
+                                if constexpr (pr + 1 < NP) {
+                                    load_a(av[(pr + 1) & 1], slot, pr + 1);
+                                    if constexpr (a0) { half(pr, 0, 1); half(pr, 0, 2); half(pr, 0, 3); }
+                                    half(pr, 1, 1); half(pr, 1, 2); half(pr, 1, 3);
+                                } else {
+                                    load_a(av[0], nslot, 0);
+                                    if constexpr (a0) half(pr, 0, 1);
+                                    half(pr, 1, 1);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    load_b(bpar ^ 1, 0);
+                                    if constexpr (a0) { half(pr, 0, 2); half(pr, 0, 3); }
+                                    half(pr, 1, 2); half(pr, 1, 3);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
+                        slot = nslot;
+                        bpar ^= 1;
+                        ++kc;
+                    };
+                    if constexpr (STATIC_DIAG) {
+                        if (a.n - S2_ROWS * jb >= S2_ROWS) s2_static_for<S2_CPB>(diag_c);
+                    }
                     for (; kc < nkc; ++kc) do_diag();
                 }
                 // this row block's share of sum V^2: rotation r's accumulators belong to the
@@ -920,17 +1059,12 @@ static int s2_prepare_device() {
     std::lock_guard<std::mutex> lock(mu);
     if (done[dev]) return 0;
     const int lds = (int)s2_lds_bytes<DPAD>();
-    hipError_t e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false, false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true, false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, false, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)sweep2_kernel<DPAD, true, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipSuccess;
+    const void* kernels[6] = {(const void*)sweep2_kernel<DPAD, false, 0>, (const void*)sweep2_kernel<DPAD, true, 0>,
+                              (const void*)sweep2_kernel<DPAD, false, 1>, (const void*)sweep2_kernel<DPAD, true, 1>,
+                              (const void*)sweep2_kernel<DPAD, false, 2>, (const void*)sweep2_kernel<DPAD, true, 2>};
+    for (int i = 0; i < 6 && e == hipSuccess; ++i)
+        e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
         apgp_set_error("apgp_acquire: hipFuncSetAttribute(%d B of LDS) failed on device %d: %s", lds, dev,
                        hipGetErrorString(e));
@@ -950,15 +1084,20 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s, bool solve) {
     const int nrb2 = s2_nrb(a.n);
     a.nrb = nrb2;
     auto launch = [&](unsigned grid) {
-        if (solve) {
+        if (solve && nrb2 <= S2_STATIC_DIAG_NRB) {
             if (a.lin_coef != 0.0)
-                hipLaunchKernelGGL((sweep2_kernel<DPAD, true, true>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, true, 2>), dim3(grid), dim3(S2_THREADS), lds, s, a);
             else
-                hipLaunchKernelGGL((sweep2_kernel<DPAD, false, true>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, false, 2>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+        } else if (solve) {
+            if (a.lin_coef != 0.0)
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, true, 1>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+            else
+                hipLaunchKernelGGL((sweep2_kernel<DPAD, false, 1>), dim3(grid), dim3(S2_THREADS), lds, s, a);
         } else if (a.lin_coef != 0.0)
-            hipLaunchKernelGGL((sweep2_kernel<DPAD, true, false>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+            hipLaunchKernelGGL((sweep2_kernel<DPAD, true, 0>), dim3(grid), dim3(S2_THREADS), lds, s, a);
         else
-            hipLaunchKernelGGL((sweep2_kernel<DPAD, false, false>), dim3(grid), dim3(S2_THREADS), lds, s, a);
+            hipLaunchKernelGGL((sweep2_kernel<DPAD, false, 0>), dim3(grid), dim3(S2_THREADS), lds, s, a);
     };
     // full rounds on the persistent grid, then the remainder split by row block (the substitution
     // form cannot split: its row blocks depend on each other -- the last round just runs short)
