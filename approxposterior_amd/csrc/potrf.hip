@@ -18,6 +18,7 @@
 #include "apgp_common.h"
 #include "mma16.h"
 #include "scratch.h"
+#include <chrono>
 #include <type_traits>
 #include <utility>
 
@@ -47,6 +48,8 @@ struct PotrfArgs {
     // sibling workgroups are not guaranteed to start together, so the factor goes here and is copied
     // into A by potrf_finish_kernel.
     double* out5;            // optional (apgp_nll_eval): potrf_finish_kernel also writes the 5-value fit summary
+    double* mail;            // optional: ... and (matrix 0) into the stream's pinned mailbox, sequence word last
+    long long seq;
     double* dscr;
     long long batch_dscr;    // per matrix: nb * 64 * 64 factor blocks, then nb * 64 entries of the forward solve (same hazard)
     long long zoff;          // offset of the latter
@@ -448,6 +451,8 @@ struct NllSmallArgs {
     long long n;
     double shift;
     KernConst kc;
+    double* mail;        // optional: pinned, device-mapped host record (5 doubles + sequence word)
+    long long seq;
 };
 
 template <int DPAD>
@@ -492,6 +497,7 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
     }
     PotrfArgs a;
     a.A = q.K; a.rhs = q.z; a.n = q.n; a.lda = q.n; a.j0 = 0; a.shift = 0.0; a.info = q.info; a.out5 = nullptr;
+    a.mail = nullptr; a.seq = 0;
     a.dscr = nullptr; a.batch_dscr = 0; a.zoff = 0; a.batch_A = 0; a.batch_rhs = 0;
     double ar[PB];
     const double ri = lane < bs ? q.y[lane] - q.shift : 0.0;
@@ -527,12 +533,24 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
         q.out5[2] = mx;
         q.out5[3] = zz;
         q.out5[4] = (double)inf;
+        if (q.mail) {
+            // the record straight into host memory, then the sequence word with system-scope release: the
+            // host polls it instead of a D2H copy + stream synchronisation (~10 us of a 40 us evaluation)
+            q.mail[0] = 2.0 * sl;
+            q.mail[1] = mn;
+            q.mail[2] = mx;
+            q.mail[3] = zz;
+            q.mail[4] = (double)inf;
+            __hip_atomic_store((long long*)(q.mail + 5), q.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
 static int nll_small_launch(const double* X, int64_t n, const apgp_kernel_t* kern, const double* y, double mean,
-                            double* K, double* z, int32_t* info_dev, double* out5_dev, hipStream_t s) {
+                            double* K, double* z, int32_t* info_dev, double* out5_dev, hipStream_t s,
+                            double* mail = nullptr, long long seq = 0) {
     NllSmallArgs q;
+    q.mail = mail; q.seq = seq;
     if (apgp_make_kernconst(kern, &q.kc) != 0) {
         apgp_set_error("apgp_nll_eval: bad argument: kernel parameters");
         return -1;
@@ -763,6 +781,14 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
             a.out5[2] = mx;
             a.out5[3] = zz;
             a.out5[4] = (double)sinfo;
+            if (a.mail && blockIdx.y == 0) {
+                a.mail[0] = 2.0 * sl;
+                a.mail[1] = mn;
+                a.mail[2] = mx;
+                a.mail[3] = zz;
+                a.mail[4] = (double)sinfo;
+                __hip_atomic_store((long long*)(a.mail + 5), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     if (!a.dscr) return;
@@ -781,13 +807,10 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
 // latency-bound steps that leaves most of the chip idle, so a batch costs little more than one.
 // pre_init: info and z = y - shift were initialised by the caller's Gram launch (apgp_gram_with_rhs);
 // out5 != NULL: the finish kernel also writes the fit summary (5 doubles per matrix)
-static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t batch_A, const double* y,
-                     const double* shifts, double* z, int32_t* info_dev, hipStream_t s, bool pre_init = false,
-                     double* out5 = nullptr) {
-    // One factorisation's launches are enqueued as a unit: two host threads on the same stream (ctypes
-    // releases the GIL) must not interleave theirs -- they share the stream's scratch (scratch.h).
-    // (one lock per (device, stream): other streams and devices enqueue concurrently)
-    std::lock_guard<std::mutex> enqueue_lock(apgp_stream_lock(s));
+// (caller holds apgp_stream_lock(s))
+static int potrf_run_locked(double* A, int64_t n, int64_t lda, int64_t batch, int64_t batch_A, const double* y,
+                            const double* shifts, double* z, int32_t* info_dev, hipStream_t s, bool pre_init = false,
+                            double* out5 = nullptr, double* mail = nullptr, long long seq = 0) {
     // info = UINT_MAX means "no failure yet"; normalised to 0 by the caller-visible finish kernel
     if (!pre_init && hipMemsetAsync(info_dev, 0xff, sizeof(int32_t) * batch, s) != hipSuccess) {
         apgp_set_error("apgp_potrf: memset failed");
@@ -795,6 +818,7 @@ static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t b
     }
     PotrfArgs a;
     a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
+    a.mail = mail; a.seq = seq;
     a.batch_A = batch_A; a.batch_rhs = n;
     if (z && !pre_init)
         for (int64_t b = 0; b < batch; ++b)
@@ -827,6 +851,39 @@ static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t b
     return 0;
 }
 
+// One factorisation's launches are enqueued as a unit: two host threads on the same stream (ctypes
+// releases the GIL) must not interleave theirs -- they share the stream's scratch (scratch.h).
+// (one lock per (device, stream): other streams and devices enqueue concurrently)
+static int potrf_run(double* A, int64_t n, int64_t lda, int64_t batch, int64_t batch_A, const double* y,
+                     const double* shifts, double* z, int32_t* info_dev, hipStream_t s, bool pre_init = false,
+                     double* out5 = nullptr) {
+    std::lock_guard<std::mutex> enqueue_lock(apgp_stream_lock(s));
+    return potrf_run_locked(A, n, lda, batch, batch_A, y, shifts, z, info_dev, s, pre_init, out5);
+}
+
+// the host side of the mailbox: polls the sequence word (bounded spin, then the ordinary stream
+// synchronisation) and copies the record out.  Caller holds apgp_stream_lock(s).
+static int mailbox_wait(ApgpMailbox* mb, long long seq, hipStream_t s, double* out5_host) {
+    volatile long long* flag = (volatile long long*)(mb->host + 5);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) {
+            if (hipStreamSynchronize(s) != hipSuccess) {
+                apgp_set_error("apgp_nll_eval: stream synchronisation failed");
+                return -2;
+            }
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                apgp_set_error("apgp_nll_eval: result record not written");
+                return -2;
+            }
+            break;
+        }
+    }
+    for (int i = 0; i < 5; ++i) out5_host[i] = mb->host[i];
+    return 0;
+}
+
 extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, double shift, double* z,
                           int32_t* info_dev, void* stream) {
     APGP_CHECK_ARG(A && info_dev, "null pointer");
@@ -849,18 +906,26 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
     APGP_CHECK_ARG(n >= 1, "n >= 1 required");
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    // The record comes back through the stream's pinned mailbox: the last kernel's last lane writes it straight
+    // into host memory and the host polls the sequence word -- no D2H copy, no stream synchronisation while
+    // the evaluation is short (bounded spin, then the ordinary synchronisation): 42.6 -> 26.9 us at N = 50.
+    ApgpMailbox* mb = apgp_stream_mailbox(s);
+    const bool mail = mb && mb->host;
+    std::lock_guard<std::mutex> lock(apgp_stream_lock(s));             // (one mailbox, one scratch per stream)
+    const long long seq = mail ? ++mb->seq : 0;
     if (n <= PB) {
         // one single-workgroup launch (nll_small_kernel): same values, two launch boundaries fewer
-        rc = nll_small_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s);
+        rc = nll_small_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s, mail ? mb->dev : nullptr, seq);
         if (rc != 0) return rc;
     } else {
         // three launches fewer than the separate calls: the Gram launch initialises the right-hand side
         // and the info word, the Cholesky's last launch writes the summary
         rc = apgp_gram_with_rhs(X, n, kern, K, n, y, mean, z, info_dev, stream);
         if (rc != 0) return rc;
-        rc = potrf_run(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, out5_dev);
+        rc = potrf_run_locked(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, out5_dev, mail ? mb->dev : nullptr, seq);
         if (rc != 0) return rc;
     }
+    if (mail) return mailbox_wait(mb, seq, s, out5_host);
     if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         apgp_set_error("apgp_nll_eval: D2H copy failed");

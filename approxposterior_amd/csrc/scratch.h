@@ -17,10 +17,16 @@
 #include <mutex>
 #include <tuple>
 
+// 64 bytes of pinned, device-mapped host memory per (device, stream): a kernel's last lane writes a small
+// result record and a sequence word straight into it (apgp_nll_eval at n <= 64: no D2H copy, no stream
+// synchronisation -- the host polls the word)
+struct ApgpMailbox { volatile double* host = nullptr; double* dev = nullptr; long long seq = 0; };
+
 struct ApgpScratchTable {
     struct Scr { double* p = nullptr; size_t doubles = 0; };
     std::mutex mu;
     std::map<std::tuple<int, hipStream_t, int>, Scr> tab;
+    std::map<std::pair<int, hipStream_t>, ApgpMailbox> mail;
     std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::mutex>> locks;
 };
 inline ApgpScratchTable& apgp_scratch_table() {
@@ -60,12 +66,38 @@ inline std::mutex& apgp_stream_lock(hipStream_t s) {
     return *m;             // (entries are never erased: the reference stays valid)
 }
 
+// the stream's mailbox (allocated on first use; NULL host pointer if pinned memory is unavailable)
+inline ApgpMailbox* apgp_stream_mailbox(hipStream_t s) {
+    ApgpScratchTable& t = apgp_scratch_table();
+    const int dev = apgp_stream_device(s);
+    std::lock_guard<std::mutex> lock(t.mu);
+    ApgpMailbox& m = t.mail[std::make_pair(dev, s)];
+    if (!m.host) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return &m;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return &m; }
+        for (int i = 0; i < 8; ++i) ((volatile double*)h)[i] = 0.0;
+        m.host = (volatile double*)h;
+        m.dev = (double*)d;
+        m.seq = 0;
+    }
+    return &m;             // (std::map nodes are stable: the pointer stays valid)
+}
+
 // frees (stream-ordered) every scratch buffer of `s`; returns the number of buffers released
 inline int apgp_stream_scratch_release(hipStream_t s) {
     ApgpScratchTable& t = apgp_scratch_table();
     const int dev = apgp_stream_device(s);
     std::lock_guard<std::mutex> lock(t.mu);
     int n = 0;
+    {
+        auto mit = t.mail.find(std::make_pair(dev, s));
+        if (mit != t.mail.end()) {
+            if (mit->second.host) { (void)hipHostFree((void*)mit->second.host); ++n; }
+            t.mail.erase(mit);
+        }
+    }
     for (auto it = t.tab.begin(); it != t.tab.end();) {
         if (std::get<0>(it->first) == dev && std::get<1>(it->first) == s) {
             if (it->second.p) { (void)hipFreeAsync(it->second.p, s); ++n; }

@@ -41,6 +41,17 @@ __all__ = ["GP", "ExpSquaredKernel", "ConstantKernel", "Product", "ConstantModel
 
 UTILITY_KINDS = {"agp": _lib.UTIL_AGP, "bape": _lib.UTIL_BAPE, "jones": _lib.UTIL_JONES}
 
+
+class _NullContext(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CONTEXT = _NullContext()
+
 # Above this condition estimate ((max L_ii / min L_ii)^2) the explicit L^-1
 # contraction is no longer trusted for the predictive variance (SURVEY.md
 # section 7, "Conditioning vs. formulation") and the solve-based sweep
@@ -308,6 +319,7 @@ class GP(object):
         self._L = None            # (N,N) lower Cholesky factor (device); a view of _L_store["buf"] after appends
         self._L_store = None      # growable store shared along a chain of appended GPs (compute(previous=))
         self._ld = None           # leading dimension of _L in memory
+        self._nll_owned = False   # _L / _z are private buffers of an _nll evaluation (reusable by the next)
         self._alpha_y = None      # host copy of the y alpha/z were computed for
         self._alpha_mean = None
         self._y_d = None
@@ -342,6 +354,14 @@ class GP(object):
         return self._rt_cache
 
     @staticmethod
+    def _on(torch, dev):
+        """Context that makes ``dev`` current -- a no-op object when it already is (the context manager of
+        torch.cuda.device costs ~4 us, on the per-evaluation path of gpUtils._nll)."""
+        if torch.cuda.current_device() == dev.index:
+            return _NULL_CONTEXT
+        return torch.cuda.device(dev)
+
+    @staticmethod
     def _stream(torch):
         # the raw-handle query is ~30x cheaper than torch.cuda.current_stream() and this
         # sits on the per-call path of the sampler's log-probability
@@ -358,8 +378,7 @@ class GP(object):
         ks.lin_coef = lin_coef
         ks.lin_order = lin_order
         ks.diag_add = float(self._yerr2) + float(np.exp(self.white_noise.value))
-        for d in range(_lib.MAX_DIM):
-            ks.inv_metric[d] = float(np.exp(-log_M[d])) if d < len(log_M) else 0.0
+        ks.inv_metric[:len(log_M)] = np.exp(-np.asarray(log_M, dtype=np.float64)).tolist()   # (the rest stays 0)
         return ks
 
     # -- parameter-vector protocol (george) -------------
@@ -540,21 +559,33 @@ class GP(object):
         keep_x = None if upload_x else getattr(self, "_x_d", None)
         keep_y = self._y_d if (yv is not None and self._alpha_y is not None
                                and np.array_equal(self._alpha_y, yv)) else None
+        keep_nll = (self._L, self._z) if (self._L is not None and self._z is not None and self._L_store is None
+                                          and self._nll_owned) else None
         self._reset_device_state()
         self._computed = False
         ks = self._kernel_struct()
-        with torch.cuda.device(dev):
+        with self._on(torch, dev):
             st = self._stream(torch)
             self._x_d = keep_x if keep_x is not None else torch.from_numpy(x).to(dev)
             # zeroed: the library reads and writes the lower triangle only (Gram, factor in place -- LAPACK's
             # dpotrf contract), so what is kept as the factor is a clean lower-triangular L.
             # (n <= 64 with y: the fused kernel writes the whole n x n itself.)
-            K = (torch.empty if (yv is not None and n <= 64) else torch.zeros)((n, n), dtype=torch.float64, device=dev)
-            z = None
+            # An optimiser's evaluations (set_parameter_vector + log_likelihood, over and over) refactorise in
+            # the SAME buffers: the previous factor is dead once its hyper-parameters are, and nothing else
+            # references an exactly-sized private factor (appended chains share a store: never reused here).
+            reuse = keep_nll if (keep_nll is not None and yv is not None and keep_nll[0].shape[0] == n) else None
+            if reuse is not None:
+                K, z = reuse
+                if n > 64:
+                    K.zero_()
+            else:
+                K = (torch.empty if (yv is not None and n <= 64) else torch.zeros)((n, n), dtype=torch.float64, device=dev)
+                z = None
             if yv is not None:
                 # the whole _nll evaluation as one library call and one synchronisation
                 y_d = keep_y if keep_y is not None else torch.from_numpy(yv).to(dev)
-                z = torch.empty(n, dtype=torch.float64, device=dev)
+                if z is None:
+                    z = torch.empty(n, dtype=torch.float64, device=dev)
                 scr = self._nll_scratch
                 if scr is None:
                     scr = self._nll_scratch = (torch.empty(1, dtype=torch.int32, device=dev),
@@ -596,6 +627,7 @@ class GP(object):
             self._y_d = y_d
             self._alpha_y = np.array(yv, copy=True)
             self._alpha_mean = self.mean.value
+            self._nll_owned = True    # (K, z) came from an _nll evaluation: the next one may refactorise in place
 
     def recompute(self, quiet=False, **kwargs):
         if self.kernel.dirty or not self._computed:
@@ -672,7 +704,9 @@ class GP(object):
                 if self._x is None:
                     raise RuntimeError("You need to compute the model first")
                 self._factor(y)
-            ztz = self._solve(y, need_alpha=False)
+                ztz = self._ztz_host          # (z = L^-1 (y - mean) rode along with the factorisation)
+            else:
+                ztz = self._solve(y, need_alpha=False)
             ll = self._const - 0.5 * ztz
         except (ValueError, LinAlgError):
             if quiet:
