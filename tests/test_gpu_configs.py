@@ -4,8 +4,8 @@ known-answer constants reproduced ON THE HIP PATH (VERDICT round 1, items 1 and 
   C2  Rosenbrock 2-D, N_train = 1024, 1e5 candidates, BAPE           (configs[1])
   C4  D = 8, N = 4096, 1e7 candidates in 8 shards with idx_offset     (configs[3], emulated
       on one GPU: shard r = rows [r M/8, (r+1) M/8) of the one NumPy seed-1 draw)
-  C5  ApproxPosterior.run, D = 8, m0 = 512, m = 64, nmax = 10, 64 walkers x 2e4 (configs[4];
-      optGPEveryN = m here -- see the test -- and the device sampler separately at N = 1152)
+  C5  ApproxPosterior.run, D = 8, m0 = 512, m = 64, nmax = 10, default optGPEveryN = 1,
+      64 walkers x 2e4 (configs[4] as written), and the device sampler separately at N = 1152
   a6  gpUtils.optimizeGP        vs test_OptimizeGP.py:91   (reference constant) + pins.json
   a12 ApproxPosterior.findNextPoint vs test_findNewPoint.py:107 (reference constant)
   f2  the 2-D Bayesian-optimisation test of the reference (test_2DBayesOpt.py:55-73)
@@ -159,19 +159,18 @@ def _oracle_twin(gp, theta):
     return o
 
 
-def test_c5_run_loop_d8_nmax10_optgp_every_m(tmp_path, monkeypatch):
-    """BASELINE.json configs[4]: ApproxPosterior.run at D = 8, m0 = 512, m = 64, **nmax = 10**
-    (N grows 512 -> 1152), 64 walkers x 2e4 iterations on the on-device sampler,
-    nCandidates = 1e6 (the fused sweep is the point search), untruncated Powell re-optimisation
-    of the hyper-parameters (approx.py:229-524).  ONE deviation from the reference's defaults,
-    stated in the name: ``optGPEveryN = m`` (one ``optGP`` per outer iteration, 10 in all)
-    instead of the default 1 (640 optimisations of 1-2 s each = ~17 min, beyond the suite's time
-    limit; ``tools/run_configs.py --c5-as-written`` runs exactly that once per round and logs it
-    under gpurun_out/ / profiles/).  Checked against the oracle:
-      * appended design points: (mu, sigma^2, u) of the sweep winner at the GP state that
-        selected it (hyper-parameters + training set at that moment) -- approx.py:648-691;
-      * the factor after the incremental appends of the last iteration == a full oracle refit
-        (log-likelihood and predictions) -- approx.py:693-717;
+def test_c5_run_loop_d8_as_written(tmp_path, monkeypatch):
+    """BASELINE.json configs[4] AS WRITTEN, with the reference's defaults (approx.py:229-235,397-424):
+    ApproxPosterior.run at D = 8, m0 = 512, m = 64, **nmax = 10** (N grows 512 -> 1152),
+    **optGPEveryN = 1** (an untruncated Powell re-optimisation of the hyper-parameters after every
+    appended point: 640 of them), 64 walkers x 2e4 iterations on the on-device sampler,
+    nCandidates = 1e6 (the fused sweep is the point search).  About 5 minutes on one MI355X
+    (profiles/r03n_c5_as_written.txt: 283 s, 21-34 s of training and 1.1-1.5 s of MCMC per outer
+    iteration).  Checked against the oracle:
+      * appended design points (every 16th and the last three of the 640): (mu, sigma^2, u) of the
+        sweep winner at the GP state that selected it (hyper-parameters + training set at that
+        moment) -- approx.py:648-691;
+      * the final factor == a full oracle refit (log-likelihood and predictions) -- approx.py:693-723;
       * the device sampler's log-probabilities == oracle GP mean at the sampled coordinates;
       * the host (batched) sampler on the same surrogate: same check on its chain."""
     monkeypatch.chdir(tmp_path)
@@ -197,7 +196,7 @@ def test_c5_run_loop_d8_nmax10_optgp_every_m(tmp_path, monkeypatch):
         return best, u
     monkeypatch.setattr(ut, "sweepObjective", spy)
     with np.errstate(all="ignore"):
-        ap.run(m=m, nmax=nmax, nCandidates=1_000_000, optGPEveryN=m, nGPRestarts=1, cache=False,
+        ap.run(m=m, nmax=nmax, nCandidates=1_000_000, nGPRestarts=1, cache=False,
                verbose=False, onDevice=True, estBurnin=True, thinChains=True,
                mcmcKwargs={"iterations": 20000}, samplerKwargs={"nwalkers": 64})
     assert len(picks) == nmax * m and len(ap.y) == m0 + nmax * m == 1152 and ap.gp._x.shape == (1152, D)
