@@ -58,8 +58,10 @@ _NULL_CONTEXT = _NullContext()
 # (apgp_acquire_solve) is used instead.  ``GP.variance_mode`` = "solve" | "inverse"
 # overrides the choice for one object (tests); no environment variable is read.
 COND_SOLVE = 1.0e10
-# from this size on a missing L^-1 is formed before the first solve (gp._solve): apgp_trtri_pack is
-# 0.11 ms at N = 512 against 0.08 + 0.09 ms for the two triangular solves it replaces, 0.8 vs 1.4 ms at 4096
+# from this size on a missing L^-1 is formed before the solves WHEN ALPHA IS WANTED (a sweep, a gradient or the
+# sampler follows -- they need W anyway): apgp_trtri_pack + two matrix-vector products, 0.11 + 0.02 ms at N = 512
+# against 0.08 + 0.09 ms for the two triangular solves, 0.82 + 0.05 ms against 2 x 0.72 ms at N = 4096
+# (profiles/r03n_fit_timing.txt).  A bare log_likelihood on a new y keeps the single forward solve.
 W_FIRST_MIN_N = 512
 
 
