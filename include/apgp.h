@@ -138,10 +138,17 @@ int apgp_fit_summary(const double* L, int64_t n, int64_t ldl, const double* z,
 int apgp_release_scratch(void* stream);
 
 /* ---- one gpUtils._nll evaluation (gpUtils.py:46-80) in one call ---------------
- * apgp_gram -> apgp_potrf (z = L^-1 (y - mean) riding along) -> apgp_fit_summary ->
- * 40-byte D2H into out5_host -> one stream synchronisation.  K: n x n work (holds
- * the factor on return), z: n, info_dev / out5_dev: device scratch.  Status as the
- * parts'; a non-PD matrix is reported in out5_host[4] (> 0), not in the status.  */
+ * apgp_gram -> apgp_potrf (z = L^-1 (y - mean) riding along) -> apgp_fit_summary, and the
+ * 5-value record of apgp_fit_summary in out5_host when the call returns (the call
+ * synchronises with its own work only).  n <= 64: ONE single-workgroup launch (Gram block
+ * in LDS, register-resident factorisation, summary; same bits as the separate calls).
+ * The record travels through 64 bytes of pinned, device-mapped host memory kept per
+ * (device, stream): the last kernel's last lane writes it and a sequence word, the host
+ * polls the word (400 us, then an ordinary stream synchronisation) -- no D2H copy; if
+ * pinned memory is unavailable the call falls back to copy + synchronisation.
+ * K: n x n work (holds the factor on return), z: n, info_dev / out5_dev: device scratch
+ * (both written as before).  Status as the parts'; a non-PD matrix is reported in
+ * out5_host[4] (> 0), not in the status.                                              */
 int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
                   const double* y, double mean, double* K, double* z,
                   int32_t* info_dev, double* out5_dev, double* out5_host /*host*/,

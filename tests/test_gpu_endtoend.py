@@ -191,11 +191,14 @@ def test_default_gp_with_linear_order_end_to_end():
     assert np.isfinite(ap.gp.log_likelihood(ap.y))
 
 
-@pytest.mark.parametrize("n,d", [(50, 2), (700, 5)])
+@pytest.mark.parametrize("n,d", [(50, 2), (64, 3), (65, 2), (90, 2), (128, 8), (129, 4), (700, 5)])
 def test_nll_batch_is_bit_identical_to_single_evaluations(n, d):
     """apgp_nll_eval_batch: several hyper-vectors through ONE batched
     Gram + Cholesky + solve.  Every entry equals gpUtils._nll of that vector exactly --
-    including +inf for a non-positive-definite matrix -- and the GP's own state survives."""
+    including +inf for a non-positive-definite matrix -- and the GP's own state survives.
+    The single evaluation is ONE fused launch for n <= 64 (nll_small_kernel), the batch always the
+    separate Gram / panel / step / finish launches: same code and operation order, so the same
+    bits, at the block boundaries +- 1."""
     import time
     from approxposterior_amd import gpUtils
     rs = np.random.RandomState(5)

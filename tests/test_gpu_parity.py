@@ -316,7 +316,8 @@ def _synthetic(n, d, seed=0):
 
 
 @pytest.mark.parametrize("n,d,m,metric", [(1024, 2, 3000, 2.0), (700, 8, 1500, 8.0), (513, 3, 777, 1.0),
-                                           (64, 16, 200, 30.0), (1, 1, 5, 1.0), (17, 4, 1, 4.0)])
+                                           (64, 16, 200, 30.0), (1, 1, 5, 1.0), (17, 4, 1, 4.0),
+                                           (90, 2, 300, 2.0), (128, 16, 100, 30.0), (65, 5, 64, 6.0)])
 def test_oracle_parity_seeded(n, d, m, metric, lib_loaded):
     """HIP vs oracle on seeded synthetic sets: ragged sizes (N, M not multiples
     of any tile), D from 1 to the 16-dim maximum, single candidate / single point."""
