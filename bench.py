@@ -379,7 +379,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "sweep2_kernel<%d, false>" % (2 if D <= 2 else 4 if D <= 4 else 8 if D <= 8 else 16),
+                         "kernel": "sweep2_kernel<%d, false, 0>" % (2 if D <= 2 else 4 if D <= 4 else 8 if D <= 8 else 16),
                          "kernel_ms": k_avg_ms,
                          "algorithmic_flops_per_candidate": f_var(N, D)},
             "best": {"index": int(best[0]), "u": float(best[1])},
@@ -387,8 +387,10 @@ def main():
             "variance": "solve" if not gp._trust_inverse() else "inverse",
         }
         if out["variance"] == "solve":
-            out["roofline"]["kernel"] = out["roofline"]["kernel"].replace("false>", "false, solve>")
+            # substitution form: MODE 2 (statically unrolled diagonal tiles) up to N = 2048, MODE 1 above
+            out["roofline"]["kernel"] = out["roofline"]["kernel"].replace(", 0>", ", 2>" if N <= 2048 else ", 1>")
             out["roofline"]["traffic"] = None
+            out["roofline"]["traffic_source"] = None
         need_oracle = (not args.no_check) or (world == 1 and not args.no_cpu_baseline)
         if need_oracle:
             gpo, fit_s = oracle_gp(X, y, args.metric, D)
