@@ -69,6 +69,8 @@ SIGNATURES = {
     "apgp_acquire_solve": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _I64, _KP, _F64, _I32,
                                           ctypes.POINTER(_F64), ctypes.POINTER(_F64), _P,
                                           _F64, _F64, _P, _P, _P, _P, _P, _P]),
+    "apgp_predict1_work_len": (_I64, [_I64]),
+    "apgp_predict1_host": (ctypes.c_int, [_P, _P, _I64, _KP, _F64, _P, _I64, _P, _I64, _P, _P, _P]),
     "apgp_predict_mean": (ctypes.c_int, [_P, _I64, _P, _I64, _KP, _F64, _P, _P]),
     "apgp_predict_mean_host": (ctypes.c_int, [_P, _I64, _P, _I64, _KP, _F64, _P, _P, _P]),
     "apgp_ensemble_sample": (ctypes.c_int, [_P, _I64, _KP, _F64, ctypes.POINTER(_F64), ctypes.POINTER(_F64),

@@ -334,6 +334,7 @@ class GP(object):
         self._xs = None           # packed training stream (depends on alpha)
         self._xs_key = None
         self._mean_work = getattr(self, "_mean_work", None)   # scratch survives refits
+        self._p1_work = getattr(self, "_p1_work", None)
         self._nll_scratch = getattr(self, "_nll_scratch", None)
         self.cond_estimate = None
         self.log_determinant = None
@@ -865,12 +866,13 @@ class GP(object):
         need_var = kind is not None or "var" in want
         ks = self._kernel_struct()
         use_solve = need_var and not self._trust_inverse()
-        with torch.cuda.device(dev):
+        with self._on(torch, dev):
             st = self._stream(torch)
+            one = need_var and kind is None and cand_device is None and cand is not None and len(cand) == 1
             if need_var and not use_solve:
                 self._ensure_linv()     # first: with W resident alpha is two matrix-vector products
-            elif need_var:
-                self._ensure_lsolve()
+            elif need_var and not one:
+                self._ensure_lsolve()   # (a single candidate solves against L itself)
             self._ensure_xs(y)
             if not need_var and cand_device is None and 0 < len(cand) <= 4096:
                 # latency-bound mean-only call (the sampler's _gpll batches): host buffers
@@ -885,6 +887,23 @@ class GP(object):
                                                       mu_h.ctypes.data, self._mean_work.data_ptr(), st),
                            "apgp_predict_mean_host")
                 return (mu_h,)
+            if need_var and kind is None and cand_device is None and len(cand) == 1:
+                # ONE candidate with variance: the reference's scalar utilities (utility.py:131,178,224), once per
+                # Nelder-Mead step of minimizeObjective -- three small launches, the result through the mailbox
+                if self._p1_work is None or self._p1_work.numel() < int(lib.apgp_predict1_work_len(n)):
+                    self._p1_work = torch.empty(int(lib.apgp_predict1_work_len(n)), dtype=torch.float64, device=dev)
+                o2 = np.empty(2, dtype=np.float64)
+                if use_solve:
+                    _lib.check(lib.apgp_predict1_host(cand.ctypes.data, self._xs.data_ptr(), n, ctypes.byref(ks),
+                                                      float(self.mean.value), None, 0, self._L.data_ptr(), self._ld,
+                                                      self._p1_work.data_ptr(), o2.ctypes.data, st), "apgp_predict1_host")
+                else:
+                    _lib.check(lib.apgp_predict1_host(cand.ctypes.data, self._xs.data_ptr(), n, ctypes.byref(ks),
+                                                      float(self.mean.value), self._work.data_ptr(), (n + 63) // 64 * 64,
+                                                      None, 0, self._p1_work.data_ptr(), o2.ctypes.data, st),
+                               "apgp_predict1_host")
+                res = {"mu": np.array([o2[0]]), "var": np.array([o2[1]])}
+                return tuple(res[w_] for w_ in want)
             T = cand_device if cand_device is not None else torch.from_numpy(cand).to(dev)
             m = T.shape[0]
             if m == 0:

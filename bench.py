@@ -400,6 +400,16 @@ def main():
             out["best_check"] = chk
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gpo, fit_s, y, D, args.cpu_seconds, args.cpu_scalar_calls)
+            # the same reference-faithful scalar path on the GPU (one candidate per predict call:
+            # apgp_predict1_host), beside the oracle's scalar_path_value
+            rs1 = np.random.RandomState(2)
+            t1 = rs1.uniform(-5.0, 5.0, size=(300, D))
+            for i in range(20):
+                gp.predict(y, t1[i:i + 1], return_var=True)
+            t0 = time.time()
+            for i in range(20, 300):
+                gp.predict(y, t1[i:i + 1], return_var=True)
+            out["cpu_baseline"]["scalar_path_gpu_value"] = 280.0 / (time.time() - t0)
             if not args.no_fit_leg:
                 out["fit"] = fit_leg(agp, dev)
         print(json.dumps(out))

@@ -269,6 +269,23 @@ int apgp_acquire_solve(const double* T, int64_t m, int64_t idx_offset,
                        double* mu, double* var, double* u,
                        void* part, apgp_best_t* best, void* stream);
 
+/* ---- ONE candidate: george GP.predict(y, t[1 x D], return_var=True) ----------
+ * What the reference's scalar utilities evaluate once per Nelder-Mead step
+ * (utility.py:131,178,224 <- minimizeObjective, utility.py:336-372; the default
+ * point search of ApproxPosterior.findNextPoint).  t_host: the candidate (host,
+ * ndim doubles; it travels in the kernel arguments).  xs: packed training stream
+ * (with alpha).  winv / ldw: the dense L^-1 left by apgp_trtri_pack in its work
+ * buffer -> sigma^2 by one matrix-vector product; or winv = NULL and L / ldl: the
+ * factor -> one triangular solve (use it above the conditioning gate).  work:
+ * apgp_predict1_work_len(n) doubles (device).  out2_host: mu, sigma^2 -- through the
+ * stream's pinned mailbox when the call returns (no allocation, copy or stream
+ * synchronisation; falls back to copy + synchronisation without pinned memory). */
+int64_t apgp_predict1_work_len(int64_t n);
+int apgp_predict1_host(const double* t_host /*host*/, const double* xs, int64_t n,
+                       const apgp_kernel_t* kern /*host*/, double mean,
+                       const double* winv, int64_t ldw, const double* L, int64_t ldl,
+                       double* work, double* out2_host /*host*/, void* stream);
+
 /* ---- mean-only prediction (the batched ApproxPosterior._gpll path) --------
  * mu_i = k(t_i,X).alpha + mean for m candidates (approx.py:178-180).         */
 int apgp_predict_mean(const double* T, int64_t m, const double* xs, int64_t n,

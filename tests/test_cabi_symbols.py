@@ -63,3 +63,5 @@ def test_bad_arguments_are_refused_without_a_gpu():
     assert lib.apgp_acquire_solve(None, 1, 0, None, None, 4, ctypes.byref(ks), 0.0, 0, None, None, None,
                                   0.01, 0.0, None, None, None, None, None, None) == -1
     assert lib.apgp_pack_lsolve(None, 4, 4, None, None) == -1
+    assert lib.apgp_predict1_host(None, None, 4, ctypes.byref(ks), 0.0, None, 0, None, 0, None, None, None) == -1
+    assert lib.apgp_predict1_work_len(100) == 2 * 512 + 1 + 8

@@ -428,6 +428,50 @@ def test_substitution_sweep_deterministic_and_matches_inverse(n, d, m, lib_loade
     assert ref[0] == inv[0] or abs(ref[1] - inv[1]) <= 1e-9 * abs(inv[1])
 
 
+@pytest.mark.parametrize("n,d", [(50, 2), (300, 5), (700, 16), (1300, 8)])
+@pytest.mark.parametrize("mode", ["inverse", "solve"])
+def test_single_candidate_path(n, d, mode, lib_loaded):
+    """ONE candidate per call (apgp_predict1_host: k* kernel -> one matrix-vector product with the dense
+    L^-1 or one triangular solve -> single-workgroup epilogue -> mailbox) is what the reference's scalar
+    utilities evaluate once per Nelder-Mead step (utility.py:131,178,224).  Against the oracle and against
+    the fused sweep over the same candidates (different summation order: to the conditioning bound), NaN
+    coordinates, and the three scalar utilities of utility.py on top of it."""
+    go, agp = _mods()
+    from approxposterior_amd import utility as ut
+    X, y = _synthetic(n, d)
+    gpo = go.GP(kernel=go.ExpSquaredKernel(np.full(d, 8.0), ndim=d), fit_mean=True, mean=np.median(y),
+                white_noise=-12, fit_white_noise=False)
+    gpo.compute(X)
+    gp = agp.GP(kernel=agp.ExpSquaredKernel(np.full(d, 8.0), ndim=d), fit_mean=True, mean=np.median(y),
+                white_noise=-12, fit_white_noise=False)
+    gp.variance_mode = mode
+    gp.compute(X)
+    T = np.random.RandomState(9).uniform(-5, 5, size=(40, d))
+    T[:4] = X[:4] + 1e-3                                     # near training points: tiny variance
+    mo, vo = gpo.predict(y, T, return_var=True)
+    mb, vb = gp.predict(y, T, return_var=True)               # fused sweep
+    one = np.array([gp.predict(y, T[i:i + 1], return_var=True) for i in range(len(T))]).reshape(len(T), 2)
+    K = gpo.kernel.get_value(gpo._x)
+    K[np.diag_indices_from(K)] += np.exp(-12.0)
+    tol = max(1e-13, 200 * np.linalg.cond(K) * EPS)
+    asum = np.abs(gpo._compute_alpha(y, False)).sum()
+    assert np.abs(one[:, 0] - mo).max() <= tol * asum and np.abs(one[:, 1] - vo).max() <= tol
+    assert np.abs(one[:, 0] - mb).max() <= tol * asum and np.abs(one[:, 1] - vb).max() <= tol
+    again = np.array(gp.predict(y, T[7:8], return_var=True)).ravel()
+    assert np.array_equal(again, one[7])                     # run-to-run identical
+    bad = T[5:6].copy(); bad[0, d - 1] = np.nan
+    mn, vn = gp.predict(y, bad, return_var=True)
+    assert np.isnan(mn[0]) and np.isnan(vn[0])
+    prior = lambda t: 0.0                                    # noqa: E731
+    with np.errstate(all="ignore"):
+        for i in (0, 9, 21):
+            assert np.isclose(float(np.ravel(ut.AGPUtility(T[i], y, gp, prior))[0]),
+                              -(mo[i] + 0.5 * np.log(2 * np.pi * np.e * vo[i])), rtol=1e-8, atol=1e-8) or vo[i] < 1e-5
+            if vo[i] > 1e-5:
+                assert np.isclose(float(np.ravel(ut.BAPEUtility(T[i], y, gp, prior))[0]),
+                                  -((2 * mo[i] + vo[i]) + (vo[i] + np.log(1.0 - np.exp(-vo[i])))), rtol=1e-7)
+
+
 @pytest.mark.parametrize("n,d", [(700, 8), (1100, 3), (50, 2), (129, 5)])
 def test_alpha_through_resident_inverse(n, d, lib_loaded):
     """K3 both ways: z = L^-1 r, alpha = L^-T z by the triangular solves (apgp_trsv) and, once
