@@ -20,7 +20,12 @@
 // 64 bytes of pinned, device-mapped host memory per (device, stream): a kernel's last lane writes a small
 // result record and a sequence word straight into it (apgp_nll_eval at n <= 64: no D2H copy, no stream
 // synchronisation -- the host polls the word)
-struct ApgpMailbox { volatile double* host = nullptr; double* dev = nullptr; long long seq = 0; };
+struct ApgpMailbox {
+    volatile double* host = nullptr; double* dev = nullptr; long long seq = 0;
+    // a larger pinned, device-mapped staging area (grown on demand) for calls that hand over host buffers
+    // (apgp_predict_mean_host): the kernel reads / writes it in place -- no H2D / D2H copies
+    double* io_host = nullptr; double* io_dev = nullptr; size_t io_doubles = 0;
+};
 
 struct ApgpScratchTable {
     struct Scr { double* p = nullptr; size_t doubles = 0; };
@@ -85,6 +90,25 @@ inline ApgpMailbox* apgp_stream_mailbox(hipStream_t s) {
     return &m;             // (std::map nodes are stable: the pointer stays valid)
 }
 
+// pinned staging area of at least `doubles` doubles for the stream (host pointer; *dev = device alias); NULL if
+// pinned memory is unavailable.  Caller holds apgp_stream_lock(s) and has no kernel in flight that uses it.
+inline double* apgp_stream_pinned_io(hipStream_t s, size_t doubles, double** dev) {
+    ApgpMailbox* m = apgp_stream_mailbox(s);
+    if (!m || !m->host) return nullptr;
+    if (m->io_doubles < doubles) {
+        if (m->io_host) { (void)hipStreamSynchronize(s); (void)hipHostFree(m->io_host); }
+        m->io_host = nullptr; m->io_dev = nullptr; m->io_doubles = 0;
+        const size_t want = doubles + doubles / 2 + 512;
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, want * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
+        m->io_host = (double*)h; m->io_dev = (double*)d; m->io_doubles = want;
+    }
+    *dev = m->io_dev;
+    return m->io_host;
+}
+
 // frees (stream-ordered) every scratch buffer of `s`; returns the number of buffers released
 inline int apgp_stream_scratch_release(hipStream_t s) {
     ApgpScratchTable& t = apgp_scratch_table();
@@ -95,6 +119,7 @@ inline int apgp_stream_scratch_release(hipStream_t s) {
         auto mit = t.mail.find(std::make_pair(dev, s));
         if (mit != t.mail.end()) {
             if (mit->second.host) { (void)hipHostFree((void*)mit->second.host); ++n; }
+            if (mit->second.io_host) { (void)hipHostFree(mit->second.io_host); ++n; }
             t.mail.erase(mit);
         }
     }

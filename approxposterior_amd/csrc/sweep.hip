@@ -29,6 +29,8 @@
 //   * mu is a VALU by-product of the generating tiles (every k exactly once).
 #include "apgp_common.h"
 #include "mma16.h"
+#include "scratch.h"
+#include <chrono>
 #include <mutex>
 #include <stdlib.h>
 #include <type_traits>
@@ -1353,17 +1355,53 @@ extern "C" int apgp_predict_mean(const double* T, int64_t m, const double* xs, i
 
 // Host-buffer form of apgp_predict_mean for the latency-bound caller: an ensemble
 // sampler's half-step evaluates a few dozen points per call (approx.py:178-180 through
-// emcee), 4e4 calls per chain.  One entry point = H2D of the points, the kernel, D2H of
-// the means and ONE stream synchronisation, instead of four host-side round trips.
+// emcee), 4e4 calls per chain.  One entry point; round 3: the points are staged in -- and
+// the means written to -- a pinned, device-mapped area of the stream that the kernel reads
+// and writes in place, and a one-thread kernel behind it posts the sequence word the host
+// polls: no H2D / D2H copy, no stream synchronisation (without pinned memory: the copies
+// through `work` and one synchronisation, as in round 2).
+__global__ void mailbox_post_kernel(double* mail, long long seq) {
+    __hip_atomic_store((long long*)(mail + 5), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 extern "C" int apgp_predict_mean_host(const double* T_host, int64_t m, const double* xs, int64_t n,
                                       const apgp_kernel_t* kern, double mean, double* mu_host,
                                       double* work, void* stream) {
     APGP_CHECK_ARG(T_host && mu_host && work && kern, "null pointer");
     APGP_CHECK_ARG(m >= 1, "m >= 1 required");
     hipStream_t s = (hipStream_t)stream;
-    const size_t tb = (size_t)m * (size_t)kern->ndim * sizeof(double);
+    const size_t tn = (size_t)m * (size_t)kern->ndim;
+    {
+        std::lock_guard<std::mutex> lock(apgp_stream_lock(s));
+        double* io_dev = nullptr;
+        double* io = apgp_stream_pinned_io(s, tn + (size_t)m, &io_dev);
+        ApgpMailbox* mb = io ? apgp_stream_mailbox(s) : nullptr;
+        if (io && mb && mb->host) {
+            memcpy(io, T_host, tn * sizeof(double));
+            const int rc = apgp_predict_mean(io_dev, m, xs, n, kern, mean, io_dev + tn, stream);
+            if (rc != 0) return rc;
+            const long long seq = ++mb->seq;
+            hipLaunchKernelGGL(mailbox_post_kernel, dim3(1), dim3(1), 0, s, mb->dev, seq);
+            APGP_CHECK_LAUNCH();
+            volatile long long* flag = (volatile long long*)(mb->host + 5);
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) {
+                    if (hipStreamSynchronize(s) != hipSuccess || __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                        apgp_set_error("apgp_predict_mean_host: result not posted");
+                        return -2;
+                    }
+                    break;
+                }
+            }
+            memcpy(mu_host, io + tn, (size_t)m * sizeof(double));
+            return 0;
+        }
+    }
+    const size_t tb = tn * sizeof(double);
     double* T_dev = work;
-    double* mu_dev = work + (size_t)m * (size_t)kern->ndim;
+    double* mu_dev = work + tn;
     if (hipMemcpyAsync(T_dev, T_host, tb, hipMemcpyHostToDevice, s) != hipSuccess) {
         apgp_set_error("apgp_predict_mean_host: H2D copy failed");
         return -2;
