@@ -6,6 +6,8 @@ integration tests, SURVEY.md section 4 style 2):
   test_MAP.py:51-65          findMAP within 1e-3 of the sphere optimum
 plus the batched extras: sweep-based findNextPoint vs restarted Nelder-Mead and
 _gpllBatch vs scalar _gpll."""
+import ctypes
+
 import numpy as np
 import pytest
 from scipy.optimize import minimize
@@ -276,6 +278,55 @@ def test_nll_from_concurrent_host_threads():
         t.join()
     for k in range(2):
         assert np.array_equal(got[k], want[k])
+
+
+def test_nll_and_scalar_predict_on_two_streams_concurrently():
+    """Two host threads, each under its OWN torch stream, evaluating _nll (mailbox + stream scratch), the
+    single-candidate predict and the pinned mean path at the same time: scratch, mailbox and enqueue lock
+    are kept per (device, stream), so nothing may leak between the streams and every value must equal
+    the single-threaded, default-stream one.  Sizes on both sides of the fused-launch boundary."""
+    import threading
+    import torch
+    from approxposterior_amd import gpUtils, _lib
+    rs = np.random.RandomState(31)
+    cases = []
+    for n, d in ((60, 2), (200, 3)):
+        X = rs.uniform(-5, 5, size=(n, d))
+        y = np.sin(X).sum(axis=1) + 0.1 * rs.randn(n)
+        np.random.seed(6)
+        gp = gpUtils.defaultGP(X, y, fitAmp=False)
+        p0 = np.array(gp.get_parameter_vector())
+        P = np.array([p0 + 0.05 * rs.randn(len(p0)) for _ in range(40)])
+        T = rs.uniform(-5, 5, size=(40, d))
+        cases.append((gp, y, P, T))
+
+    def run(gp, y, P, T):
+        out = []
+        with np.errstate(all="ignore"):
+            for i in range(len(P)):
+                v = gpUtils._nll(P[i], gp, y, None)
+                mu, var = gp.predict(y, T[i:i + 1], return_var=True)
+                m8 = gp.predict(y, T[:8], return_cov=False)
+                out.append((v, mu[0], var[0]) + tuple(m8))
+        return np.array(out)
+    want = [run(*c) for c in cases]
+    got = [None, None]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def work(k):
+        with torch.cuda.stream(streams[k]):
+            got[k] = run(*cases[k])
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert np.array_equal(got[k], want[k])
+    lib = _lib.load()
+    for st in streams:                       # the streams' scratch / mailboxes are released explicitly
+        st.synchronize()
+        assert lib.apgp_release_scratch(ctypes.c_void_p(st.cuda_stream)) >= 1
 
 
 def test_optimizegp_batched_restarts_equal_sequential():
