@@ -318,13 +318,130 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(TrsvStepArgs a) {
     if (w == 0 && i0 + lane < n) a.r[i0 + lane] = rown - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 
+// Round 3: FOUR 64-row blocks (256 rows) per launch.  The launch-to-launch dependency (~7 us) is what a step of the
+// chain above costs whatever it computes, so a step now takes a 256-row diagonal "super-block": every workgroup
+// solves it itself -- four 64 x 64 diagonal solves with the six 64 x 64 products between them, redundantly as
+// before -- and applies the 256 solved values to ITS 64 rows (forward) / columns (transposed) of the remaining
+// right-hand side.  Same arithmetic in the same order per element as the one-block step (a tile's product is the
+// four wavefronts' 16-term partial sums added pairwise, tiles are subtracted in block order), so the solution has
+// the same bits; a quarter of the launches.
+#define TRSV_SB 4
+template <int TRANS>
+__global__ __launch_bounds__(256) void trsv_step4_kernel(TrsvStepArgs a) {
+    __shared__ double Lb[64][65];
+    __shared__ double zb[TRSV_SB * 64];
+    __shared__ double part[4][64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long J0 = a.j0, n = a.n;
+    const int nsb = (int)(((n - J0) < 64 * TRSV_SB ? (n - J0) : 64 * TRSV_SB) + 63) / 64;    // real sub-blocks
+    const bool off = blockIdx.x != 0;
+    // this workgroup's block of the remaining right-hand side (forward: rows after the super-block; transposed:
+    // columns before it)
+    const long long i0 = TRANS ? J0 - 64 * (long long)blockIdx.x : J0 + 64 * TRSV_SB + 64 * ((long long)blockIdx.x - 1);
+    // its tiles against the super-block's solution: requested now, used last
+    double own[TRSV_SB][16];
+#pragma unroll
+    for (int q = 0; q < TRSV_SB; ++q)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const long long k = J0 + 64 * q + 16 * w + kk;      // element of the super-block's solution
+            if (!TRANS) own[q][kk] = (off && q < nsb && i0 + lane < n && k < n) ? a.L[(i0 + lane) * a.ldl + k] : 0.0;
+            else own[q][kk] = (off && q < nsb && k < n) ? a.L[k * a.ldl + i0 + lane] : 0.0;
+        }
+    const double rown = (w == 0 && off && (TRANS || i0 + lane < n)) ? a.r[i0 + lane] : 0.0;
+    // sub-blocks in dependency order: forward 0 .. nsb-1, transposed nsb-1 .. 0
+    for (int step = 0; step < nsb; ++step) {
+        const int sb = TRANS ? nsb - 1 - step : step;
+        const long long j0 = J0 + 64 * sb;
+        const int bs = (int)((n - j0) < 64 ? (n - j0) : 64);
+        double dg[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = 16 * w + q;
+            dg[q] = (r < bs && lane <= r) ? a.L[(j0 + r) * a.ldl + j0 + lane] : ((r == lane) ? 1.0 : 0.0);
+        }
+        double rj = (w == 0 && lane < bs) ? a.r[j0 + lane] : 0.0;
+        // minus the already solved sub-blocks of this super-block, one tile at a time, in their order
+        for (int st2 = 0; st2 < step; ++st2) {
+            const int qb = TRANS ? nsb - 1 - st2 : st2;
+            const long long q0 = J0 + 64 * qb;
+            double ob[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const long long k = q0 + 16 * w + kk;
+                if (!TRANS) ob[kk] = (lane < bs) ? a.L[(j0 + lane) * a.ldl + k] : 0.0;           // (k < j0 <= n)
+                else ob[kk] = (k < n) ? a.L[k * a.ldl + j0 + lane] : 0.0;
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = fma(ob[kk], zb[64 * qb + 16 * w + kk], acc);
+            __syncthreads();                                 // (part is free: the previous tile's sum was consumed)
+            part[w][lane] = acc;
+            __syncthreads();
+            if (w == 0) rj = rj - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+        }
+        __syncthreads();                                     // (Lb / part free)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Lb[16 * w + q][lane] = dg[q];
+        __syncthreads();
+        if (w == 0) {
+            double ri = rj;
+            const double inv = 1.0 / Lb[lane][lane];
+            double v[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) v[k] = TRANS ? Lb[k][lane] : Lb[lane][k];
+            if (!TRANS) {
+                trtri_static_for<64>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const double zk = trsv_bcast(ri, k) * trsv_bcast(inv, k);
+                    ri = lane == k ? zk : (lane > k ? fma(-v[k], zk, ri) : ri);
+                });
+            } else {
+                trtri_static_for<64>([&](auto kc) {
+                    constexpr int k = 63 - decltype(kc)::value;
+                    const double xk = trsv_bcast(ri, k) * trsv_bcast(inv, k);
+                    ri = lane == k ? xk : (lane < k ? fma(-v[k], xk, ri) : ri);
+                });
+            }
+            zb[64 * sb + lane] = lane < bs ? ri : 0.0;
+            if (!off) {
+                if (lane < bs) a.x[j0 + lane] = ri;
+                if (a.sumsq) {
+                    double ss = lane < bs ? ri * ri : 0.0;
+                    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+                    if (lane == 0) *a.sumsq += ss;          // (one writer, sub-blocks in order, launches in stream order)
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!off) return;
+    // this workgroup's block minus the super-block's contribution, tile by tile in the solving order
+    double racc = rown;
+    for (int step = 0; step < nsb; ++step) {
+        const int qb = TRANS ? nsb - 1 - step : step;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < TRSV_SB; ++q)
+            if (q == qb) {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) acc = fma(own[q][kk], zb[64 * q + 16 * w + kk], acc);
+            }
+        __syncthreads();
+        part[w][lane] = acc;
+        __syncthreads();
+        if (w == 0) racc = racc - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    }
+    if (w == 0 && (TRANS || i0 + lane < n)) a.r[i0 + lane] = racc;
+}
+
 extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
                          int trans, double* x, double* sumsq, void* stream) {
     APGP_CHECK_ARG(L && b && x, "null pointer");
     APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
     hipStream_t st = (hipStream_t)stream;
-    if (n >= 768) {
-        // blocked form (trsv_step_kernel): one small launch per 64-row block (~10 us each, bound by the
+    if (n >= 256) {
+        // blocked form (trsv_step4_kernel): one small launch per 256 rows (round 2, trsv_step_kernel: per 64-row block (~10 us each, bound by the
         // launch-to-launch dependency; the single-workgroup form below costs ~10 us per block at N = 512
         // and 26 us per block at N = 4096).  Scratch and launches
         // of one solve are taken as a unit: host threads sharing a stream share the scratch.
@@ -338,15 +455,17 @@ extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* 
         TrsvStepArgs sa;
         sa.L = L; sa.r = r; sa.x = x; sa.sumsq = sumsq; sa.n = n; sa.ldl = ldl;
         const long long nb = (n + 63) / 64;
+        const long long nsup = (nb + TRSV_SB - 1) / TRSV_SB;          // 256-row super-blocks
         if (!trans) {
-            for (long long jb = 0; jb < nb; ++jb) {
-                sa.j0 = jb * 64;
-                hipLaunchKernelGGL(trsv_step_kernel<0>, dim3((unsigned)(nb - jb)), dim3(256), 0, st, sa);
+            for (long long sj = 0; sj < nsup; ++sj) {
+                sa.j0 = sj * 64 * TRSV_SB;
+                const long long after = nb - (sj + 1) * TRSV_SB;     // 64-row blocks below the super-block
+                hipLaunchKernelGGL(trsv_step4_kernel<0>, dim3((unsigned)(1 + (after > 0 ? after : 0))), dim3(256), 0, st, sa);
             }
         } else {
-            for (long long jb = nb - 1; jb >= 0; --jb) {
-                sa.j0 = jb * 64;
-                hipLaunchKernelGGL(trsv_step_kernel<1>, dim3((unsigned)(jb + 1)), dim3(256), 0, st, sa);
+            for (long long sj = nsup - 1; sj >= 0; --sj) {
+                sa.j0 = sj * 64 * TRSV_SB;
+                hipLaunchKernelGGL(trsv_step4_kernel<1>, dim3((unsigned)(1 + sj * TRSV_SB)), dim3(256), 0, st, sa);
             }
         }
         APGP_CHECK_LAUNCH();
