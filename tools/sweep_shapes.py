@@ -19,12 +19,19 @@ if "--extra" in sys.argv:
               (1152, 8, 1000000, "agp"), (4096, 8, 1000000, "agp")]
 if "--dsweep" in sys.argv:
     shapes = [(n, d, 1000000, "agp") for d in (2, 4, 8, 16) for n in (1024, 1152, 2048)]
+if "--ring" in sys.argv:
+    shapes = [(1024, 2, 100000, "bape"), (1024, 2, 1000000, "agp"), (1152, 8, 1000000, "agp"), (1152, 2, 1000000, "agp"),
+              (1100, 8, 1000000, "agp"), (1280, 8, 1000000, "agp"), (2048, 8, 1000000, "agp"), (2304, 16, 1000000, "agp"),
+              (4096, 8, 1000000, "agp")]
+if "--elim" in sys.argv:
+    shapes = [(1152, 8, 1000000, "agp"), (1152, 2, 1000000, "agp"), (1024, 2, 1000000, "agp"), (1280, 8, 1000000, "agp"),
+              (4096, 8, 1000000, "agp")]
 reps = 5
 out = []
 for n, d, m, kind in shapes:
     X, y = synthetic_c3(n, d)
     T = torch.from_numpy(np.random.RandomState(1).uniform(-5, 5, size=(m, d))).cuda()
-    for mode in ("inverse", "solve"):
+    for mode in (("inverse",) if "--inverse-only" in sys.argv else ("inverse", "solve")):
         g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(d, 8.0), ndim=d), fit_mean=True, mean=np.median(y),
                    white_noise=-12, fit_white_noise=False)
         g.variance_mode = mode
