@@ -305,8 +305,12 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[s_][r] = 0.0;
                 int kc = 0;
-                auto do_tile = [&](auto pred_tag) {
+                auto do_tile_n = [&](auto pred_tag, auto npa_tag) {
                     constexpr bool PRED = decltype(pred_tag)::value;
+                    // NPA: sub-block pairs this body works through (8 = the whole tile; 4 / 6: the straight tiles
+                    // of a partial last row block, whose remaining rows are zero in the packed factor; even,
+                    // so that the last pair's prefetch of the next tile lands in the free fragment buffer)
+                    constexpr int NPA = decltype(npa_tag)::value;
                     const int nslot = slot == 2 ? 0 : slot + 1;
                     auto mfma_pair = [&](int pr, int kk) {
 #pragma unroll
@@ -322,17 +326,17 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                     int p1 = (a.n - S2_ROWS * jb + 31) >> 5;
                     if (p1 > NP) p1 = NP;
 #pragma unroll
-                    for (int pr = 0; pr < NP; ++pr) {
+                    for (int pr = 0; pr < NPA; ++pr) {
                         const bool act = !PRED || (pr >= p0 && pr < p1);
                         if (act) mfma_pair(pr, 0);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (pr == 4) {
+                        if (pr == NPA / 2) {
                             // (SOLVE: the park stores of the last diagonal tile are acknowledged before this
                             // wavefront arrives -- their readers request them >= 14 barriers later)
                             if constexpr (SOLVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             __syncthreads();                    // barrier i: tile i+1 is complete
                         }
-                        if (pr + 1 < NP) {
+                        if (pr + 1 < NPA) {
                             // (first pair: the k-step 2-3 half of this tile's B operands; its
                             // registers were still in use when the 0-1 half was prefetched)
                             if (pr == 0) load_b(bpar, 1);
@@ -379,9 +383,18 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
                     slot = nslot;
                     bpar ^= 1;
                 };
+                auto do_tile = [&](auto pred_tag) { do_tile_n(pred_tag, std::integral_constant<int, NP>{}); };
                 const int nstraight = (a.n - S2_ROWS * jb >= S2_ROWS) ? ndiag0 : 0;
                 for (; kc < nstraight; ++kc) do_tile(std::false_type{});
                 if constexpr (!SOLVE) {
+                    // partial last row block of <= 128 / <= 192 rows: its straight tiles with four / six pairs at
+                    // compile time (the predicated body costs 3.4 k cycles for four pairs' 2.05 k of MFMAs,
+                    // profiles/r03aa; N = 1152: 23.9 -> 22.8 ms, bit-identical).  Plain loops in sequence: as
+                    // if / else alternatives that join with the 128 accumulators live, hipcc spilled them.
+                    const int npart4 = (nstraight == 0 && a.n - S2_ROWS * jb <= 128) ? ndiag0 : 0;
+                    for (; kc < npart4; ++kc) do_tile_n(std::false_type{}, std::integral_constant<int, 4>{});
+                    const int npart6 = (nstraight == 0 && a.n - S2_ROWS * jb <= 192) ? ndiag0 : 0;
+                    for (; kc < npart6; ++kc) do_tile_n(std::false_type{}, std::integral_constant<int, 6>{});
                     for (; kc < nkc; ++kc) do_tile(std::true_type{});
                 } else {
                     for (; kc < ndiag0 && kc < nkc; ++kc) do_tile(std::true_type{});   // (partial last row block)
