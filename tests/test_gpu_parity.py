@@ -317,10 +317,13 @@ def _synthetic(n, d, seed=0):
 
 @pytest.mark.parametrize("n,d,m,metric", [(1024, 2, 3000, 2.0), (700, 8, 1500, 8.0), (513, 3, 777, 1.0),
                                            (64, 16, 200, 30.0), (1, 1, 5, 1.0), (17, 4, 1, 4.0),
-                                           (90, 2, 300, 2.0), (128, 16, 100, 30.0), (65, 5, 64, 6.0)])
+                                           (90, 2, 300, 2.0), (128, 16, 100, 30.0), (65, 5, 64, 6.0),
+                                           (1100, 8, 2000, 8.0), (500, 4, 900, 4.0), (448, 2, 700, 2.0)])
 def test_oracle_parity_seeded(n, d, m, metric, lib_loaded):
     """HIP vs oracle on seeded synthetic sets: ragged sizes (N, M not multiples
-    of any tile), D from 1 to the 16-dim maximum, single candidate / single point."""
+    of any tile), D from 1 to the 16-dim maximum, single candidate / single point.  The last
+    256-row block of the factor is partial in most of them: 1 / 76 rows (four-pair tile body),
+    188 / 192 rows (six-pair body), 244 rows (predicated body)."""
     go, agp = _mods()
     X, y = _synthetic(n, d)
     cands = np.random.RandomState(1).uniform(-5.2, 5.2, size=(m, d))
