@@ -822,14 +822,39 @@ class GP(object):
         self.recompute()
         xs = self.parse_samples(t)
         if return_cov and not return_var:
-            raise NotImplementedError(
-                "full predictive covariance is not on the MI355X hot path; "
-                "approxposterior only ever asks for return_var=True or the mean")
+            return self._predict_cov(y, xs)
         if not return_var:
             mu, = self._sweep(y, xs, kind=None, want=("mu",))
             return mu
         mu, var = self._sweep(y, xs, kind=None, want=("mu", "var"))
         return mu, var
+
+    def _predict_cov(self, y, xs):
+        """(mu, cov) of george's ``GP.predict`` defaults (return_cov=True): cov = k(t, t) - V^T V with
+        V = L^-1 k(X, t).  Not on approxposterior's path (it only ever asks for the mean or
+        return_var=True: approx.py:178, utility.py:131,178,224) -- served for callers that use the
+        george default: the two cross-kernel matrices by the HIP kernel of the row append
+        (apgp_kernel_cross), the triangular solve against the resident factor and the (M, N) x (N, M)
+        product as plain library calls (rocBLAS trsm / gemm through torch), all on the device.
+        Memory: (2 N + M) M doubles."""
+        torch, dev, lib = self._rt()
+        mu, = self._sweep(y, xs, kind=None, want=("mu",))
+        n, m = len(self._x), len(xs)
+        with self._on(torch, dev):
+            st = self._stream(torch)
+            ks = self._kernel_struct()
+            if getattr(self, "_x_d", None) is None or self._x_d.shape[0] != n:
+                self._x_d = torch.from_numpy(self._x).to(dev)
+            t_d = torch.from_numpy(np.ascontiguousarray(xs, dtype=np.float64)).to(dev)
+            kxt = torch.empty((m, n), dtype=torch.float64, device=dev)
+            cov = torch.empty((m, m), dtype=torch.float64, device=dev)
+            _lib.check(lib.apgp_kernel_cross(t_d.data_ptr(), m, self._x_d.data_ptr(), n, ctypes.byref(ks),
+                                             kxt.data_ptr(), n, st), "apgp_kernel_cross")
+            _lib.check(lib.apgp_kernel_cross(t_d.data_ptr(), m, t_d.data_ptr(), m, ctypes.byref(ks),
+                                             cov.data_ptr(), m, st), "apgp_kernel_cross")
+            v = torch.linalg.solve_triangular(self._L[:n, :n], kxt.T, upper=False)
+            cov -= v.T @ v
+            return mu, cov.cpu().numpy()
 
     def acquire(self, y, t, kind, bounds=None, mask=None, zeta=0.01, return_all=False,
                 idx_offset=0):

@@ -356,6 +356,39 @@ def test_oracle_parity_seeded(n, d, m, metric, lib_loaded):
         assert bi == -1
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,m,metric,order", [(130, 5, 40, 6.0, None), (700, 8, 257, 8.0, None), (50, 2, 1, 2.0, None),
+                                                (150, 3, 33, 3.0, 1)])
+def test_predict_full_covariance(n, d, m, metric, order, lib_loaded):
+    """george's GP.predict DEFAULT (return_cov=True): (mu, cov) with cov = k(t,t) - k(t,X) K^-1 k(X,t).
+    The reference never asks for it (approx.py:178 and utility.py:131,178,224 pass return_cov=False /
+    return_var=True) -- served for callers of the george default, against the oracle's restatement
+    (Appendix A.7): the whole matrix, its symmetry, and its diagonal against return_var=True."""
+    go, agp = _mods()
+    X, y = _synthetic(n, d)
+    T = np.random.RandomState(3).uniform(-5, 5, size=(m, d))
+    def make(mod):
+        k = mod.ExpSquaredKernel(np.full(d, metric), ndim=d)
+        if order is not None:
+            k = 7.0 * k + 0.3 * mod.kernels.LinearKernel(log_gamma2=0.5, order=order, bounds=None, ndim=d)
+        gp_ = mod.GP(kernel=k, fit_mean=True, mean=np.median(y), white_noise=-12, fit_white_noise=False)
+        gp_.compute(X)
+        return gp_
+    gpo, gp = make(go), make(agp)
+    K = gpo.kernel.get_value(gpo._x)
+    K[np.diag_indices_from(K)] += np.exp(-12.0)
+    tol = max(1e-12, 200 * np.linalg.cond(K) * EPS)
+    mo, co = gpo.predict(y, T)
+    mu, cov = gp.predict(y, T)
+    assert cov.shape == (m, m) and mu.shape == (m,)
+    scale = max(1.0, np.abs(co).max())
+    assert np.abs(mu - mo).max() <= tol * max(np.abs(gpo._compute_alpha(y, False)).sum(), 1e-300)
+    assert np.abs(cov - co).max() <= tol * scale
+    assert np.abs(cov - cov.T).max() <= 1e-10 * scale
+    _, var = gp.predict(y, T, return_var=True)
+    assert np.abs(np.diag(cov) - var).max() <= tol * scale
+
+
 @pytest.mark.parametrize("n,d,m,metric", [(1024, 2, 3000, 2.0), (700, 8, 1500, 8.0), (513, 3, 777, 1.0),
                                            (64, 16, 200, 30.0), (1, 1, 5, 1.0), (17, 4, 1, 4.0),
                                            (1300, 8, 20000, 8.0), (255, 2, 333, 2.0), (271, 5, 16500, 6.0)])
