@@ -829,6 +829,56 @@ class GP(object):
         mu, var = self._sweep(y, xs, kind=None, want=("mu", "var"))
         return mu, var
 
+    # -- the rest of george.GP's public surface (not called by approxposterior) ---------------
+    def apply_inverse(self, y):
+        """K^-1 y for a vector (N,) or a matrix (N, k) -- george ``GP.apply_inverse`` (cho_solve against the
+        resident factor; a library triangular solve pair on the device)."""
+        self.recompute()
+        torch, dev, lib = self._rt()
+        b = np.ascontiguousarray(y, dtype=np.float64)
+        n = len(self._x)
+        if b.shape[0] != n:
+            raise ValueError("Dimension mismatch")
+        with self._on(torch, dev):
+            bd = torch.from_numpy(b.reshape(n, -1)).to(dev)
+            out = torch.cholesky_solve(bd, self._L[:n, :n], upper=False)
+            return out.cpu().numpy().reshape(b.shape)
+
+    def get_matrix(self, x1, x2=None):
+        """The kernel matrix k(x1, x2) (x2 = None: k(x1, x1)), without the white-noise diagonal -- george
+        ``GP.get_matrix``; evaluated by the HIP cross-kernel."""
+        torch, dev, lib = self._rt()
+        a1 = np.ascontiguousarray(self.parse_samples(x1), dtype=np.float64)
+        a2 = a1 if x2 is None else np.ascontiguousarray(self.parse_samples(x2), dtype=np.float64)
+        with self._on(torch, dev):
+            st = self._stream(torch)
+            ks = self._kernel_struct()
+            d1 = torch.from_numpy(a1).to(dev)
+            d2 = d1 if x2 is None else torch.from_numpy(a2).to(dev)
+            out = torch.empty((len(a1), len(a2)), dtype=torch.float64, device=dev)
+            _lib.check(lib.apgp_kernel_cross(d1.data_ptr(), len(a1), d2.data_ptr(), len(a2), ctypes.byref(ks),
+                                             out.data_ptr(), len(a2), st), "apgp_kernel_cross")
+            return out.cpu().numpy()
+
+    def nll(self, vector, y, quiet=True):
+        """george ``GP.nll``: -log_likelihood at ``vector`` (the parameters stay set, as in george)."""
+        self.set_parameter_vector(vector)
+        if not quiet:
+            return -self.log_likelihood(y, quiet=False)
+        ll = self.log_likelihood(y, quiet=True)
+        return -ll if np.isfinite(ll) else np.inf
+
+    def grad_nll(self, vector, y, quiet=True):
+        """george ``GP.grad_nll``: -grad_log_likelihood at ``vector``."""
+        self.set_parameter_vector(vector)
+        return -self.grad_log_likelihood(y, quiet=quiet)
+
+    def lnlikelihood(self, y, quiet=False):
+        return self.log_likelihood(y, quiet=quiet)
+
+    def grad_lnlikelihood(self, y, quiet=False):
+        return self.grad_log_likelihood(y, quiet=quiet)
+
     def _predict_cov(self, y, xs):
         """(mu, cov) of george's ``GP.predict`` defaults (return_cov=True): cov = k(t, t) - V^T V with
         V = L^-1 k(X, t).  Not on approxposterior's path (it only ever asks for the mean or

@@ -357,6 +357,41 @@ def test_oracle_parity_seeded(n, d, m, metric, lib_loaded):
 
 
 @pytest.mark.gpu
+def test_george_surface_off_the_path(lib_loaded):
+    """george.GP methods approxposterior never calls but a george user may: apply_inverse (vector and
+    matrix right-hand sides), get_matrix, nll / grad_nll and the lnlikelihood aliases -- against the oracle."""
+    go, agp = _mods()
+    n, d = 200, 3
+    X, y = _synthetic(n, d)
+    def make(mod):
+        gp_ = mod.GP(kernel=4.0 * mod.ExpSquaredKernel(np.full(d, 3.0), ndim=d), fit_mean=True, mean=np.median(y),
+                     white_noise=-10, fit_white_noise=False)
+        gp_.compute(X)
+        return gp_
+    gpo, gp = make(go), make(agp)
+    K = gpo.kernel.get_value(gpo._x)
+    K[np.diag_indices_from(K)] += np.exp(-10.0)
+    tol = max(1e-11, 200 * np.linalg.cond(K) * EPS)
+    B = np.random.RandomState(5).normal(size=(n, 3))
+    for b in (B[:, 0].copy(), B):
+        want = gpo.apply_inverse(b)
+        got = gp.apply_inverse(b)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= tol * np.abs(want).max()
+    T = np.random.RandomState(6).uniform(-5, 5, size=(17, d))
+    assert np.abs(gp.get_matrix(T) - gpo.kernel.get_value(T)).max() <= 1e-13 * 4.0
+    assert np.abs(gp.get_matrix(T, X) - gpo.kernel.get_value(T, X)).max() <= 1e-13 * 4.0
+    p = np.array(gpo.get_parameter_vector()) + 0.05
+    gpo.set_parameter_vector(p)
+    llo = gpo.log_likelihood(y)
+    glo = gpo.grad_log_likelihood(y)
+    assert np.isclose(gp.nll(p, y), -llo, rtol=max(1e-11, tol))
+    assert np.abs(gp.grad_nll(p, y) + glo).max() <= max(1e-9, tol) * max(1.0, np.abs(glo).max())
+    assert gp.lnlikelihood(y) == gp.log_likelihood(y)
+    assert np.array_equal(gp.grad_lnlikelihood(y), gp.grad_log_likelihood(y))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,d,m,metric,order", [(130, 5, 40, 6.0, None), (700, 8, 257, 8.0, None), (50, 2, 1, 2.0, None),
                                                 (150, 3, 33, 3.0, 1)])
 def test_predict_full_covariance(n, d, m, metric, order, lib_loaded):
