@@ -211,6 +211,33 @@ def fit_leg(agp, dev, seconds_cap=20.0):
     return out
 
 
+def mid_n_leg(agp, dev):
+    """The same fused sweep at BASELINE.json's other sweep sizes -- C2 (N=1024, D=2, 1e5 candidates, BAPE) and
+    C5's final size (N=1152, D=8, 1e6, AGP) -- HIP events around the launches of one call, median of 5 calls,
+    fraction of the FP64 roof on F_var.  Outside the headline's timed region; extra keys only
+    (tools/sweep_shapes.py is the developer version of this leg)."""
+    import torch
+    out = []
+    for n, d, m, kind in ((1024, 2, 100000, "bape"), (1152, 8, 1000000, "agp")):
+        X, y = synthetic_c3(n, d)
+        T = torch.from_numpy(np.random.RandomState(1).uniform(-5.0, 5.0, size=(m, d))).to(dev)
+        g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(d, 8.0), ndim=d), fit_mean=True, mean=np.median(y),
+                   white_noise=-12, fit_white_noise=False, device=dev)
+        g.compute(X)
+        g.acquire(y, T, kind, bounds=[(-5.0, 5.0)] * d)
+        g.kernel_events = ev = []
+        for _ in range(5):
+            best = g.acquire(y, T, kind, bounds=[(-5.0, 5.0)] * d)
+        torch.cuda.synchronize()
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        tf = f_var(n, d) * m / (ms * 1e-3) / 1e12
+        out.append({"n_train": n, "ndim": d, "candidates": m, "utility": kind, "kernel_ms": ms,
+                    "candidates_per_s": m / (ms * 1e-3), "tflops": tf, "frac_of_f64_peak": tf / PEAK_F64_TFLOPS,
+                    "best": [int(best[0]), float(best[1])]})
+        del T, g
+    return out
+
+
 def cpu_baseline(gpo, fit_s, y, ndim, seconds=12.0, scalar_calls=2000):
     """Reference-library batched path on the oracle:
     predict(y, T_chunk, return_var=True) on 4096-candidate chunks + vectorised
@@ -412,6 +439,7 @@ def main():
             out["cpu_baseline"]["scalar_path_gpu_value"] = 280.0 / (time.time() - t0)
             if not args.no_fit_leg:
                 out["fit"] = fit_leg(agp, dev)
+                out["mid_n"] = mid_n_leg(agp, dev)
         print(json.dumps(out))
     if launched:
         dist.destroy_process_group()
