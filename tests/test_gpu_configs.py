@@ -137,6 +137,53 @@ def test_c4_emulated_eight_shards_1e7():
     assert bu <= uo.min() + 1e-9 * abs(uo.min())      # nothing in the subsample beats the winner
 
 
+# --------------------------------------------------------------------------------------- C3
+@pytest.mark.parametrize("mode", ["inverse", "solve"])
+def test_c3_full_size_properties(mode):
+    """BASELINE.json configs[2] at FULL size (N_train = 4096, D = 8, 1e6 candidates of the seed-1
+    draw, AGP) in both variance forms, through properties that do not need the oracle on all 1e6 rows:
+    (i) the fused arg-min equals the arg-min of the utilities the same launch returns for every candidate;
+    (ii) the candidate matrix in reversed order gives the mirrored winner with the same bits;
+    (iii) sigma^2 does not depend on y and mu is affine in y (two right-hand sides, same factor);
+    (iv) a 4,096-row random subsample plus the winner's neighbourhood against the oracle."""
+    import torch
+    N, D, M = 4096, 8, 1_000_000
+    X, y = _synthetic(N, D)
+    gpo, gp = _pair(X, y, 8.0, D)
+    gp.variance_mode = mode
+    cands = np.random.RandomState(1).uniform(-5.0, 5.0, size=(M, D))
+    bounds = [(-5, 5)] * D
+    T = torch.from_numpy(cands).cuda()
+    bi, bu, u, mu, var = gp.acquire(y, T, "agp", bounds=bounds, return_all=True)
+    assert (bi, bu) == gp.acquire(y, T, "agp", bounds=bounds)          # (run to run)
+    # (i)
+    assert bi == int(np.nanargmin(u)) and bu == u[bi]
+    assert np.isfinite(u).all() and (var > 0).all()
+    # (ii)
+    Tr = torch.from_numpy(np.ascontiguousarray(cands[::-1])).cuda()
+    ri, ru = gp.acquire(y, Tr, "agp", bounds=bounds)
+    assert (ri, ru) == (M - 1 - bi, bu)
+    del Tr
+    # (iii)
+    y2 = 0.5 * y + np.sin(X[:, 0])
+    mu2, var2 = gp.predict(y2, cands, return_var=True)
+    assert np.array_equal(var2, var)
+    rows = np.unique(np.concatenate([np.random.RandomState(7).randint(0, M, size=4096),
+                                     np.arange(max(0, bi - 8), min(M, bi + 8))]))
+    m_o, v_o = gpo.predict(y, cands[rows], return_var=True)
+    m2_o, _ = gpo.predict(y2, cands[rows], return_var=True)
+    asum = np.abs(gpo._compute_alpha(y, False)).sum()
+    tol = 1e-11                              # cond(K) ~ 1.5e3 at these hyper-parameters
+    # (iv)
+    assert np.abs(mu[rows] - m_o).max() <= tol * asum
+    assert np.abs(mu2[rows] - m2_o).max() <= tol * max(asum, np.abs(gpo._compute_alpha(y2, False)).sum())
+    assert np.abs(var[rows] - v_o).max() <= (tol if mode == "inverse" else 10 * tol)
+    uo = _agp(m_o, v_o)
+    assert np.abs(u[rows] - uo).max() <= 1e-9 * np.abs(uo).max()
+    assert bu <= uo.min() + 1e-9 * abs(uo.min())
+    del T
+
+
 # --------------------------------------------------------------------------------------- C5
 def _box(D):
     lo, hi = -5.0, 5.0
