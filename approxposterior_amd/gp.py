@@ -890,6 +890,8 @@ class GP(object):
         torch, dev, lib = self._rt()
         mu, = self._sweep(y, xs, kind=None, want=("mu",))
         n, m = len(self._x), len(xs)
+        if m == 0:
+            return mu, np.empty((0, 0), dtype=np.float64)
         with self._on(torch, dev):
             st = self._stream(torch)
             ks = self._kernel_struct()

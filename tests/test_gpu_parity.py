@@ -777,6 +777,8 @@ def test_full_size_properties(lib_loaded):
     assert np.abs(svar - fvar[pick]).max() <= 1e-13 and np.abs(su - fu[pick]).max() <= 1e-11 * np.abs(fu).max()
     # (e) an empty candidate set: nothing admissible
     assert gp.acquire(y, np.empty((0, D)), "agp") == (-1, np.inf)
+    emu, ecov = gp.predict(y, np.empty((0, D)))
+    assert emu.shape == (0,) and ecov.shape == (0, 0)
     emu, evar = gp.predict(y, np.empty((0, D)), return_var=True)
     assert emu.shape == (0,) and evar.shape == (0,)
 
