@@ -30,6 +30,8 @@ if "--partial" in sys.argv:
     shapes = [(1100, 8, 1000000, "agp"), (1152, 8, 1000000, "agp"), (1200, 8, 1000000, "agp"), (1216, 2, 1000000, "agp"),
               (1250, 8, 1000000, "agp"), (600, 8, 1000000, "agp"), (2100, 4, 1000000, "agp"), (4200, 8, 500000, "agp"),
               (4096, 8, 1000000, "agp")]
+if "--big" in sys.argv:
+    shapes = [(8192, 8, 262144, "agp"), (6144, 8, 524288, "agp"), (4096, 8, 1000000, "agp")]
 reps = 5
 out = []
 for n, d, m, kind in shapes:
