@@ -841,7 +841,7 @@ class GP(object):
             raise ValueError("Dimension mismatch")
         with self._on(torch, dev):
             bd = torch.from_numpy(b.reshape(n, -1)).to(dev)
-            out = torch.cholesky_solve(bd, self._L[:n, :n], upper=False)
+            out = torch.cholesky_solve(bd, torch.tril(self._L[:n, :n]), upper=False)   # (bytes above the diagonal are undefined)
             return out.cpu().numpy().reshape(b.shape)
 
     def get_matrix(self, x1, x2=None):
@@ -904,7 +904,7 @@ class GP(object):
                                              kxt.data_ptr(), n, st), "apgp_kernel_cross")
             _lib.check(lib.apgp_kernel_cross(t_d.data_ptr(), m, t_d.data_ptr(), m, ctypes.byref(ks),
                                              cov.data_ptr(), m, st), "apgp_kernel_cross")
-            v = torch.linalg.solve_triangular(self._L[:n, :n], kxt.T, upper=False)
+            v = torch.linalg.solve_triangular(torch.tril(self._L[:n, :n]), kxt.T, upper=False)   # (bytes above the diagonal are undefined)
             cov -= v.T @ v
             return mu, cov.cpu().numpy()
 

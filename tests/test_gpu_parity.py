@@ -389,6 +389,19 @@ def test_george_surface_off_the_path(lib_loaded):
     assert np.abs(gp.grad_nll(p, y) + glo).max() <= max(1e-9, tol) * max(1.0, np.abs(glo).max())
     assert gp.lnlikelihood(y) == gp.log_likelihood(y)
     assert np.array_equal(gp.grad_lnlikelihood(y), gp.grad_log_likelihood(y))
+    # N <= 64: the factor of the fused one-launch evaluation lives in an uninitialised buffer above its diagonal
+    Xs, ys = X[:40], y[:40]
+    gps = agp.GP(kernel=4.0 * agp.ExpSquaredKernel(np.full(d, 3.0), ndim=d), fit_mean=True, mean=np.median(ys),
+                 white_noise=-10, fit_white_noise=False)
+    gos = go.GP(kernel=4.0 * go.ExpSquaredKernel(np.full(d, 3.0), ndim=d), fit_mean=True, mean=np.median(ys),
+                white_noise=-10, fit_white_noise=False)
+    gps.compute(Xs); gos.compute(Xs)
+    assert np.isclose(gps.log_likelihood(ys), gos.log_likelihood(ys), rtol=1e-10)
+    bs = B[:40, 0].copy()
+    assert np.abs(gps.apply_inverse(bs) - gos.apply_inverse(bs)).max() <= 1e-8 * np.abs(gos.apply_inverse(bs)).max()
+    ms_, cs_ = gps.predict(ys, T)
+    mo_, co_ = gos.predict(ys, T)
+    assert np.abs(cs_ - co_).max() <= 1e-8 * max(1.0, np.abs(co_).max())
 
 
 @pytest.mark.gpu
