@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) void trsv_kernel(TrsvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// K3, blocked: the same solves as a sequence of small launches, one per 64-row block, for N >= 768.
+// K3, blocked: the same solves as a sequence of small launches, four 64-row blocks per launch, for N >= 256.
 // Launch jb: every workgroup (four wavefronts) solves the 64 x 64 diagonal block against the current
 // right-hand side of block jb itself (redundantly: 1 us, and no workgroup waits for another) and
 // applies the result to ITS block of the remaining rows (forward: block rows below, a wavefront-wide sum
@@ -755,7 +755,7 @@ extern "C" int apgp_predict1_host(const double* t_host, const double* xs, int64_
         hipLaunchKernelGGL(winv_gemv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, winv, (long long)ldw,
                            (long long)n, (const double*)a.kstar, 0.0, (double*)a.v);
     } else {
-        // (takes the stream's enqueue lock itself for n >= 768: not held here)
+        // (takes the stream's enqueue lock itself for n >= 256: not held here)
         const int rc = apgp_trsv(L, n, ldl, a.kstar, 0.0, 0, (double*)a.v, qbuf, stream);
         if (rc != 0) return rc;
         a.q_in = qbuf;

@@ -45,14 +45,18 @@ __device__ __forceinline__ int apgp_mma16_col(int lane, int r) { return 4 * ((((
 typedef double f64x2_g __attribute__((ext_vector_type(2), aligned(8)));   // global operand rows are only 8-byte aligned (ld = n)
 // With BB (row-major B only) the product B B^T of the B rows rides along in acc2 (same tile shape:
 // its A fragments are read from the B chunk), at the cost of its MFMAs alone.
+// `t` = index of the thread among the 256 that share the tile (threadIdx.x for a 256-thread workgroup; a
+// 512-thread workgroup runs two tiles side by side, t = threadIdx.x & 255, each half with its own `lds`; the
+// barriers are the workgroup's, so both halves make the call together -- a half without a tile passes
+// a_rows = b_rows = 0 and multiplies zeros).
 template <bool AK, bool BK, bool BB>
-__device__ __forceinline__ void apgp_gemm64_tile2(const double* __restrict__ Ap, long long lda, long long a_rows,
-                                                  const double* __restrict__ Bp, long long ldb, long long b_rows,
-                                                  long long k0, long long k1, double* lds, double (&acc)[2][2][4],
-                                                  double (&acc2)[2][2][4]) {
+__device__ __forceinline__ void apgp_gemm64_tile2_t(const int t, const double* __restrict__ Ap, long long lda, long long a_rows,
+                                                    const double* __restrict__ Bp, long long ldb, long long b_rows,
+                                                    long long k0, long long k1, double* lds, double (&acc)[2][2][4],
+                                                    double (&acc2)[2][2][4]) {
     static_assert(!BB || !BK, "B B^T needs the row-major B chunk");
     // LDS: [buffer][A 1280 | B 1280]; a k-major chunk is [16][80], a row-major one [64][18]
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
     const int kr = t >> 4, cq = (t & 15) * 4;       // k-major chunk: thread -> (k, 4 consecutive columns)
     const int rr = t >> 2, rq = (t & 3) * 4;        // row-major chunk: thread -> (row, 4 consecutive k)
@@ -126,6 +130,14 @@ __device__ __forceinline__ void apgp_gemm64_tile2(const double* __restrict__ Ap,
         __syncthreads();
         buf ^= 1;
     }
+}
+
+template <bool AK, bool BK, bool BB>
+__device__ __forceinline__ void apgp_gemm64_tile2(const double* __restrict__ Ap, long long lda, long long a_rows,
+                                                  const double* __restrict__ Bp, long long ldb, long long b_rows,
+                                                  long long k0, long long k1, double* lds, double (&acc)[2][2][4],
+                                                  double (&acc2)[2][2][4]) {
+    apgp_gemm64_tile2_t<AK, BK, BB>((int)threadIdx.x, Ap, lda, a_rows, Bp, ldb, b_rows, k0, k1, lds, acc, acc2);
 }
 
 template <bool AK, bool BK>

@@ -18,6 +18,7 @@
 #include "apgp_common.h"
 #include "mma16.h"
 #include "scratch.h"
+#include <atomic>
 #include <chrono>
 #include <type_traits>
 #include <utility>
@@ -55,6 +56,10 @@ struct PotrfArgs {
     long long zoff;          // offset of the latter
     // batched factorisation (apgp_nll_eval_batch): blockIdx.y selects the matrix
     long long batch_A, batch_rhs;   // element strides between consecutive matrices / right-hand sides
+    // persistent factorisation (potrf_persist.h): *abort_word == abort_id <=> the launch gave up; potrf_finish_kernel
+    // then reports PP_ABORTED in the summary's info slot and the host re-runs on the multi-launch path
+    const unsigned long long* abort_word;
+    unsigned long long abort_id;
 };
 
 // matrix of this workgroup in a batched launch (gridDim.y = batch size; strides 0 otherwise)
@@ -111,6 +116,9 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// every LDS spin between wavefronts is bounded (2^18 polls, tens of ms): a role that never publishes makes the result wrong,
+// never the GPU hang
+#define PANEL_SPIN_WHILE(cond) do { unsigned guard_ = 0; while (cond) { __builtin_amdgcn_s_sleep(1); if (++guard_ > (1u << 18)) break; } } while (0)
 // (a C++ volatile store through a generic pointer becomes a FLAT system-scope store plus
 // s_waitcnt vmcnt(0) -- hundreds of cycles per pivot on the critical path; this is the LDS store)
 __device__ __forceinline__ void lds_store_volatile(int* p, int v) {
@@ -173,7 +181,7 @@ __device__ __forceinline__ void panel_helper_wave(const int bs, const int lane, 
     PANEL_FENCE();
     static_for<HELPER_COL0 / CB>([&](auto cc_) {
         constexpr int c0 = CB * decltype(cc_)::value;
-        while (lds_load_volatile(&prog) < c0 + CB) __builtin_amdgcn_s_sleep(1);
+        PANEL_SPIN_WHILE(lds_load_volatile(&prog) < c0 + CB);
         PANEL_FENCE();
         double xs[CB];
 #pragma unroll
@@ -208,7 +216,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
         if constexpr (c0 == HELPER_COL0) {
             // columns HELPER_COL0 .. of this row come back from the helper wavefront, updated with
             // the groups before this one (panel_helper_wave)
-            while (lds_load_volatile(hflag_p) == 0) __builtin_amdgcn_s_sleep(1);
+            PANEL_SPIN_WHILE(lds_load_volatile(hflag_p) == 0);
             PANEL_FENCE();
 #pragma unroll
             for (int k = HELPER_COL0; k < PB; k += 2) {
@@ -322,7 +330,7 @@ __device__ __forceinline__ void panel_solve_wave(PotrfArgs& a, const long long j
                                                  const double* invd, const double* zblk, int* prog_p, const int wb_index) {
 #define prog (*prog_p)
     auto wait_prog = [&](int need) {
-        while (lds_load_volatile(&prog) < need) __builtin_amdgcn_s_sleep(1);
+        PANEL_SPIN_WHILE(lds_load_volatile(&prog) < need);
         PANEL_FENCE();
     };
     static_for<PB / CB>([&](auto cc_) {
@@ -499,6 +507,7 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
     a.A = q.K; a.rhs = q.z; a.n = q.n; a.lda = q.n; a.j0 = 0; a.shift = 0.0; a.info = q.info; a.out5 = nullptr;
     a.mail = nullptr; a.seq = 0;
     a.dscr = nullptr; a.batch_dscr = 0; a.zoff = 0; a.batch_A = 0; a.batch_rhs = 0;
+    a.abort_word = nullptr; a.abort_id = 0;
     double ar[PB];
     const double ri = lane < bs ? q.y[lane] - q.shift : 0.0;
 #pragma unroll
@@ -746,6 +755,7 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
     potrf_select(a);
     __shared__ double ssum[16], smin[16], smax[16], szz[16];
     __shared__ int sinfo;
+    const bool aborted = a.abort_word && *a.abort_word == a.abort_id;     // (persistent launch gave up: potrf_persist.h)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (*(unsigned int*)a.info == 0xffffffffu) *a.info = 0;
         sinfo = *a.info;
@@ -780,13 +790,13 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
             a.out5[1] = mn;
             a.out5[2] = mx;
             a.out5[3] = zz;
-            a.out5[4] = (double)sinfo;
+            a.out5[4] = aborted ? -7777.0 /* PP_ABORTED */ : (double)sinfo;
             if (a.mail && blockIdx.y == 0) {
                 a.mail[0] = 2.0 * sl;
                 a.mail[1] = mn;
                 a.mail[2] = mx;
                 a.mail[3] = zz;
-                a.mail[4] = (double)sinfo;
+                a.mail[4] = aborted ? -7777.0 : (double)sinfo;
                 __hip_atomic_store((long long*)(a.mail + 5), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -800,6 +810,100 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
         if (r < bs && c <= r) a.A[(j0 + r) * a.lda + j0 + c] = src[e];
     }
     if (a.rhs && threadIdx.x < bs) a.rhs[j0 + threadIdx.x] = a.dscr[a.zoff + j0 + threadIdx.x];
+}
+
+
+#include "potrf_persist.h"
+
+// ---------------------------------------------------------------------------
+// host side of the persistent factorisation
+// ---------------------------------------------------------------------------
+// 0 = persistent where it applies (default) | 1 = multi-launch path only | 2 = persistent, workgroup 0 gives up at
+// once (exercises the fallback).  A test / profiling switch (apgp_potrf_mode), not read from the environment.
+static std::atomic<int> g_potrf_mode{0};
+static std::atomic<long long> g_potrf_fallbacks{0};
+extern "C" int apgp_potrf_mode(int mode) {
+    if (mode < 0) return g_potrf_mode.load();
+    if (mode > 2) { apgp_set_error("apgp_potrf_mode: bad argument: mode 0 .. 2"); return -1; }
+    return g_potrf_mode.exchange(mode);
+}
+extern "C" int64_t apgp_potrf_fallbacks(void) { return g_potrf_fallbacks.load(); }
+
+static int potrf_device_cus(int dev) {
+    static std::mutex mu;
+    static int cus[64] = {0};
+    if (dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = -1;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
+// the persistent launch serves one matrix of 64 < n <= 4096 whose byte offsets fit the buffer descriptor, on a device
+// with a CU for every row workgroup and at least one more
+static bool potrf_persist_applies(int64_t n, int64_t lda, hipStream_t s) {
+    if (g_potrf_mode.load() == 1) return false;
+    const int64_t nb = (n + PB - 1) / PB;
+    if (nb < 2 || nb > PP_MAX_NB) return false;
+    if (lda * n * 8 >= (1ll << 31)) return false;
+    return potrf_device_cus(apgp_stream_device(s)) >= nb + 1;
+}
+
+// gram (pre_init) -> ONE persistent launch -> potrf_finish_kernel (summary, factored diagonal blocks into place).
+// Caller holds apgp_stream_lock(s).  The summary's info slot reads PP_ABORTED if the launch gave up.
+static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, int32_t* info_dev, hipStream_t s,
+                                double* out5, double* mail, long long seq) {
+    const int dev = apgp_stream_device(s);
+    const long long nb = (n + PB - 1) / PB;
+    PersistArgs q;
+    PotrfArgs& a = q.a;
+    a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.j0 = 0; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
+    a.mail = mail; a.seq = seq; a.batch_A = 0; a.batch_rhs = n;
+    a.zoff = nb * (long long)(PB * PB); a.batch_dscr = a.zoff + nb * PB;
+    a.dscr = apgp_stream_scratch(0, s, (size_t)a.batch_dscr);
+    bool fresh = false;
+    unsigned long long* calls = nullptr;
+    pp_u64* pw = (pp_u64*)apgp_stream_scratch_ex(2, s, (size_t)PP_SCRATCH_WORDS, &fresh, &calls);
+    if (!a.dscr || !pw) {
+        apgp_set_error("apgp_potrf: scratch allocation failed");
+        return -2;
+    }
+    unsigned long long id = ++*calls;
+    if ((unsigned)id == 0u) { fresh = true; id = ++*calls; }             // (the 32-bit granule tag wrapped: start over)
+    if (fresh && hipMemsetAsync(pw, 0, (size_t)PP_SCRATCH_WORDS * 8, s) != hipSuccess) {
+        apgp_set_error("apgp_potrf: memset failed");
+        return -2;
+    }
+    q.ctl = pw; q.strm = pw + PP_CTL_WORDS; q.zstrm = q.strm + PP_STRM_WORDS;
+    q.call_id = id;
+    q.timeout = 5000000ull;                                             // 50 ms of the 100 MHz clock
+    q.nb = (int)nb;
+    q.debug = g_potrf_mode.load() == 2 ? 1 : 0;
+    a.abort_word = pw + PP_CTL_ABORT; a.abort_id = id;
+    {
+        static std::mutex attr_mu;
+        static bool attr_set[64] = {false};
+        std::lock_guard<std::mutex> lock(attr_mu);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            if (hipFuncSetAttribute((const void*)potrf_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess) {
+                apgp_set_error("apgp_potrf: hipFuncSetAttribute failed");
+                return -2;
+            }
+            attr_set[dev] = true;
+        }
+    }
+    const long long tiles0 = (nb - 1) * (nb - 2) / 2;                   // tiles of the first update step
+    long long nupd = (tiles0 + 1) / 2;
+    const long long room = potrf_device_cus(dev) - nb;
+    if (nupd > room) nupd = room;
+    if (nupd < 1) nupd = 1;
+    hipLaunchKernelGGL(potrf_persist_kernel, dim3((unsigned)(nb + nupd)), dim3(PP_THREADS), PP_LDS_BYTES, s, q);
+    hipLaunchKernelGGL(potrf_finish_kernel, dim3((unsigned)nb, 1u), dim3(256), 0, s, a);
+    APGP_CHECK_LAUNCH();
+    return 0;
 }
 
 // `batch` matrices A + b * batch_A (right-hand sides y - shifts[b] -> z + b * n) factorised by
@@ -820,6 +924,7 @@ static int potrf_run_locked(double* A, int64_t n, int64_t lda, int64_t batch, in
     a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
     a.mail = mail; a.seq = seq;
     a.batch_A = batch_A; a.batch_rhs = n;
+    a.abort_word = nullptr; a.abort_id = 0;
     if (z && !pre_init)
         for (int64_t b = 0; b < batch; ++b)
             hipLaunchKernelGGL(potrf_rhs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, shifts[b],
@@ -884,6 +989,17 @@ static int mailbox_wait(ApgpMailbox* mb, long long seq, hipStream_t s, double* o
     return 0;
 }
 
+// the 5-value record of an evaluation: through the mailbox, or the 40-byte copy + synchronisation
+static int nll_fetch(ApgpMailbox* mb, bool mail, long long seq, hipStream_t s, const double* out5_dev, double* out5_host) {
+    if (mail) return mailbox_wait(mb, seq, s, out5_host);
+    if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        apgp_set_error("apgp_nll_eval: D2H copy failed");
+        return -2;
+    }
+    return 0;
+}
+
 extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, double shift, double* z,
                           int32_t* info_dev, void* stream) {
     APGP_CHECK_ARG(A && info_dev, "null pointer");
@@ -922,16 +1038,25 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
         // and the info word, the Cholesky's last launch writes the summary
         rc = apgp_gram_with_rhs(X, n, kern, K, n, y, mean, z, info_dev, stream);
         if (rc != 0) return rc;
-        rc = potrf_run_locked(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, out5_dev, mail ? mb->dev : nullptr, seq);
+        const bool persist = potrf_persist_applies(n, n, s);
+        rc = persist ? potrf_persist_locked(K, n, n, z, info_dev, s, out5_dev, mail ? mb->dev : nullptr, seq)
+                     : potrf_run_locked(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, out5_dev, mail ? mb->dev : nullptr, seq);
         if (rc != 0) return rc;
+        if (persist) {
+            rc = nll_fetch(mb, mail, seq, s, out5_dev, out5_host);
+            if (rc != 0 || out5_host[4] != PP_ABORTED) return rc;
+            // the persistent launch gave up (its workgroups were not all resident in time): the evaluation again,
+            // from the Gram matrix, on the multi-launch path
+            g_potrf_fallbacks.fetch_add(1);
+            const long long seq2 = mail ? ++mb->seq : 0;
+            rc = apgp_gram_with_rhs(X, n, kern, K, n, y, mean, z, info_dev, stream);
+            if (rc != 0) return rc;
+            rc = potrf_run_locked(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, out5_dev, mail ? mb->dev : nullptr, seq2);
+            if (rc != 0) return rc;
+            return nll_fetch(mb, mail, seq2, s, out5_dev, out5_host);
+        }
     }
-    if (mail) return mailbox_wait(mb, seq, s, out5_host);
-    if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess) {
-        apgp_set_error("apgp_nll_eval: D2H copy failed");
-        return -2;
-    }
-    return 0;
+    return nll_fetch(mb, mail, seq, s, out5_dev, out5_host);
 }
 
 // `batch` _nll evaluations at different hyper-parameters of the SAME training set in one call

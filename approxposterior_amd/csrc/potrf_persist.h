@@ -1,0 +1,669 @@
+// The blocked Cholesky of potrf.hip as ONE persistent launch (round 4): no launch boundary between the 64-column
+// steps, the trailing update off the critical path, and the 64 x 64 products of the next block column fed group by
+// group while the current one is still being factorised.  Included by potrf.hip (same translation unit: it reuses
+// the panel wavefront roles unchanged, so every element sees the arithmetic of the multi-launch path in the same
+// order and the two factorisations are bit-identical -- tests/test_gpu_parity.py compares them).
+//
+// Replaces, per gpUtils._nll evaluation (gpUtils.py:46-80 -> george GP.log_likelihood -> BasicSolver.compute),
+// the chain of 18 (N = 1152) .. 64 (N = 4096) dependent potrf_step_kernel launches.
+//
+// Grid: nb "row" workgroups (one per 64-row block, 512 threads = 8 wavefronts, one per CU) + "update" workgroups.
+//
+// Row workgroup r lives through the steps s = 0 .. r.  At step s < r it holds T = tile (r, s) and D = the diagonal
+// block (s, s), both updated with the block columns < s, and runs the panel step of the multi-launch path:
+//   wavefront 0  factorises D (redundantly in every row workgroup, as before: no workgroup waits for a factor);
+//   wavefront 2  is its helper (columns 32 .. 63 of groups 0 .. 7);
+//   wavefront 1  solves the 64 rows of T one 4-column group behind, and PUBLISHES each solved group: to LDS (the A
+//                operand of this workgroup's next products) and -- in workgroup s + 1 only, whose rows are the B
+//                operand of everybody's next products -- to global memory as data-tagged granules
+//                ({value half, tag} in one 8-byte word; the consumer needs no flag, the producer no fence or wait);
+//   wavefront 3  receives the groups of L(s+1, s) (one 8-byte agent-scope load per granule, polled) into LDS, and
+//                carries this block row's right-hand side of the forward solve z = L^-1 (y - mean);
+//   wavefronts 4-7 multiply: tile (r, s+1) -= L(r, s) L(s+1, s)^T and the next diagonal block (s+1, s+1) -=
+//                L(s+1, s) L(s+1, s)^T, one k = 4 step of v_mfma_f64_4x4x4_4b per published group, so that when the
+//                last group of the factorisation is out only ONE k-step, the subtraction from the tiles' values in
+//                memory (requested four groups earlier) and the LDS hand-over to wavefronts 0 / 1 remain.
+//   The critical path per 64-column step is then the factorisation itself + one granule hand-off + one k-step
+//   (the multi-launch path: launch boundary + operand loads + two 64^3 products + factorisation).
+//   At step r the workgroup factorises its own diagonal block for the output (L_rr, info, z_r): nobody waits for that.
+// Update workgroups apply block column s to the tiles (i, q), q >= s + 2 ("update step" s), two tiles at a time,
+//   as soon as all rows of L(:, s) are in memory (row workgroups store them at the start of their next step) -- one
+//   whole row step ahead of their use: tile (i, s + 2) is needed at the END of row step s + 1.  Tiles are owned
+//   statically (column-major index modulo the number of update half-workgroups), column s + 2 first.
+//
+// Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility; measured with tools/handoff_probe.hip):
+//   payload stores are write-through (sc1), every storing wavefront drains (s_waitcnt vmcnt(0)) before ONE relaxed
+//   agent-scope flag store; consumers poll ONE word relaxed, then either read with sc1 loads (row workgroups) or
+//   take ONE agent-scope acquire per update step and read plainly (update workgroups: operands stay L2-resident).
+//   Flags and granule tags are call-unique (a per-stream call counter), so nothing is zeroed between calls.
+// Every global spin is bounded: on timeout (the workgroups are not all resident -- a foreign kernel holds CUs --
+//   or a bug) the call is marked aborted and the host re-runs the evaluation on the multi-launch path.
+#pragma once
+
+typedef unsigned long long pp_u64;
+typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
+
+#define PP_MAX_NB 64
+#define PP_THREADS 512
+#define PP_CHUNK (64 * 18)                        // a 16-column chunk of a 64-row tile, rows padded to 18 (apgp_gemm64_tile's)
+// LDS map of a row workgroup (doubles)
+#define PP_LS 0                                   // [64][66]  diagonal block: staged rows, then the published factor
+#define PP_AS (PP_LS + 64 * 66)                   // [2][4][64][18]  own solved tile L(r, s), by step parity
+#define PP_BS (PP_AS + 2 * 4 * PP_CHUNK)          // [4][64][18]     received L(s+1, s)
+#define PP_INVD (PP_BS + 4 * PP_CHUNK)
+#define PP_ZBLK (PP_INVD + 64)
+#define PP_ZROW (PP_ZBLK + 64)
+#define PP_ZST (PP_ZROW + 64)
+#define PP_INTS (PP_ZST + 64)                     // 2 x 8 step-parity counters + 8 others
+#define PP_LDS_DOUBLES (PP_INTS + 12)
+#define PP_LDS_BYTES (PP_LDS_DOUBLES * 8)
+static_assert(PP_LDS_BYTES <= 160 * 1024, "one row workgroup per CU");
+static_assert(2 * GEMM64_LDS_DOUBLES <= PP_INTS, "update role: two tile buffers below the counters");
+static_assert(64 * 66 <= 4 * PP_CHUNK, "the handed-over tile fits one parity of As");
+// control block (pp_u64 words) in the stream's scratch
+#define PP_CTL_ABORT 0
+#define PP_CTL_ROWDONE 8                          // [64]      (call << 8) | block columns of this block row in memory
+#define PP_CTL_TILEFINAL 128                      // [64][64]  call id once tile (i, q) carries the block columns < q - 1
+#define PP_CTL_WORDS (128 + 64 * 64)
+#define PP_STRM_WORDS ((long long)PP_MAX_NB * 16 * 64 * 8)   // [step][group][lane][4 doubles x 2 granules]
+#define PP_ZSTRM_WORDS ((long long)PP_MAX_NB * 64 * 2)       // [step][lane][2 granules]
+#define PP_SCRATCH_WORDS (PP_CTL_WORDS + PP_STRM_WORDS + PP_ZSTRM_WORDS)
+#define PP_ABORTED (-7777.0)                      // out5[4] of an aborted call
+
+struct PersistArgs {
+    PotrfArgs a;
+    pp_u64* ctl;
+    pp_u64* strm;
+    pp_u64* zstrm;
+    pp_u64 call_id;
+    pp_u64 timeout;       // 100 MHz ticks
+    int nb;
+    int debug;            // 1: workgroup 0 aborts at once (exercises the host's fallback)
+};
+
+__device__ __forceinline__ pp_u64 pp_ld(const pp_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pp_st(pp_u64* p, pp_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double pp_ld_f64(const double* p) { return __longlong_as_double((long long)pp_ld((const pp_u64*)p)); }
+__device__ __forceinline__ void pp_st_f64(double* p, double v) { pp_st((pp_u64*)p, (pp_u64)__double_as_longlong(v)); }
+__device__ __forceinline__ void pp_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// one failed poll of a global spin: sleeps; every 32nd time looks at the abort word and the clock.
+// true = give up (the abort word carries this call's id, set here on timeout or by somebody else)
+struct PpSpin { pp_u64 t0 = 0; unsigned it = 0; };
+__device__ __forceinline__ bool pp_give_up(PpSpin& sp, pp_u64* ctl, const pp_u64 call_id, const pp_u64 timeout) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++sp.it & 31u) != 0) return false;
+    if (pp_ld(ctl + PP_CTL_ABORT) == call_id) return true;
+    const pp_u64 now = __builtin_amdgcn_s_memrealtime();
+    if (sp.t0 == 0) { sp.t0 = now; return false; }
+    if (now - sp.t0 > timeout) { pp_st(ctl + PP_CTL_ABORT, call_id); return true; }
+    return false;
+}
+__device__ __forceinline__ void pp_lds_wait_ge(const int* p, int need) {
+    PANEL_SPIN_WHILE(lds_load_volatile(p) < need);
+    PANEL_FENCE();
+}
+
+// wavefront 1 of a row workgroup: panel_solve_wave with every solved 4-column group published at once -- to As
+// (this workgroup's A operand, chunk layout) and, in the workgroup whose rows are everybody's B operand, to the
+// granule stream.  The rows themselves go to memory from As at the start of the next step (matrix wavefronts).
+__device__ __forceinline__ void pp_solve_wave(const int lane, double (&x)[PB], const double (*Ls)[PB + 2], const double* invd,
+                                              int* prog_p, double* As_par, int* xprog_p, const bool stream,
+                                              const __amdgpu_buffer_rsrc_t rs_strm, const unsigned strm_off, const unsigned tag) {
+    static_for<PB / CB>([&](auto cc_) {
+        constexpr int cc = decltype(cc_)::value, c0 = CB * cc;
+        pp_lds_wait_ge(prog_p, c0 + CB);                 // columns c0 .. c0 + CB - 1 of L_jj published
+        f64x2 dq[CB][CB / 2], iq[CB / 2];
+#pragma unroll
+        for (int r = 0; r < CB; ++r)
+#pragma unroll
+            for (int q = 0; 2 * q < r; ++q) dq[r][q] = *(const f64x2*)(&Ls[c0 + r][c0 + 2 * q]);
+#pragma unroll
+        for (int q = 0; q < CB / 2; ++q) iq[q] = *(const f64x2*)(&invd[c0 + 2 * q]);
+        PANEL_FENCE();
+        double xs[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            double sacc = x[c0 + k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) sacc = fma(-xs[m], (m & 1) ? dq[k][m >> 1].y : dq[k][m >> 1].x, sacc);
+            xs[k] = sacc * ((k & 1) ? iq[k >> 1].y : iq[k >> 1].x);
+            x[c0 + k] = xs[k];
+        }
+        {
+            double* dst = As_par + (cc >> 2) * PP_CHUNK + lane * 18 + 4 * (cc & 3);
+            *(f64x2*)dst = (f64x2){xs[0], xs[1]};
+            *(f64x2*)(dst + 2) = (f64x2){xs[2], xs[3]};
+            lds_store_volatile(xprog_p, cc + 1);         // (same wavefront: LDS stores stay in order)
+        }
+        if (stream) {
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                const pp_u32x4 g = {(unsigned)__double2loint(xs[k]), tag, (unsigned)__double2hiint(xs[k]), tag};
+                __builtin_amdgcn_raw_buffer_store_b128(g, rs_strm, (unsigned)(lane * 64 + k * 16), strm_off + (unsigned)(cc * 4096), 16);
+            }
+        }
+        PANEL_FENCE();
+        panel_trailing<c0, c0 + CB, PB, 0, PB>(x, xs, Ls);
+    });
+}
+
+// one k = 4 step (group g of the current block column) of a matrix wavefront's 32 x 32 quadrant:
+// acc += A_g B_g^T (own rows x received rows) and, with TWO, acc2 += B_g B_g^T -- the operations and operand
+// order of apgp_gemm64_tile2's inner loop, so the sums carry the same bits
+template <bool TWO>
+__device__ __forceinline__ void pp_kstep(const double* Ach, const double* Bch, const int ks, const int lane, const int wr, const int wc,
+                                         const int (&bcol)[4], double (&acc)[2][2][4], double (&acc2)[2][2][4]) {
+    double af[2], bf[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[i] = Ach[(wr + 16 * i + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j][r] = Bch[(wc + 16 * j + bcol[r]) * 18 + ks * 4 + (lane >> 4)];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf[j][r], acc[i][j][r], 0, 0, 0);
+    if constexpr (TWO) {
+        double bfa[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bfa[i] = Bch[(wr + 16 * i + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bfa[i], bf[j][r], acc2[i][j][r], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// row workgroup.  Each wavefront role is its own (not inlined) function: one register allocation per role instead
+// of one for a 30,000-instruction body (which spilled in the matrix wavefronts' loop).  The roles read the call's
+// arguments from the kernel-argument segment (scalar loads: uniform) and rebuild their LDS pointers from the byte
+// offset of the dynamic region.
+// ---------------------------------------------------------------------------
+// (the kernel-argument segment pointer is only defined in the kernel itself -- in a called function the builtin
+// reads as NULL on this toolchain -- so the kernel passes it down as two 32-bit halves, made uniform again here)
+typedef const __attribute__((address_space(4))) PersistArgs* pp_args_ptr;
+struct PpKarg { unsigned lo, hi; };
+__device__ __forceinline__ pp_args_ptr pp_args(PpKarg k) {
+    const unsigned long long v = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)k.hi) << 32) |
+                                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)k.lo);
+    return (pp_args_ptr)v;
+}
+__device__ __forceinline__ double* pp_lds_base(unsigned off) {
+    return (double*)(__attribute__((address_space(3))) double*)(size_t)__builtin_amdgcn_readfirstlane(off);
+}
+#define PP_NOINLINE __attribute__((noinline))
+// every role runs the same loop over the steps s = 0 .. r, with the workgroup's ONE barrier per step at its end (the
+// roles are functions that are entered once: a function's callee-saved registers are stored and reloaded through
+// scratch memory at entry and exit -- once per launch, not once per step)
+#define PP_STEP_LOOP_BEGIN(lds_)                                                                     \
+    for (int s_in = 0, r_ = (int)blockIdx.x; s_in <= r_; ++s_in) {                                   \
+        if (lds_load_volatile((int*)((lds_) + PP_INTS) + 17 + ((s_in + 1) & 1))) return;   /* somebody gave up during the previous step (uniform) */
+#define PP_STEP_LOOP_END()                                                                           \
+        if (s_in < r_) __syncthreads();                                                              \
+    }
+
+struct PpStep {            // what every role derives from (r, s)
+    int r, s, bs;
+    long long j0;
+    bool producer;
+    int* cnt;              // this step's counters: 0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag
+    int* wocnt;
+    int* abl;
+    double* As_cur;
+    double* As_prev;
+};
+__device__ __forceinline__ PpStep pp_step(double* lds, int s_in, long long n) {
+    PpStep p;
+    p.r = (int)blockIdx.x;
+    p.s = __builtin_amdgcn_readfirstlane(s_in);
+    p.j0 = (long long)p.s * PB;
+    p.bs = (int)((n - p.j0) < PB ? (n - p.j0) : PB);
+    p.producer = p.r == p.s + 1;                               // this workgroup's rows are the B operand of the step
+    int* ints = (int*)(lds + PP_INTS);
+    // step-parity counters: [par][0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag]; others: 16 wocnt | 17, 18 "give up" by
+    // step parity (set during step s, read at the head of step s + 1: never while it may still be written)
+    p.cnt = ints + 8 * (p.s & 1);
+    p.wocnt = ints + 16;
+    p.abl = ints + 17 + (p.s & 1);
+    p.As_cur = lds + PP_AS + (p.s & 1) * 4 * PP_CHUNK;         // this step's solved tile; at the step's start: the handed-over tile [64][66]
+    p.As_prev = lds + PP_AS + ((p.s & 1) ^ 1) * 4 * PP_CHUNK;  // L(r, s-1); at the step's end: the hand-over of the next tile
+    return p;
+}
+
+// ---------------- wavefront 0: the diagonal block (s, s); at step r also z_r ----------------
+__device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
+    pp_args_ptr q = pp_args(karg);
+    double* lds = pp_lds_base(lds_off);
+    const int lane = threadIdx.x & 63;
+    const long long n = q->a.n;
+    PP_STEP_LOOP_BEGIN(lds)
+    const PpStep p = pp_step(lds, s_in, n);
+    if (lane == 0) {
+        int* nx = (int*)(lds + PP_INTS) + 8 * ((s_in + 1) & 1);   // the next step's counters (nobody uses them before the barrier)
+        nx[0] = 0; nx[1] = 0; nx[2] = 0; nx[3] = 0; nx[4] = 0;
+    }
+    double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
+    double* invd = lds + PP_INVD;
+    double* zblk = lds + PP_ZBLK;
+    const double* zrow = lds + PP_ZROW;
+    const int bs = p.bs, s = p.s, r = p.r;
+    double rowv[PB];                                           // row `lane` of the diagonal block
+#pragma unroll
+    for (int k = 0; k < PB; k += 2) {
+        const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
+        rowv[k] = (lane < bs && k <= lane) ? v.x : ((k == lane) ? 1.0 : 0.0);
+        rowv[k + 1] = (lane < bs && k + 1 <= lane) ? v.y : ((k + 1 == lane) ? 1.0 : 0.0);
+    }
+    PotrfArgs pa;
+    pa.A = q->a.A; pa.rhs = nullptr;                           // (the forward solve is a separate pass below)
+    pa.n = n; pa.lda = q->a.lda; pa.j0 = p.j0; pa.shift = 0.0; pa.info = q->a.info; pa.out5 = nullptr; pa.mail = nullptr; pa.seq = 0;
+    pa.dscr = q->a.dscr; pa.batch_dscr = 0; pa.zoff = q->a.zoff; pa.batch_A = 0; pa.batch_rhs = 0; pa.abort_word = nullptr; pa.abort_id = 0;
+    panel_factor_wave(pa, p.j0, bs, lane, rowv, 0.0, Ls, invd, zblk, p.cnt + 0, p.cnt + 1, r == s ? 0 : PB, 1);
+    if (r == s && q->a.rhs) {
+        // z_s = L_ss^-1 (rhs block s): the operations of the pass that rides along in panel_factor_wave, in its
+        // order, on the finished factor (Ls, invd) -- the 4 x 4 blocks of Ls ARE its d[][] bit for bit
+        pp_lds_wait_ge(p.cnt + 4, 1);
+        double ri = lane < bs ? zrow[lane] : 0.0;
+        static_for<PB / CB>([&](auto cc_) {
+            constexpr int c0 = CB * decltype(cc_)::value;
+            double d[CB][CB], zb[CB], inv[CB], x[CB];
+#pragma unroll
+            for (int rr = 0; rr < CB; ++rr) {
+#pragma unroll
+                for (int qq = 0; qq < rr; ++qq) d[rr][qq] = Ls[c0 + rr][c0 + qq];
+                zb[rr] = bcast_lane(ri, c0 + rr);
+                inv[rr] = invd[c0 + rr];
+                x[rr] = Ls[lane][c0 + rr];
+            }
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                double zacc = zb[k];
+#pragma unroll
+                for (int m = 0; m < k; ++m) zacc = fma(-zb[m], d[k][m], zacc);
+                zb[k] = zacc * inv[k];
+            }
+            double racc = ri;
+#pragma unroll
+            for (int k = 0; k < CB; ++k) racc = fma(-x[k], zb[k], racc);
+            ri = lane >= c0 + CB ? racc : ri;
+#pragma unroll
+            for (int k = 0; k < CB; ++k) ri = lane == c0 + k ? zb[k] : ri;
+        });
+        if (lane < bs) (q->a.dscr + q->a.zoff)[p.j0 + lane] = ri;
+        if (s + 1 < q->nb) {
+            const unsigned tag = (unsigned)q->call_id;
+            const pp_u32x4 g = {(unsigned)__double2loint(ri), tag, (unsigned)__double2hiint(ri), tag};
+            const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)q->zstrm, 0, (int)(PP_ZSTRM_WORDS * 8), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(g, rs_z, (unsigned)(lane * 16), (unsigned)(s * 1024), 16);
+        }
+    }
+    PP_STEP_LOOP_END()
+}
+
+// ---------------- wavefront 1: the 64 rows of tile (r, s) ----------------
+__device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
+    pp_args_ptr q = pp_args(karg);
+    double* lds = pp_lds_base(lds_off);
+    const int lane = threadIdx.x & 63;
+    const long long n = q->a.n, lda = q->a.lda;
+    PP_STEP_LOOP_BEGIN(lds)
+    const PpStep p = pp_step(lds, s_in, n);
+    if (p.r > p.s) {
+    const double (*Ls)[PB + 2] = (const double (*)[PB + 2])(lds + PP_LS);
+    const long long row = (long long)p.r * PB + lane;
+    const bool has_row = row < n;
+    double rowv[PB];                                           // row `lane` of tile (r, s)
+    if (p.s == 0) {
+        const double* src = q->a.A + (has_row ? row : 0) * lda;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) rowv[k] = has_row ? src[k] : 0.0;
+    } else {
+        const double (*St)[PB + 2] = (const double (*)[PB + 2])p.As_cur;
+#pragma unroll
+        for (int k = 0; k < PB; k += 2) {
+            const f64x2 v = *(const f64x2*)(&St[lane][k]);
+            rowv[k] = has_row ? v.x : 0.0;
+            rowv[k + 1] = has_row ? v.y : 0.0;
+        }
+        PANEL_FENCE();
+    }
+    const __amdgpu_buffer_rsrc_t rs_strm = __builtin_amdgcn_make_buffer_rsrc((void*)q->strm, 0, (int)(PP_STRM_WORDS * 8), 0x00020000);
+    pp_solve_wave(lane, rowv, Ls, lds + PP_INVD, p.cnt + 0, p.As_cur, p.cnt + 2, p.producer, rs_strm, (unsigned)(p.s * 16 * 4096),
+                  (unsigned)q->call_id);
+    }
+    PP_STEP_LOOP_END()
+}
+
+// ---------------- wavefront 3: receiver -- z of the previous block column, then the groups of L(s+1, s) ----------------
+// rhs_r: the running right-hand side of the forward solve for this lane's matrix row
+__device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double rhs_r) {
+    pp_args_ptr q = pp_args(karg);
+    double* lds = pp_lds_base(lds_off);
+    const int lane = threadIdx.x & 63;
+    const long long n = q->a.n;
+    PP_STEP_LOOP_BEGIN(lds)
+    const PpStep p = pp_step(lds, s_in, n);
+    const int s = p.s, r = p.r;
+    const bool has_row = (long long)r * PB + lane < n;
+    const unsigned tag = (unsigned)q->call_id;
+    const pp_u64 call_id = q->call_id, timeout = q->timeout;
+    pp_u64* ctl = q->ctl;
+    double* Bs = lds + PP_BS;
+    double* zrow = lds + PP_ZROW;
+    double* zst = lds + PP_ZST;
+    int* bprog = p.cnt + 3;
+    int* zflag = p.cnt + 4;
+    bool dead = false;
+    if (q->a.rhs && s >= 1) {
+        const pp_u64* src = q->zstrm + ((long long)(s - 1) * 64 + lane) * 2;
+        pp_u64 g0, g1;
+        PpSpin sp;
+        for (;;) {
+            g0 = pp_ld(src); g1 = pp_ld(src + 1);
+            if (__all((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag)) break;
+            if (pp_give_up(sp, ctl, call_id, timeout)) { dead = true; break; }
+        }
+        if (!dead) {
+            zst[lane] = __hiloint2double((int)(unsigned)g1, (int)(unsigned)g0);
+            // rhs_row -= L(row, block s-1) . z_(s-1): the two-accumulator sum of panel_solve_wave
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < PB; k += 2) {
+                const f64x2 xv = *(const f64x2*)(p.As_prev + (k >> 4) * PP_CHUNK + lane * 18 + (k & 15));
+                const f64x2 zv = *(const f64x2*)(zst + k);
+                d0 = fma(xv.x, zv.x, d0);
+                d1 = fma(xv.y, zv.y, d1);
+            }
+            if (has_row) rhs_r -= d0 + d1;
+        }
+    }
+    if (!dead && r == s) {
+        zrow[lane] = rhs_r;
+        lds_store_volatile(zflag, 1);
+    } else if (!dead && !p.producer) {
+        static_for<PB / CB>([&](auto cc_) {
+            constexpr int cc = decltype(cc_)::value;
+            if (dead) return;
+            const pp_u64* src = q->strm + (((long long)s * 16 + cc) * 64 + lane) * 8;
+            pp_u64 g[8];
+            PpSpin sp;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { g[k] = pp_ld(src + k); ok = ok && (unsigned)(g[k] >> 32) == tag; }
+                if (__all(ok)) break;
+                if (pp_give_up(sp, ctl, call_id, timeout)) { dead = true; return; }
+            }
+            double* dst = Bs + (cc >> 2) * PP_CHUNK + lane * 18 + 4 * (cc & 3);
+            *(f64x2*)dst = (f64x2){__hiloint2double((int)(unsigned)g[1], (int)(unsigned)g[0]), __hiloint2double((int)(unsigned)g[3], (int)(unsigned)g[2])};
+            *(f64x2*)(dst + 2) = (f64x2){__hiloint2double((int)(unsigned)g[5], (int)(unsigned)g[4]), __hiloint2double((int)(unsigned)g[7], (int)(unsigned)g[6])};
+            lds_store_volatile(bprog, cc + 1);
+        });
+    }
+    if (dead) {
+        // release whoever waits for this wavefront; everybody leaves at the next step's head
+        lds_store_volatile(p.abl, 1);
+        lds_store_volatile(zflag, 1);
+    }
+    lds_store_volatile(bprog, PB);                             // (>= 16: also "this wavefront is done with As_prev")
+    PP_STEP_LOOP_END()
+}
+
+// ---------------- wavefronts 4-7: L(r, s-1) to memory; the next tile and the next diagonal block ----------------
+__device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
+    pp_args_ptr q = pp_args(karg);
+    double* lds = pp_lds_base(lds_off);
+    const int t = threadIdx.x, lane = t & 63;
+    const long long n = q->a.n, lda = q->a.lda;
+    PP_STEP_LOOP_BEGIN(lds)
+    const PpStep p = pp_step(lds, s_in, n);
+    const int s = p.s, r = p.r;
+    double* A = q->a.A;
+    double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
+    const double* Bs = lds + PP_BS;
+    int* prog = p.cnt + 0; int* xprog = p.cnt + 2; int* bprog = p.cnt + 3;
+    const int mt = t - 256, mw = __builtin_amdgcn_readfirstlane((t >> 6) - 4);
+    const int wr = (mw >> 1) * 32, wc = (mw & 1) * 32;
+    const pp_u64 call_id = q->call_id, timeout = q->timeout;
+    pp_u64* ctl = q->ctl;
+    bool dead = false;
+    if (s >= 1) {
+        // L(r, s-1) from LDS to memory, coalesced write-through stores; the flag once all four wavefronts drained
+        const __amdgpu_buffer_rsrc_t rs_A = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(lda * n * 8), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = it * 256 + mt, rw = e >> 5, col = 2 * (e & 31);
+            const f64x2 v = *(const f64x2*)(p.As_prev + (col >> 4) * PP_CHUNK + rw * 18 + (col & 15));
+            const long long gr = (long long)r * PB + rw;
+            if (gr < n)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_u32x4, v), rs_A,
+                                                       (unsigned)((gr * lda + (long long)(s - 1) * PB + col) * 8), 0, 16);
+        }
+        pp_drain();
+        if (lane == 0) {                                       // (ONE arrival per wavefront)
+            const int old = __hip_atomic_fetch_add(p.wocnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 4 * s - 1) pp_st(ctl + PP_CTL_ROWDONE + r, (call_id << 8) | (pp_u64)s);
+        }
+    }
+    if (r > s) {
+    int bcol[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) bcol[rr] = ((lane & 15) - 4 * rr) & 15;
+    double v[2][2][4], v2[2][2][4], cin[2][2][4], cin2[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { v[i][j][rr] = 0.0; v2[i][j][rr] = 0.0; cin[i][j][rr] = 0.0; cin2[i][j][rr] = 0.0; }
+    const long long base_n = p.j0 + PB;                        // first row / column of the next block column
+    const long long ri0 = (long long)r * PB;
+    const bool producer = p.producer;
+    auto ksteps = [&](auto lo_, auto hi_) {
+        constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
+        static_for<hi - lo>([&](auto g_) {
+            constexpr int g = lo + decltype(g_)::value;
+            pp_lds_wait_ge(xprog, g + 1);
+            if (producer) {
+                pp_kstep<false>(p.As_cur + (g >> 2) * PP_CHUNK, p.As_cur + (g >> 2) * PP_CHUNK, g & 3, lane, wr, wc, bcol, v, v2);
+            } else {
+                pp_lds_wait_ge(bprog, g + 1);
+                pp_kstep<true>(p.As_cur + (g >> 2) * PP_CHUNK, Bs + (g >> 2) * PP_CHUNK, g & 3, lane, wr, wc, bcol, v, v2);
+            }
+        });
+    };
+    ksteps(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
+    // the tiles' values in memory (block columns < s applied by the update workgroups): requested now, used last
+    if (s + 1 >= 2) {
+        const pp_u64* f0 = ctl + PP_CTL_TILEFINAL + (long long)r * 64 + (s + 1);
+        const pp_u64* f1 = ctl + PP_CTL_TILEFINAL + (long long)(s + 1) * 64 + (s + 1);
+        PpSpin sp;
+        for (;;) {
+            const pp_u64 f = lane == 0 ? pp_ld(f0) : (lane == 1 ? pp_ld(f1) : call_id);
+            if (__all(f == call_id)) break;
+            if (pp_give_up(sp, ctl, call_id, timeout)) { dead = true; break; }
+        }
+    }
+    if (!dead) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
+                    const long long gr = ri0 + lr, gc = base_n + lc;
+                    if (producer) {
+                        if (gr < n && gc < n && gc <= gr) cin[i][j][rr] = pp_ld_f64(A + gr * lda + gc);
+                    } else {
+                        if (gr < n) cin[i][j][rr] = pp_ld_f64(A + gr * lda + gc);                 // (gc < ri0 <= gr, gc < n)
+                        if (lc <= lr) cin2[i][j][rr] = pp_ld_f64(A + (base_n + lr) * lda + base_n + lc);   // (the block is full)
+                    }
+                }
+    }
+    ksteps(std::integral_constant<int, 12>{}, std::integral_constant<int, 16>{});
+    // hand-over: next tile -> the free parity of As ([64][66]) for wavefront 1, next diagonal block -> Ls
+    pp_lds_wait_ge(p.wocnt, 4 * s);                            // (every matrix wavefront has read L(r, s-1) out of it)
+    pp_lds_wait_ge(bprog, 16);                                 // (wavefront 3 too)
+    pp_lds_wait_ge(prog, PB + 1);                              // (wavefronts 0 / 2 are done with Ls; wavefront 1: xprog = 16 above)
+    double (*St)[PB + 2] = (double (*)[PB + 2])p.As_prev;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
+                const double c = cin[i][j][rr] - v[i][j][rr];
+                if (producer) Ls[lr][lc] = c;
+                else {
+                    St[lr][lc] = c;
+                    Ls[lr][lc] = cin2[i][j][rr] - v2[i][j][rr];
+                }
+            }
+    if (dead) lds_store_volatile(p.abl, 1);
+    }
+    PP_STEP_LOOP_END()
+}
+
+__device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, const unsigned lds_off) {
+    const PotrfArgs& a = q.a;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = (int)blockIdx.x;
+    double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
+    int* ints = (int*)(lds + PP_INTS);
+    const long long n = a.n, lda = a.lda;
+    if (t < 24) ints[t] = 0;
+    double rhs_r = 0.0;     // wavefront 3: running right-hand side of the forward solve for matrix row r * 64 + lane
+    if (w == 0) {
+        // block (0, 0), coalesced (lane = column), transposed to lane = row through Ls (n > 64: the block is full)
+        const double* src = a.A + lane;
+        double tt[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) tt[k] = src[(long long)k * lda];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) Ls[k][lane] = tt[k];
+    } else if (w == 3) {
+        const long long row = (long long)r * PB + lane;
+        rhs_r = (a.rhs && row < n) ? a.rhs[row] : 0.0;
+    }
+    if (q.debug == 1 && r == 0 && t == 0) pp_st(q.ctl + PP_CTL_ABORT, q.call_id);
+    __syncthreads();
+
+    PpKarg karg;
+    {
+        const unsigned long long kp = (unsigned long long)(size_t)__builtin_amdgcn_kernarg_segment_ptr();
+        karg.lo = (unsigned)kp; karg.hi = (unsigned)(kp >> 32);
+    }
+    if (w == 0) pp_role_factor(lds_off, karg);
+    else if (w == 1) pp_role_solve(lds_off, karg);
+    else if (w == 3) pp_role_recv(lds_off, karg, rhs_r);
+    else if (w >= 4) pp_role_matrix(lds_off, karg);
+    else {
+        PP_STEP_LOOP_BEGIN(lds)
+        const long long j0 = (long long)s_in * PB;
+        int* cnt = ints + 8 * (s_in & 1);
+        panel_helper_wave((int)((n - j0) < PB ? (n - j0) : PB), lane, Ls, cnt + 0, cnt + 1);
+        PP_STEP_LOOP_END()
+    }
+}
+
+// ---------------------------------------------------------------------------
+// update workgroup: block column s applied to the tiles (i, q), q >= s + 2, two tiles at a time
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds) {
+    const PotrfArgs& a = q.a;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = t >> 8, tid = t & 255;
+    const int nb = q.nb;
+    const int u = (int)blockIdx.x - nb, nupd = (int)gridDim.x - nb;
+    double* hl = lds + half * GEMM64_LDS_DOUBLES;
+    int* ints = (int*)(lds + PP_INTS);
+    const long long n = a.n, lda = a.lda;
+    const pp_u64 base = q.call_id << 8;
+    const int hw = w & 3;
+    const int wr = (hw >> 1) * 32, wc = (hw & 1) * 32;
+    const long long total = (long long)(nb - 1) * (nb - 2) / 2;          // tiles (i, q), 2 <= q <= i < nb, column-major index
+    for (int s = 0; s + 2 < nb; ++s) {
+        // every block row below s has L(:, s) in memory
+        if (w == 0) {
+            const int i = s + 1 + lane;
+            PpSpin sp;
+            int ok = 1;
+            for (;;) {
+                const bool have = i >= nb || pp_ld(q.ctl + PP_CTL_ROWDONE + i) >= (base | (pp_u64)(s + 1));
+                if (__all(have)) break;
+                if (pp_give_up(sp, q.ctl, q.call_id, q.timeout)) { ok = 0; break; }
+            }
+            if (lane == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // ONE acquire per update step: then plain, L2-served loads
+                ints[s & 1] = ok;
+            }
+        }
+        __syncthreads();
+        if (!ints[s & 1]) return;
+        const long long j0 = (long long)s * PB;
+        const long long F = (long long)s * nb - ((long long)(s + 1) * (s + 2) / 2 - 1);   // index of tile (s + 2, s + 2)
+        long long m = (F - 1 - 2 * u) <= 0 ? 0 : (F - 1 - 2 * u + 2 * nupd - 1) / (2 * nupd);
+        for (;; ++m) {
+            const long long pair = 2 * u + 2ll * nupd * m;
+            if (pair >= total) break;
+            const long long idx = pair + half;
+            const bool active = idx >= F && idx < total;
+            long long ti = 0, tq = 0;
+            if (active) {
+                long long rem = idx - F;
+                tq = s + 2;
+                while (rem >= nb - tq) { rem -= nb - tq; ++tq; }
+                ti = tq + rem;
+            }
+            const long long ri = ti * PB, rk = tq * PB;
+            double cin[2][2][4], v[2][2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
+                        const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, rr);
+                        cin[i][j][rr] = (active && gr < n && gc < n && gc <= gr) ? a.A[gr * lda + gc] : 0.0;
+                        v[i][j][rr] = 0.0;
+                    }
+            {
+                double none[2][2][4];
+                apgp_gemm64_tile2_t<false, false, false>(tid, a.A + ri * lda + j0, lda, active ? n - ri : 0, a.A + rk * lda + j0, lda,
+                                                         active ? n - rk : 0, 0, PB, hl, v, none);
+            }
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
+                            const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, rr);
+                            if (gr < n && gc < n && gc <= gr) pp_st_f64(a.A + gr * lda + gc, cin[i][j][rr] - v[i][j][rr]);
+                        }
+            }
+            pp_drain();
+            __syncthreads();
+            // column s + 2 now carries every block column the update workgroups owe it
+            if (active && tq == s + 2 && tid == 0) pp_st(q.ctl + PP_CTL_TILEFINAL + ti * 64 + tq, q.call_id);
+        }
+    }
+}
+
+__global__ __launch_bounds__(PP_THREADS) void potrf_persist_kernel(PersistArgs q) {
+    extern __shared__ __attribute__((aligned(16))) double pp_lds[];
+    if ((int)blockIdx.x < q.nb) pp_row_role(q, pp_lds, (unsigned)(size_t)(__attribute__((address_space(3))) double*)pp_lds);
+    else pp_update_role(q, pp_lds);
+}

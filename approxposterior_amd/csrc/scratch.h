@@ -1,12 +1,13 @@
 // Stream-ordered device scratch kept per (device, stream, slot) and grown on demand (hipMallocAsync /
 // hipFreeAsync): calls on one stream are serialised, so they can share a buffer; calls on different
 // streams cannot.  Slots: 0 = Cholesky (factored diagonal blocks), 1 = blocked triangular solve
-// (working right-hand side).  One definition for the whole library (inline functions, static locals).
+// (working right-hand side), 2 = persistent Cholesky (flags, granule streams).  One definition for the whole
+// library (inline functions, static locals).
 //   * The device is the STREAM's (hipStreamGetDevice), not the caller's current device.
 //   * Entries live until apgp_release_scratch(stream) (include/apgp.h) or process exit: call it before
 //     destroying a stream -- a recycled stream handle would otherwise inherit the dead stream's entry.
 //   * Growing allocates (hipMallocAsync): the entry points that use scratch -- apgp_potrf / apgp_nll_eval*
-//     for n > 64, apgp_trsv for n >= 768 -- must not be called during stream capture.
+//     for n > 64, apgp_trsv for n >= 256 -- must not be called during stream capture.
 //   * apgp_stream_lock(stream): one mutex per (device, stream).  The launches of one factorisation /
 //     blocked solve share the stream's scratch and are enqueued as a unit under it; calls on different
 //     streams or devices do not serialise each other (round 2 had one process-wide mutex).
@@ -28,7 +29,7 @@ struct ApgpMailbox {
 };
 
 struct ApgpScratchTable {
-    struct Scr { double* p = nullptr; size_t doubles = 0; };
+    struct Scr { double* p = nullptr; size_t doubles = 0; unsigned long long calls = 0; };
     std::mutex mu;
     std::map<std::tuple<int, hipStream_t, int>, Scr> tab;
     std::map<std::pair<int, hipStream_t>, ApgpMailbox> mail;
@@ -45,12 +46,15 @@ inline int apgp_stream_device(hipStream_t s) {
     return dev;
 }
 
-inline double* apgp_stream_scratch(int slot, hipStream_t s, size_t doubles) {
+// *fresh (optional): the buffer was (re)allocated by this call -- its contents are undefined.
+// *calls (optional): a counter that lives with the entry (the persistent Cholesky's call-unique flag values).
+inline double* apgp_stream_scratch_ex(int slot, hipStream_t s, size_t doubles, bool* fresh, unsigned long long** calls) {
     ApgpScratchTable& t = apgp_scratch_table();
     const int dev = apgp_stream_device(s);
     if (dev < 0) return nullptr;
     std::lock_guard<std::mutex> lock(t.mu);
     ApgpScratchTable::Scr& e = t.tab[std::make_tuple(dev, s, slot)];
+    if (fresh) *fresh = false;
     if (e.doubles < doubles) {
         if (e.p) (void)hipFreeAsync(e.p, s);
         e.p = nullptr; e.doubles = 0;
@@ -58,8 +62,13 @@ inline double* apgp_stream_scratch(int slot, hipStream_t s, size_t doubles) {
         double* p = nullptr;
         if (hipMallocAsync((void**)&p, want * sizeof(double), s) != hipSuccess) return nullptr;
         e.p = p; e.doubles = want;
+        if (fresh) *fresh = true;
     }
+    if (calls) *calls = &e.calls;     // (std::map nodes are stable; the caller holds apgp_stream_lock(s))
     return e.p;
+}
+inline double* apgp_stream_scratch(int slot, hipStream_t s, size_t doubles) {
+    return apgp_stream_scratch_ex(slot, s, doubles, nullptr, nullptr);
 }
 
 inline std::mutex& apgp_stream_lock(hipStream_t s) {

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define APGP_ABI_VERSION 5
+#define APGP_ABI_VERSION 6
 #define APGP_MAX_DIM 16          /* feature dimension D supported by the kernels */
 #define APGP_ROW_BLOCK 512       /* rows per packed L^-1 row block (sweep tile)  */
 #define APGP_K_CHUNK 16          /* contraction depth per packed tile            */
@@ -130,7 +130,7 @@ int apgp_fit_summary(const double* L, int64_t n, int64_t ldl, const double* z,
                      const int32_t* info_dev, double* out5, void* stream);
 
 /* ---- stream scratch ------------------------------------------------------------
- * apgp_potrf / apgp_nll_eval* (n > 64) and apgp_trsv (n >= 768) keep stream-ordered
+ * apgp_potrf / apgp_nll_eval* (n > 64) and apgp_trsv (n >= 256) keep stream-ordered
  * device scratch per (device of the stream, stream), grown with hipMallocAsync -- so
  * they must not be called while the stream is being captured into a graph.
  * apgp_release_scratch frees (stream-ordered) what `stream` holds and returns the
@@ -146,13 +146,30 @@ int apgp_release_scratch(void* stream);
  * (device, stream): the last kernel's last lane writes it and a sequence word, the host
  * polls the word (400 us, then an ordinary stream synchronisation) -- no D2H copy; if
  * pinned memory is unavailable the call falls back to copy + synchronisation.
- * K: n x n work (holds the factor on return), z: n, info_dev / out5_dev: device scratch
- * (both written as before).  Status as the parts'; a non-PD matrix is reported in
- * out5_host[4] (> 0), not in the status.                                              */
+ * K: n x n work (holds the factor once the stream has passed the call's work), z: n,
+ * info_dev / out5_dev: device scratch (both written as before).  Only the 5-value record in
+ * out5_host is host-visible when the call returns: the host stops polling as soon as the
+ * record lands, which may be before the posting kernel has finished -- K, z, *info_dev and
+ * out5_dev are STREAM-ordered (read them from work enqueued on `stream`, or after
+ * synchronising it), not host- or other-stream-visible on return.
+ * Status as the parts'; a non-PD matrix is reported in out5_host[4] (> 0), not in the status.
+ * 64 < n <= 4096: the Cholesky is ONE persistent launch (csrc/potrf_persist.h: row workgroups
+ * chained by in-launch hand-offs instead of a launch per 64-column step; bit-identical to the
+ * multi-launch path).  All of its workgroups must be resident at once; if they are not within
+ * 50 ms (a foreign kernel holds compute units) the launch gives up and the call transparently
+ * re-runs the evaluation on the multi-launch path (counted by apgp_potrf_fallbacks).      */
 int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
                   const double* y, double mean, double* K, double* z,
                   int32_t* info_dev, double* out5_dev, double* out5_host /*host*/,
                   void* stream);
+
+/* Test / profiling switch for the Cholesky inside apgp_nll_eval (not read from the
+ * environment): 0 = persistent launch where it applies (default), 1 = multi-launch path
+ * only, 2 = persistent launch that gives up at once (exercises the fallback).  mode < 0
+ * only queries.  Returns the previous mode (-1: bad argument).
+ * apgp_potrf_fallbacks: evaluations re-run on the multi-launch path so far (process-wide). */
+int apgp_potrf_mode(int mode);
+int64_t apgp_potrf_fallbacks(void);
 
 /* ---- `batch` _nll evaluations at different hyper-parameters, one call ----------
  * (the restarts of gpUtils.optimizeGP, gpUtils.py:223-247,
@@ -170,7 +187,7 @@ int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch,
  * Replaces BasicSolver.apply_inverse / dot_solve on a vector (scipy cho_solve;
  * george GP.log_likelihood and _compute_alpha; gpUtils.py:78, utility.py:131).
  * trans = 0: solve L x = (b - shift); trans = 1: solve L^T x = (b - shift).
- * If sumsq != NULL, *sumsq = x.x (device scalar).  x may alias b.  From n = 768 the solve runs
+ * If sumsq != NULL, *sumsq = x.x (device scalar).  x may alias b.  From n = 256 the solve runs
  * as one small launch per 64-row block with n doubles of stream-ordered scratch kept by the
  * library per (device, stream) (hipMallocAsync); below that one workgroup, right-hand side in LDS. */
 int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,

@@ -1,0 +1,274 @@
+// Hand-off probe for the persistent Cholesky / triangular solve (round 4): measures, on the real chip, the two
+// in-launch hand-off forms those kernels use, with every received word checked and consumers L1-warm:
+//   A  "granule stream": ONE producer wavefront publishes 2 KB groups (64 lanes x 4 doubles) as data-tagged
+//      16-byte sc1 stores ({lo, tag, hi, tag} per double: no flag, no fence, no wait on the producer),
+//      every other workgroup's loader wavefront polls the 4 KB with 16-byte sc1 loads until all tags match;
+//   B  "tile + flag": a 256-thread producer stores a 32 KB tile with 16-byte sc1 stores, drains
+//      (s_waitcnt vmcnt(0)), barrier, one relaxed agent-scope flag store; consumers poll the flag from one lane
+//      and read the tile with sc1 loads (variant 0) or after ONE agent acquire with plain loads (variant 1).
+// Latencies are s_memrealtime (100 MHz) differences publish -> fully received, per consumer.
+// Build: hipcc --offload-arch=gfx950 -O3 -o handoff_probe handoff_probe.hip ; run: ./handoff_probe [nwg] [bg]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ u64 now() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void spin_ticks(u64 t) { const u64 t0 = now(); while (now() - t0 < t) __builtin_amdgcn_s_sleep(1); }
+__device__ __forceinline__ double val(unsigned tag, int s, int g, int lane, int k) {
+    return (double)tag * 1.0e6 + (double)s * 4096.0 + (double)g * 256.0 + (double)lane * 4.0 + (double)k + 0.125;
+}
+__device__ __forceinline__ void st16_sc1(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");   /* s_nop: hipcc does not pad the store-data hazard of an asm x4 store */ }
+__device__ __forceinline__ u32x4 ld16_sc1(const void* p) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+
+#define NG 16
+#define TIMEOUT_TICKS 400000ull   // 4 ms
+
+// ---------------- A: granule stream ----------------
+// G: [S][NG][64 lanes][4 doubles] x 16 B
+__global__ __launch_bounds__(256) void stream_probe(u32x4* G, unsigned tag, u64* t_pub, u64* t_arr, unsigned* err, int S,
+                                                    u64 gap_ticks, double* bg, long long bg_len, int ncons, int mode) {
+    const int wg = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (wg > ncons) {
+        // background load: stream a buffer (plain 16-byte loads/stores) until the stop word is set
+        f64x2* b = (f64x2*)bg;
+        f64x2 acc = {0.0, 0.0};
+        for (int rep = 0; rep < 64; ++rep) {
+            for (long long i = (long long)(wg - ncons - 1) * 256 + t; i < bg_len / 2; i += (long long)(gridDim.x - ncons - 1) * 256) {
+                f64x2 v = b[i];
+                acc += v;
+            }
+            if (__hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        }
+        if (acc.x == 123.456) bg[0] = acc.y;
+        return;
+    }
+    if (w != 0) return;
+    if (wg == 0) {
+        for (int s = 0; s < S; ++s)
+            for (int g = 0; g < NG; ++g) {
+                spin_ticks(gap_ticks);
+                u32x4* dst = G + (((long long)s * NG + g) * 64 + lane) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double d = val(tag, s, g, lane, k);
+                    const unsigned lo = (unsigned)__double2loint(d), hi = (unsigned)__double2hiint(d);
+                    st16_sc1(dst + k, (u32x4){lo, tag, hi, tag});
+                }
+                if (lane == 0) t_pub[s * NG + g] = now();
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stop the background
+        return;
+    }
+    // consumer: L1-warm first (plain loads of everything it will later poll)
+    if (mode & 1) {
+        unsigned acc = 0;
+        for (long long i = lane; i < (long long)S * NG * 64 * 4; i += 64) acc += G[i].y;
+        if (acc == 0xdeadbeefu) err[2] = acc;
+    }
+    const int flav = mode >> 1;
+    unsigned bad = 0;
+    for (int s = 0; s < S && !(bad & 0x80000000u); ++s)
+        for (int g = 0; g < NG; ++g) {
+            const u32x4* src = G + (((long long)s * NG + g) * 64 + lane) * 4;
+            u32x4 v[4];
+            const u64 t0 = now();
+            bool timeout = false;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (flav == 0) v[k] = ld16_sc1(src + k);
+                    else if (flav == 1) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v[k]) : "v"(src + k) : "memory");
+                    else if (flav == 2) {
+                        const u64 a = __hip_atomic_load((const u64*)(src + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const u64 b = __hip_atomic_load((const u64*)(src + k) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v[k] = (u32x4){(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+                    } else {
+                        if (k == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        v[k] = *(const volatile u32x4*)(src + k);
+                    }
+                    ok = ok && v[k].y == tag && v[k].w == tag;
+                }
+                if (__all(ok)) break;
+                if (now() - t0 > TIMEOUT_TICKS) { timeout = true; if (wg == 1) { bg[8 + lane * 4 + 0] = (double)v[0].x; bg[8 + lane * 4 + 1] = (double)v[0].y; bg[8 + lane * 4 + 2] = (double)v[3].z; bg[8 + lane * 4 + 3] = (double)v[3].w; bg[7] = (double)tag; bg[6] = (double)(s * 100 + g);}
+                    for (int k = 0; k < 4; ++k) { const u64 by = __ballot(v[k].y == tag), bw = __ballot(v[k].w == tag); if (wg == 1 && lane == 0) { ((u64*)bg)[300 + 2 * k] = by; ((u64*)bg)[301 + 2 * k] = bw; } } break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) t_arr[((long long)(wg - 1) * S + s) * NG + g] = now();
+            if (timeout) { bad |= 0x80000000u; break; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double d = __hiloint2double((int)v[k].z, (int)v[k].x);
+                if (d != val(tag, s, g, lane, k)) ++bad;
+            }
+        }
+    if (bad & 0x80000000u) { if (lane == 0) atomicAdd(err + 3, 1u); }
+    else if (bad) atomicAdd(err, bad);
+}
+
+// ---------------- B: 32 KB tile + flag ----------------
+// T: [S][2048] x 16 B ; flag: [S] u64
+__global__ __launch_bounds__(256) void tile_probe(u32x4* T, u64* flag, unsigned tag, u64* t_pub, u64* t_arr, unsigned* err, int S,
+                                                  u64 gap_ticks, int variant) {
+    const int wg = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    __shared__ int stop;
+    if (wg == 0) {
+        for (int s = 0; s < S; ++s) {
+            spin_ticks(gap_ticks);
+            __syncthreads();
+            u32x4* dst = T + (long long)s * 2048;
+            const u64 ta = now();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = k * 256 + t;
+                const double d0 = val(tag, s, e >> 6, e & 63, 0), d1 = val(tag, s, e >> 6, e & 63, 1);
+                st16_sc1(dst + e, (u32x4){(unsigned)__double2loint(d0), (unsigned)__double2hiint(d0), (unsigned)__double2loint(d1), (unsigned)__double2hiint(d1)});
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                __hip_atomic_store(flag + s, (u64)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t_pub[s] = now();
+                t_pub[S + s] = ta;           // start of the publish
+            }
+        }
+        return;
+    }
+    {
+        unsigned acc = 0;
+        for (long long i = t; i < (long long)S * 2048; i += 256) acc += T[i].y;
+        if (acc == 0xdeadbeefu) err[2] = acc;
+    }
+    __syncthreads();
+    unsigned bad = 0;
+    for (int s = 0; s < S; ++s) {
+        if (t == 0) {
+            const u64 t0 = now();
+            int st = 0;
+            while (__hip_atomic_load(flag + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (u64)tag) {
+                if (now() - t0 > TIMEOUT_TICKS) { st = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (variant == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            stop = st;
+        }
+        __syncthreads();
+        if (stop) { if (t == 0) atomicAdd(err + 3, 1u); bad = 0; break; }
+        const u32x4* src = T + (long long)s * 2048;
+        u32x4 v[8];
+        if (variant == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(src + k * 256 + t) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[k * 256 + t];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = k * 256 + t;
+            const double d0 = __hiloint2double((int)v[k].y, (int)v[k].x), d1 = __hiloint2double((int)v[k].w, (int)v[k].z);
+            if (d0 != val(tag, s, e >> 6, e & 63, 0)) ++bad;
+            if (d1 != val(tag, s, e >> 6, e & 63, 1)) ++bad;
+        }
+        __syncthreads();
+        if (t == 0) t_arr[(long long)(wg - 1) * S + s] = now();
+    }
+    if (bad) atomicAdd(err, bad);
+    (void)lane;
+}
+
+static void stats(const char* name, std::vector<double>& v) {
+    if (v.empty()) { printf("%s: no samples\n", name); return; }
+    std::sort(v.begin(), v.end());
+    printf("%s: n=%zu min %.2f  p10 %.2f  median %.2f  p90 %.2f  max %.2f us\n", name, v.size(), v.front(), v[v.size() / 10],
+           v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+}
+
+int main(int argc, char** argv) {
+    const int ncons = argc > 1 ? atoi(argv[1]) : 63;
+    const int nbg = argc > 2 ? atoi(argv[2]) : 0;
+    const int S = 24;
+    u32x4* G; u64 *t_pub, *t_arr, *flag; unsigned* err; double* bg;
+    const long long bg_len = 64ll << 20;   // 512 MB of doubles
+    CK(hipMalloc(&G, sizeof(u32x4) * S * NG * 64 * 4));
+    CK(hipMemset(G, 0, sizeof(u32x4) * S * NG * 64 * 4));
+    CK(hipMalloc(&t_pub, sizeof(u64) * S * NG * 2));
+    CK(hipMalloc(&t_arr, sizeof(u64) * (size_t)ncons * S * NG));
+    CK(hipMalloc(&err, 16));
+    CK(hipMalloc(&flag, sizeof(u64) * S));
+    CK(hipMemset(flag, 0, sizeof(u64) * S));
+    CK(hipMalloc(&bg, sizeof(double) * bg_len));
+    CK(hipMemset(bg, 0, sizeof(double) * bg_len));
+    std::vector<u64> hp(S * NG * 2), ha((size_t)ncons * S * NG);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int bgw = pass == 0 ? 0 : nbg;
+        if (pass == 1 && nbg == 0) break;
+        for (int mode = 0; mode < 8; ++mode)
+        for (u64 gap : {80ull}) {
+            std::vector<double> all, last;
+            unsigned herr_total = 0, tmo_total = 0;
+            for (unsigned tag = 1; tag <= 6; ++tag) {
+                CK(hipMemset(err, 0, 16));
+                hipLaunchKernelGGL(stream_probe, dim3(1 + ncons + bgw), dim3(256), 0, 0, G, tag + 10 * (unsigned)mode + 1000 * pass + 100, t_pub, t_arr, err, S, gap, bg, bg_len, ncons, mode);
+                CK(hipDeviceSynchronize());
+                unsigned herr[4];
+                CK(hipMemcpy(herr, err, 16, hipMemcpyDeviceToHost));
+                herr_total += herr[0]; tmo_total += herr[3];
+                if (herr[3] && tag == 2 && mode == 0) { double dbg[8 + 256]; CK(hipMemcpy(dbg, bg, sizeof(dbg), hipMemcpyDeviceToHost));
+                    printf("  dbg: at %g expected tag %g; lanes 0,1,63 saw x,y | z,w of k=3: ", dbg[6], dbg[7]);
+                    for (int l : {0, 1, 63}) printf("[%g %g | %g %g] ", dbg[8 + 4 * l], dbg[8 + 4 * l + 1], dbg[8 + 4 * l + 2], dbg[8 + 4 * l + 3]); printf("\n");
+                    u64 bl[8]; CK(hipMemcpy(bl, (u64*)bg + 300, sizeof(bl), hipMemcpyDeviceToHost)); for (int k = 0; k < 4; ++k) printf("  k=%d ballots y %016llx w %016llx\n", k, bl[2 * k], bl[2 * k + 1]); }
+                CK(hipMemcpy(hp.data(), t_pub, sizeof(u64) * S * NG, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(ha.data(), t_arr, sizeof(u64) * (size_t)ncons * S * NG, hipMemcpyDeviceToHost));
+                if (tag == 1 || herr[3]) continue;   // first launch: cold
+                for (int c = 0; c < ncons; ++c)
+                    for (int s = 0; s < S; ++s)
+                        for (int g = 0; g < NG; ++g) {
+                            const double us = ((double)ha[((size_t)c * S + s) * NG + g] - (double)hp[s * NG + g]) * 0.01;
+                            all.push_back(us);
+                            if (g == NG - 1) last.push_back(us);
+                        }
+            }
+            printf("A stream  consumers=%d background=%d gap=%.1fus preread=%d poll=%s wrong-values=%u timed-out-consumers=%u\n", ncons, bgw, gap * 0.01, mode & 1,
+                   (mode >> 1) == 0 ? "16B sc1" : (mode >> 1) == 1 ? "16B sc0 sc1" : (mode >> 1) == 2 ? "8B agent atomics" : "acquire + plain 16B", herr_total, tmo_total);
+            stats("   every group", all);
+            stats("   last group of a step", last);
+        }
+        for (int variant = 0; variant < 2; ++variant) {
+            std::vector<double> all, pubt;
+            unsigned herr_total = 0, tmo_total = 0;
+            for (unsigned tag = 1; tag <= 6; ++tag) {
+                CK(hipMemset(err, 0, 16));
+                hipLaunchKernelGGL(tile_probe, dim3(1 + ncons), dim3(256), 0, 0, (u32x4*)bg, flag, tag + 100 * variant + 1000 * pass, t_pub, t_arr, err, S, 1500ull, variant);
+                CK(hipDeviceSynchronize());
+                unsigned herr[4];
+                CK(hipMemcpy(herr, err, 16, hipMemcpyDeviceToHost));
+                herr_total += herr[0]; tmo_total += herr[3];
+                CK(hipMemcpy(hp.data(), t_pub, sizeof(u64) * S * 2, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(ha.data(), t_arr, sizeof(u64) * (size_t)ncons * S, hipMemcpyDeviceToHost));
+                if (tag == 1) continue;
+                for (int s = 0; s < S; ++s) pubt.push_back(((double)hp[s] - (double)hp[S + s]) * 0.01);
+                for (int c = 0; c < ncons; ++c)
+                    for (int s = 0; s < S; ++s) all.push_back(((double)ha[(size_t)c * S + s] - (double)hp[s]) * 0.01);
+            }
+            printf("B tile+flag variant=%s consumers=%d wrong-values=%u timed-out=%u\n", variant ? "acquire+plain" : "sc1 loads", ncons, herr_total, tmo_total);
+            stats("   publish (stores + drain + flag)", pubt);
+            stats("   flag stored -> tile received", all);
+        }
+    }
+    return 0;
+}
