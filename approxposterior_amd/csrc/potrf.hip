@@ -819,12 +819,13 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
 // host side of the persistent factorisation
 // ---------------------------------------------------------------------------
 // 0 = persistent where it applies (default) | 1 = multi-launch path only | 2 = persistent, workgroup 0 gives up at
-// once (exercises the fallback).  A test / profiling switch (apgp_potrf_mode), not read from the environment.
+// once (exercises the fallback) | 3 = persistent wherever it can run (n <= 4096).  A test / profiling switch
+// (apgp_potrf_mode), not read from the environment.
 static std::atomic<int> g_potrf_mode{0};
 static std::atomic<long long> g_potrf_fallbacks{0};
 extern "C" int apgp_potrf_mode(int mode) {
     if (mode < 0) return g_potrf_mode.load();
-    if (mode > 2) { apgp_set_error("apgp_potrf_mode: bad argument: mode 0 .. 2"); return -1; }
+    if (mode > 3) { apgp_set_error("apgp_potrf_mode: bad argument: mode 0 .. 3"); return -1; }
     return g_potrf_mode.exchange(mode);
 }
 extern "C" int64_t apgp_potrf_fallbacks(void) { return g_potrf_fallbacks.load(); }
@@ -847,7 +848,11 @@ static int potrf_device_cus(int dev) {
 static bool potrf_persist_applies(int64_t n, int64_t lda, hipStream_t s) {
     if (g_potrf_mode.load() == 1) return false;
     const int64_t nb = (n + PB - 1) / PB;
+    // (measured, apgp_nll_eval: 0.177 vs 0.208 ms at n = 512, 0.406 vs 0.470 at 1152, 0.782 vs 0.887 at 2048, but 2.08 vs
+    // 1.99 at 4096, where the trailing update's throughput decides and the multi-launch path keeps all 256 CUs on it:
+    // mode 0 takes the persistent launch up to PP_AUTO_NB block columns; mode 3 forces it wherever it can run)
     if (nb < 2 || nb > PP_MAX_NB) return false;
+    if (nb > PP_AUTO_NB && g_potrf_mode.load() != 3) return false;
     if (lda * n * 8 >= (1ll << 31)) return false;
     return potrf_device_cus(apgp_stream_device(s)) >= nb + 1;
 }
@@ -895,8 +900,8 @@ static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, in
             attr_set[dev] = true;
         }
     }
-    const long long tiles0 = (nb - 1) * (nb - 2) / 2;                   // tiles of the first update step
-    long long nupd = (tiles0 + 1) / 2;
+    const long long tiles0 = (nb - 1) * (nb - 2) / 2;                   // tiles of the first update step: one per workgroup
+    long long nupd = tiles0;
     const long long room = potrf_device_cus(dev) - nb;
     if (nupd > room) nupd = room;
     if (nupd < 1) nupd = 1;

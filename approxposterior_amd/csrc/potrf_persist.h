@@ -44,6 +44,7 @@ typedef unsigned long long pp_u64;
 typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
 
 #define PP_MAX_NB 64
+#define PP_AUTO_NB 40                                // block columns up to which the persistent launch is the default
 #define PP_THREADS 512
 #define PP_CHUNK (64 * 18)                        // a 16-column chunk of a 64-row tile, rows padded to 18 (apgp_gemm64_tile's)
 // LDS map of a row workgroup (doubles)
@@ -55,10 +56,13 @@ typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
 #define PP_ZROW (PP_ZBLK + 64)
 #define PP_ZST (PP_ZROW + 64)
 #define PP_INTS (PP_ZST + 64)                     // 2 x 8 step-parity counters + 8 others
-#define PP_LDS_DOUBLES (PP_INTS + 12)
+#define PP_LDS_DOUBLES (160 * 1024 / 8)
 #define PP_LDS_BYTES (PP_LDS_DOUBLES * 8)
-static_assert(PP_LDS_BYTES <= 160 * 1024, "one row workgroup per CU");
-static_assert(2 * GEMM64_LDS_DOUBLES <= PP_INTS, "update role: two tile buffers below the counters");
+static_assert(PP_INTS + 12 <= PP_LDS_DOUBLES, "one row workgroup per CU");
+// update role: two buffers (current / next tile) of the two whole operand tiles of a product (chunk layout), counters
+#define PP_UPD_HALF (2 * 4 * PP_CHUNK)
+#define PP_UPD_INTS (2 * PP_UPD_HALF)
+static_assert(PP_UPD_INTS + 4 <= PP_LDS_DOUBLES, "update role: two buffers of two whole tiles + counters");
 static_assert(64 * 66 <= 4 * PP_CHUNK, "the handed-over tile fits one parity of As");
 // control block (pp_u64 words) in the stream's scratch
 #define PP_CTL_ABORT 0
@@ -69,6 +73,28 @@ static_assert(64 * 66 <= 4 * PP_CHUNK, "the handed-over tile fits one parity of 
 #define PP_ZSTRM_WORDS ((long long)PP_MAX_NB * 64 * 2)       // [step][lane][2 granules]
 #define PP_SCRATCH_WORDS (PP_CTL_WORDS + PP_STRM_WORDS + PP_ZSTRM_WORDS)
 #define PP_ABORTED (-7777.0)                      // out5[4] of an aborted call
+
+// -DPP_STAMPS (tools/persist_stamps.py builds its own copy of the library with it): 100 MHz wall-clock stamps of
+// the LAST row workgroup, per step -- 0 step start | 1 factor done | 2 solve done | 3 last group received |
+// 4 k-step 15 done | 5 tile values requested (flags seen) | 6 hand-over written | 7 z applied | 8 L(r, s-1) stored |
+// 9 k-step 5 done | 10 first group received | 11 k-step 0 done | 12-14 k-steps 12-14 done | 15 group 14 received
+#ifdef PP_STAMPS
+__device__ unsigned long long pp_stamps[64 * 24];
+#define PP_STAMP(s_, i_) do { if ((int)blockIdx.x == q->nb - 1 && (threadIdx.x & 63) == 0) pp_stamps[(s_) * 24 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int apgp_debug_read_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_stamps), sizeof(unsigned long long) * 64 * 24) == hipSuccess ? 0 : -2;
+}
+// the update half-workgroup that owns tile (s + 2, s + 2), per update step: 0 rows seen | 1 acquired | 2 first tile pair: operands in LDS | 3 products done |
+// 4 stored and drained | 5 step done
+__device__ unsigned long long pp_ustamps[64 * 8];
+#define PP_USTAMP(s_, i_) do { if (((i_) >= 2 && (i_) <= 4) ? (ustamp_me && (threadIdx.x & 255) == 0) : (ustamp_wg && threadIdx.x == 0)) pp_ustamps[(s_) * 8 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int apgp_debug_read_ustamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_ustamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -2;
+}
+#else
+#define PP_STAMP(s_, i_) do { } while (0)
+#define PP_USTAMP(s_, i_) do { } while (0)
+#endif
 
 struct PersistArgs {
     PotrfArgs a;
@@ -100,16 +126,20 @@ __device__ __forceinline__ bool pp_give_up(PpSpin& sp, pp_u64* ctl, const pp_u64
     return false;
 }
 __device__ __forceinline__ void pp_lds_wait_ge(const int* p, int need) {
+#ifdef PP_EXP_SLOWPOLL   // (timing experiment: the matrix wavefronts poll eight times less often)
+    { unsigned guard_ = 0; while (lds_load_volatile(p) < need) { __builtin_amdgcn_s_sleep(8); if (++guard_ > (1u << 18)) break; } }
+#else
     PANEL_SPIN_WHILE(lds_load_volatile(p) < need);
+#endif
     PANEL_FENCE();
 }
 
-// wavefront 1 of a row workgroup: panel_solve_wave with every solved 4-column group published at once -- to As
-// (this workgroup's A operand, chunk layout) and, in the workgroup whose rows are everybody's B operand, to the
-// granule stream.  The rows themselves go to memory from As at the start of the next step (matrix wavefronts).
+// wavefront 1 of a row workgroup: panel_solve_wave with every solved 4-column group published at once to As (this
+// workgroup's A operand, chunk layout).  In the workgroup whose rows are everybody's B operand wavefront 3 forwards
+// the groups from there to the granule stream (the stores would cost the solving wavefront ~1 us per step, and its
+// groups pace everybody).  The rows themselves go to memory from As at the start of the next step (matrix wavefronts).
 __device__ __forceinline__ void pp_solve_wave(const int lane, double (&x)[PB], const double (*Ls)[PB + 2], const double* invd,
-                                              int* prog_p, double* As_par, int* xprog_p, const bool stream,
-                                              const __amdgpu_buffer_rsrc_t rs_strm, const unsigned strm_off, const unsigned tag) {
+                                              int* prog_p, double* As_par, int* xprog_p) {
     static_for<PB / CB>([&](auto cc_) {
         constexpr int cc = decltype(cc_)::value, c0 = CB * cc;
         pp_lds_wait_ge(prog_p, c0 + CB);                 // columns c0 .. c0 + CB - 1 of L_jj published
@@ -136,13 +166,6 @@ __device__ __forceinline__ void pp_solve_wave(const int lane, double (&x)[PB], c
             *(f64x2*)(dst + 2) = (f64x2){xs[2], xs[3]};
             lds_store_volatile(xprog_p, cc + 1);         // (same wavefront: LDS stores stay in order)
         }
-        if (stream) {
-#pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                const pp_u32x4 g = {(unsigned)__double2loint(xs[k]), tag, (unsigned)__double2hiint(xs[k]), tag};
-                __builtin_amdgcn_raw_buffer_store_b128(g, rs_strm, (unsigned)(lane * 64 + k * 16), strm_off + (unsigned)(cc * 4096), 16);
-            }
-        }
         PANEL_FENCE();
         panel_trailing<c0, c0 + CB, PB, 0, PB>(x, xs, Ls);
     });
@@ -154,6 +177,9 @@ __device__ __forceinline__ void pp_solve_wave(const int lane, double (&x)[PB], c
 template <bool TWO>
 __device__ __forceinline__ void pp_kstep(const double* Ach, const double* Bch, const int ks, const int lane, const int wr, const int wc,
                                          const int (&bcol)[4], double (&acc)[2][2][4], double (&acc2)[2][2][4]) {
+#ifdef PP_EXP_NOMFMA     // (timing experiment: no products)
+    return;
+#endif
     double af[2], bf[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) af[i] = Ach[(wr + 16 * i + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
@@ -213,7 +239,7 @@ struct PpStep {            // what every role derives from (r, s)
     int r, s, bs;
     long long j0;
     bool producer;
-    int* cnt;              // this step's counters: 0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag
+    int* cnt;              // this step's counters: 0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 aprev-free
     int* wocnt;
     int* abl;
     double* As_cur;
@@ -227,7 +253,7 @@ __device__ __forceinline__ PpStep pp_step(double* lds, int s_in, long long n) {
     p.bs = (int)((n - p.j0) < PB ? (n - p.j0) : PB);
     p.producer = p.r == p.s + 1;                               // this workgroup's rows are the B operand of the step
     int* ints = (int*)(lds + PP_INTS);
-    // step-parity counters: [par][0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag]; others: 16 wocnt | 17, 18 "give up" by
+    // step-parity counters: [par][0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 aprev-free]; others: 16 wocnt | 17, 18 "give up" by
     // step parity (set during step s, read at the head of step s + 1: never while it may still be written)
     p.cnt = ints + 8 * (p.s & 1);
     p.wocnt = ints + 16;
@@ -243,11 +269,12 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     double* lds = pp_lds_base(lds_off);
     const int lane = threadIdx.x & 63;
     const long long n = q->a.n;
+    __builtin_amdgcn_s_setprio(3);         // (shares its SIMD with a matrix wavefront: the critical path goes first)
     PP_STEP_LOOP_BEGIN(lds)
     const PpStep p = pp_step(lds, s_in, n);
     if (lane == 0) {
         int* nx = (int*)(lds + PP_INTS) + 8 * ((s_in + 1) & 1);   // the next step's counters (nobody uses them before the barrier)
-        nx[0] = 0; nx[1] = 0; nx[2] = 0; nx[3] = 0; nx[4] = 0;
+        nx[0] = 0; nx[1] = 0; nx[2] = 0; nx[3] = 0; nx[4] = 0; nx[5] = 0; nx[6] = 0;
     }
     double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
     double* invd = lds + PP_INVD;
@@ -255,6 +282,7 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     const double* zrow = lds + PP_ZROW;
     const int bs = p.bs, s = p.s, r = p.r;
     double rowv[PB];                                           // row `lane` of the diagonal block
+    PP_STAMP(s, 0);
 #pragma unroll
     for (int k = 0; k < PB; k += 2) {
         const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
@@ -266,6 +294,7 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     pa.n = n; pa.lda = q->a.lda; pa.j0 = p.j0; pa.shift = 0.0; pa.info = q->a.info; pa.out5 = nullptr; pa.mail = nullptr; pa.seq = 0;
     pa.dscr = q->a.dscr; pa.batch_dscr = 0; pa.zoff = q->a.zoff; pa.batch_A = 0; pa.batch_rhs = 0; pa.abort_word = nullptr; pa.abort_id = 0;
     panel_factor_wave(pa, p.j0, bs, lane, rowv, 0.0, Ls, invd, zblk, p.cnt + 0, p.cnt + 1, r == s ? 0 : PB, 1);
+    PP_STAMP(s, 1);
     if (r == s && q->a.rhs) {
         // z_s = L_ss^-1 (rhs block s): the operations of the pass that rides along in panel_factor_wave, in its
         // order, on the finished factor (Ls, invd) -- the 4 x 4 blocks of Ls ARE its d[][] bit for bit
@@ -313,6 +342,7 @@ __device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
     double* lds = pp_lds_base(lds_off);
     const int lane = threadIdx.x & 63;
     const long long n = q->a.n, lda = q->a.lda;
+    __builtin_amdgcn_s_setprio(3);
     PP_STEP_LOOP_BEGIN(lds)
     const PpStep p = pp_step(lds, s_in, n);
     if (p.r > p.s) {
@@ -334,9 +364,8 @@ __device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
         }
         PANEL_FENCE();
     }
-    const __amdgpu_buffer_rsrc_t rs_strm = __builtin_amdgcn_make_buffer_rsrc((void*)q->strm, 0, (int)(PP_STRM_WORDS * 8), 0x00020000);
-    pp_solve_wave(lane, rowv, Ls, lds + PP_INVD, p.cnt + 0, p.As_cur, p.cnt + 2, p.producer, rs_strm, (unsigned)(p.s * 16 * 4096),
-                  (unsigned)q->call_id);
+    pp_solve_wave(lane, rowv, Ls, lds + PP_INVD, p.cnt + 0, p.As_cur, p.cnt + 2);
+    PP_STAMP(p.s, 2);
     }
     PP_STEP_LOOP_END()
 }
@@ -361,6 +390,12 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
     int* bprog = p.cnt + 3;
     int* zflag = p.cnt + 4;
     bool dead = false;
+    if (s >= 1) {
+        // L(r, s-1) went to memory at the end of the previous step (below): drained by now -- publish it
+        pp_drain();
+        if (lane == 0) pp_st(ctl + PP_CTL_ROWDONE + r, (call_id << 8) | (pp_u64)s);
+        PP_STAMP(s, 8);
+    }
     if (q->a.rhs && s >= 1) {
         const pp_u64* src = q->zstrm + ((long long)(s - 1) * 64 + lane) * 2;
         pp_u64 g0, g1;
@@ -383,6 +418,7 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
             }
             if (has_row) rhs_r -= d0 + d1;
         }
+        PP_STAMP(s, 7);
     }
     if (!dead && r == s) {
         zrow[lane] = rhs_r;
@@ -405,6 +441,25 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
             *(f64x2*)dst = (f64x2){__hiloint2double((int)(unsigned)g[1], (int)(unsigned)g[0]), __hiloint2double((int)(unsigned)g[3], (int)(unsigned)g[2])};
             *(f64x2*)(dst + 2) = (f64x2){__hiloint2double((int)(unsigned)g[5], (int)(unsigned)g[4]), __hiloint2double((int)(unsigned)g[7], (int)(unsigned)g[6])};
             lds_store_volatile(bprog, cc + 1);
+            if (cc == 0) PP_STAMP(s, 10);
+            if (cc == 14) PP_STAMP(s, 15);
+        });
+        PP_STAMP(s, 3);
+    }
+    else if (!dead && p.producer) {
+        // this workgroup's rows are the step's B operand: every group wavefront 1 has solved goes out as granules
+        const __amdgpu_buffer_rsrc_t rs_strm = __builtin_amdgcn_make_buffer_rsrc((void*)q->strm, 0, (int)(PP_STRM_WORDS * 8), 0x00020000);
+        static_for<PB / CB>([&](auto cc_) {
+            constexpr int cc = decltype(cc_)::value;
+            pp_lds_wait_ge(p.cnt + 2, cc + 1);
+            const double* src = p.As_cur + (cc >> 2) * PP_CHUNK + lane * 18 + 4 * (cc & 3);
+            const f64x2 a0 = *(const f64x2*)src, a1 = *(const f64x2*)(src + 2);
+            const double xs[4] = {a0.x, a0.y, a1.x, a1.y};
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                const pp_u32x4 g = {(unsigned)__double2loint(xs[k]), tag, (unsigned)__double2hiint(xs[k]), tag};
+                __builtin_amdgcn_raw_buffer_store_b128(g, rs_strm, (unsigned)(lane * 64 + k * 16), (unsigned)((s * 16 + cc) * 4096), 16);
+            }
         });
     }
     if (dead) {
@@ -413,45 +468,42 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
         lds_store_volatile(zflag, 1);
     }
     lds_store_volatile(bprog, PB);                             // (>= 16: also "this wavefront is done with As_prev")
+    if (r > s) {
+        // L(r, s) from LDS to memory, coalesced write-through stores (this wavefront is idle until the step ends; the
+        // update workgroups need the rows as early as possible: they have one step to apply them to column s + 2).
+        // The flag follows at the head of the next step, once the stores have drained.
+        pp_lds_wait_ge(p.cnt + 2, PB / CB);
+        const __amdgpu_buffer_rsrc_t rs_A = __builtin_amdgcn_make_buffer_rsrc((void*)q->a.A, 0, (int)(q->a.lda * n * 8), 0x00020000);
+        const long long lda = q->a.lda;
+#pragma unroll 8
+        for (int it = 0; it < 32; ++it) {
+            const int e = it * 64 + lane, rw = e >> 5, col = 2 * (e & 31);
+            const f64x2 v = *(const f64x2*)(p.As_cur + (col >> 4) * PP_CHUNK + rw * 18 + (col & 15));
+            const long long gr = (long long)r * PB + rw;
+            if (gr < n)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_u32x4, v), rs_A,
+                                                       (unsigned)((gr * lda + (long long)s * PB + col) * 8), 0, 16);
+        }
+    }
     PP_STEP_LOOP_END()
 }
 
-// ---------------- wavefronts 4-7: L(r, s-1) to memory; the next tile and the next diagonal block ----------------
+// ---------------- wavefronts 4-7: the next tile and the next diagonal block ----------------
 __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     pp_args_ptr q = pp_args(karg);
     double* lds = pp_lds_base(lds_off);
     const int t = threadIdx.x, lane = t & 63;
     const long long n = q->a.n, lda = q->a.lda;
+    double* A = q->a.A;
     PP_STEP_LOOP_BEGIN(lds)
     const PpStep p = pp_step(lds, s_in, n);
     const int s = p.s, r = p.r;
-    double* A = q->a.A;
     double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
     const double* Bs = lds + PP_BS;
     int* prog = p.cnt + 0; int* xprog = p.cnt + 2; int* bprog = p.cnt + 3;
-    const int mt = t - 256, mw = __builtin_amdgcn_readfirstlane((t >> 6) - 4);
+    const int mw = __builtin_amdgcn_readfirstlane((t >> 6) - 4);
     const int wr = (mw >> 1) * 32, wc = (mw & 1) * 32;
-    const pp_u64 call_id = q->call_id, timeout = q->timeout;
-    pp_u64* ctl = q->ctl;
     bool dead = false;
-    if (s >= 1) {
-        // L(r, s-1) from LDS to memory, coalesced write-through stores; the flag once all four wavefronts drained
-        const __amdgpu_buffer_rsrc_t rs_A = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(lda * n * 8), 0x00020000);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int e = it * 256 + mt, rw = e >> 5, col = 2 * (e & 31);
-            const f64x2 v = *(const f64x2*)(p.As_prev + (col >> 4) * PP_CHUNK + rw * 18 + (col & 15));
-            const long long gr = (long long)r * PB + rw;
-            if (gr < n)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_u32x4, v), rs_A,
-                                                       (unsigned)((gr * lda + (long long)(s - 1) * PB + col) * 8), 0, 16);
-        }
-        pp_drain();
-        if (lane == 0) {                                       // (ONE arrival per wavefront)
-            const int old = __hip_atomic_fetch_add(p.wocnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == 4 * s - 1) pp_st(ctl + PP_CTL_ROWDONE + r, (call_id << 8) | (pp_u64)s);
-        }
-    }
     if (r > s) {
     int bcol[4];
 #pragma unroll
@@ -479,40 +531,64 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
             }
         });
     };
-    ksteps(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
-    // the tiles' values in memory (block columns < s applied by the update workgroups): requested now, used last
-    if (s + 1 >= 2) {
-        const pp_u64* f0 = ctl + PP_CTL_TILEFINAL + (long long)r * 64 + (s + 1);
-        const pp_u64* f1 = ctl + PP_CTL_TILEFINAL + (long long)(s + 1) * 64 + (s + 1);
-        PpSpin sp;
-        for (;;) {
-            const pp_u64 f = lane == 0 ? pp_ld(f0) : (lane == 1 ? pp_ld(f1) : call_id);
-            if (__all(f == call_id)) break;
-            if (pp_give_up(sp, ctl, call_id, timeout)) { dead = true; break; }
-        }
-    }
-    if (!dead) {
+    // the tiles' values in memory (block columns < s applied by the update workgroups) are requested as soon as wavefront 2
+    // has seen their flags (an LDS word), and used last
+    int* cflag = p.cnt + 5;
+    auto request = [&]() {
+        // (the lane's row / column numbers are recomputed from an opaque copy of the lane number: kept live from the
+        // function's head they were spilled, and a scratch reload between the loads waits for every load before it)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
+                    // (UNCONDITIONAL loads from clamped addresses, masked when used: a load under a per-lane condition
+                    // has to land at the join -- hipcc put an s_waitcnt vmcnt(0) behind each, 8 us for the 48 of them)
+                    const int lr = wr + 16 * i + apgp_mma16_row(ln), lc = wc + 16 * j + apgp_mma16_col(ln, rr);
                     const long long gr = ri0 + lr, gc = base_n + lc;
-                    if (producer) {
-                        if (gr < n && gc < n && gc <= gr) cin[i][j][rr] = pp_ld_f64(A + gr * lda + gc);
-                    } else {
-                        if (gr < n) cin[i][j][rr] = pp_ld_f64(A + gr * lda + gc);                 // (gc < ri0 <= gr, gc < n)
-                        if (lc <= lr) cin2[i][j][rr] = pp_ld_f64(A + (base_n + lr) * lda + base_n + lc);   // (the block is full)
-                    }
+                    const long long grc = gr < n ? gr : n - 1, gcc = gc < n ? gc : n - 1;
+                    cin[i][j][rr] = pp_ld_f64(A + grc * lda + gcc);
+                    // (the next diagonal block: full for every consumer; the producer -- whose own tile it is -- loads the
+                    // same clamped element twice rather than branch)
+                    const long long dr = base_n + lr < n ? base_n + lr : n - 1, dc = base_n + lc < n ? base_n + lc : n - 1;
+                    cin2[i][j][rr] = pp_ld_f64(A + dr * lda + dc);
                 }
+    };
+    // Two straight-line paths, no conditional request in between (a load issued under a condition has to land at the
+    // join for the merged registers: every look that fired cost a memory round trip, 2 us per k-step measured):
+    // flags up after k-step 6 (the normal case: they rise ~8 us into the step) -> request there; otherwise before k-step 14.
+    ksteps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    if (mw == 0) PP_STAMP(s, 11);
+    ksteps(std::integral_constant<int, 1>{}, std::integral_constant<int, 6>{});
+    if (mw == 0) PP_STAMP(s, 9);
+    ksteps(std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{});
+    if (mw == 0) PP_STAMP(s, 13);
+    if (lds_load_volatile(cflag) == 1) {
+        request();
+        if (mw == 0) PP_STAMP(s, 5);
+        ksteps(std::integral_constant<int, 7>{}, std::integral_constant<int, 13>{});
+        if (mw == 0) PP_STAMP(s, 12);
+        ksteps(std::integral_constant<int, 13>{}, std::integral_constant<int, 15>{});
+    } else {
+        ksteps(std::integral_constant<int, 7>{}, std::integral_constant<int, 13>{});
+        if (mw == 0) PP_STAMP(s, 12);
+        ksteps(std::integral_constant<int, 13>{}, std::integral_constant<int, 14>{});
+        PANEL_SPIN_WHILE(lds_load_volatile(cflag) == 0);
+        if (lds_load_volatile(cflag) == 1) request();
+        else dead = true;
+        if (mw == 0) PP_STAMP(s, 5);
+        ksteps(std::integral_constant<int, 14>{}, std::integral_constant<int, 15>{});
     }
-    ksteps(std::integral_constant<int, 12>{}, std::integral_constant<int, 16>{});
+    if (mw == 0) PP_STAMP(s, 14);
+    // (what the hand-over below waits for besides the last group -- polled here, where it costs nothing)
+    pp_lds_wait_ge(prog, PB + 1);                              // (wavefronts 0 / 2 are done with Ls: the factorisation ends before the last solved group is out)
+    ksteps(std::integral_constant<int, 15>{}, std::integral_constant<int, 16>{});
+    if (mw == 0) PP_STAMP(s, 4);
     // hand-over: next tile -> the free parity of As ([64][66]) for wavefront 1, next diagonal block -> Ls
-    pp_lds_wait_ge(p.wocnt, 4 * s);                            // (every matrix wavefront has read L(r, s-1) out of it)
-    pp_lds_wait_ge(bprog, 16);                                 // (wavefront 3 too)
-    pp_lds_wait_ge(prog, PB + 1);                              // (wavefronts 0 / 2 are done with Ls; wavefront 1: xprog = 16 above)
+    pp_lds_wait_ge(bprog, 16);                                 // (wavefront 3 is done with As_prev and -- forwarding or receiving -- with the groups; wavefront 1: xprog = 16 above)
     double (*St)[PB + 2] = (double (*)[PB + 2])p.As_prev;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -521,13 +597,14 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
-                const double c = cin[i][j][rr] - v[i][j][rr];
-                if (producer) Ls[lr][lc] = c;
+                const long long gr = ri0 + lr, gc = base_n + lc;
+                if (producer) Ls[lr][lc] = ((gr < n && gc < n && gc <= gr) ? cin[i][j][rr] : 0.0) - v[i][j][rr];
                 else {
-                    St[lr][lc] = c;
-                    Ls[lr][lc] = cin2[i][j][rr] - v2[i][j][rr];
+                    St[lr][lc] = (gr < n ? cin[i][j][rr] : 0.0) - v[i][j][rr];       // (gc < ri0 <= gr, gc < n)
+                    Ls[lr][lc] = (lc <= lr ? cin2[i][j][rr] : 0.0) - v2[i][j][rr];
                 }
             }
+    if (mw == 0) PP_STAMP(s, 6);
     if (dead) lds_store_volatile(p.abl, 1);
     }
     PP_STEP_LOOP_END()
@@ -572,26 +649,101 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
         const long long j0 = (long long)s_in * PB;
         int* cnt = ints + 8 * (s_in & 1);
         panel_helper_wave((int)((n - j0) < PB ? (n - j0) : PB), lane, Ls, cnt + 0, cnt + 1);
+        // ... then -- idle otherwise -- it watches the flags of the two tiles the matrix wavefronts subtract their products
+        // from (tile (r, s+1) and the next diagonal block, finished by the update workgroups during this step) and raises an
+        // LDS word: a global poll in a matrix wavefront costs it a memory round trip per look (2 us per k-step measured)
+        if (r > s_in) {
+            bool up = s_in + 1 < 2;
+            if (!up) {
+                const pp_u64* f0 = q.ctl + PP_CTL_TILEFINAL + (long long)r * 64 + (s_in + 1);
+                const pp_u64* f1 = q.ctl + PP_CTL_TILEFINAL + (long long)(s_in + 1) * 64 + (s_in + 1);
+                PpSpin sp;
+                for (;;) {
+                    const pp_u64 f = lane == 0 ? pp_ld(f0) : (lane == 1 ? pp_ld(f1) : q.call_id);
+                    if (__all(f == q.call_id)) { up = true; break; }
+                    if (pp_give_up(sp, q.ctl, q.call_id, q.timeout)) break;
+                }
+            }
+            if (!up) lds_store_volatile(ints + 17 + (s_in & 1), 1);      // (gave up: everybody leaves at the next step's head)
+            lds_store_volatile(cnt + 5, up ? 1 : 2);                   // 1: the tiles' values may be requested | 2: never
+        }
         PP_STEP_LOOP_END()
     }
 }
 
 // ---------------------------------------------------------------------------
-// update workgroup: block column s applied to the tiles (i, q), q >= s + 2, two tiles at a time
+// update workgroup: block column s applied to the tiles (i, q), q >= s + 2, ONE tile at a time on all eight
+// wavefronts (32 x 16 outputs each: a tile's products take 1.7 us of the four matrix pipes instead of 3.4 for two
+// tiles side by side -- the tiles of column s + 2 are awaited by the row workgroups).  A tile's two 64 x 64 operands
+// and its own values are requested in ONE round of loads, one tile AHEAD (registers -> the other LDS buffer while the
+// current tile is multiplied: the memory latency of a tile hides behind its predecessor), staged whole in LDS (chunk
+// layout) and multiplied with the k-step order of apgp_gemm64_tile, so the values are those of the multi-launch path.
+// Tiles are owned statically: column-major index of (i, q), 2 <= q <= i < nb, modulo the number of update workgroups.
 // ---------------------------------------------------------------------------
+struct PpTile { long long ri, rk; int q; bool active; };
+__device__ __forceinline__ PpTile pp_tile(long long idx, long long F, long long total, int s, int nb) {
+    PpTile tl;
+    tl.active = idx >= F && idx < total;
+    long long ti = 0, tq = 0;
+    if (tl.active) {
+        long long rem = idx - F;
+        tq = s + 2;
+        while (rem >= nb - tq) { rem -= nb - tq; ++tq; }
+        ti = tq + rem;
+    }
+    tl.ri = ti * PB; tl.rk = tq * PB; tl.q = (int)tq;
+    return tl;
+}
+
 __device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds) {
     const PotrfArgs& a = q.a;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = t >> 8, tid = t & 255;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int nb = q.nb;
     const int u = (int)blockIdx.x - nb, nupd = (int)gridDim.x - nb;
-    double* hl = lds + half * GEMM64_LDS_DOUBLES;
-    int* ints = (int*)(lds + PP_INTS);
+    int* ints = (int*)(lds + PP_UPD_INTS);
     const long long n = a.n, lda = a.lda;
     const pp_u64 base = q.call_id << 8;
-    const int hw = w & 3;
-    const int wr = (hw >> 1) * 32, wc = (hw & 1) * 32;
-    const long long total = (long long)(nb - 1) * (nb - 2) / 2;          // tiles (i, q), 2 <= q <= i < nb, column-major index
+    const int wr = (w >> 2) * 32, wc = (w & 3) * 16;          // this wavefront's 32 x 16 outputs
+    int bcol[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) bcol[rr] = ((lane & 15) - 4 * rr) & 15;
+    const long long total = (long long)(nb - 1) * (nb - 2) / 2;
+    // operand rows: thread -> row e >> 5, columns 2 (e & 31), + 1 of each operand, four rounds
+    // (a second register set / loads two tiles ahead measured slower: 0.85 vs 0.81 ms at n = 2048, 3.8 vs 2.2 at 4096)
+    f64x2 ra[4], rb[4];
+    double cin[2][4];
+    auto request = [&](const PpTile& tl, long long j0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = it * 512 + t, rw = e >> 5, col = 2 * (e & 31);
+            // (unconditional loads from clamped rows, masked when staged / used: see the matrix wavefronts' request)
+            const long long ar = tl.ri + rw < n ? tl.ri + rw : n - 1, br = tl.rk + rw < n ? tl.rk + rw : n - 1;
+            ra[it] = *(const f64x2_g*)(a.A + ar * lda + j0 + col);
+            rb[it] = *(const f64x2_g*)(a.A + br * lda + j0 + col);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const long long gr = tl.ri + wr + 16 * i + apgp_mma16_row(lane);
+                const long long gc = tl.rk + wc + apgp_mma16_col(lane, rr);
+                cin[i][rr] = a.A[(gr < n ? gr : n - 1) * lda + (gc < n ? gc : n - 1)];
+            }
+    };
+    auto stage = [&](double* buf, const PpTile& tl) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = it * 512 + t, rw = e >> 5, col = 2 * (e & 31);
+            const f64x2 zero = {0.0, 0.0};
+            *(f64x2*)(buf + (col >> 4) * PP_CHUNK + rw * 18 + (col & 15)) = (tl.active && tl.ri + rw < n) ? ra[it] : zero;
+            *(f64x2*)(buf + 4 * PP_CHUNK + (col >> 4) * PP_CHUNK + rw * 18 + (col & 15)) = (tl.active && tl.rk + rw < n) ? rb[it] : zero;
+        }
+    };
     for (int s = 0; s + 2 < nb; ++s) {
+#ifdef PP_STAMPS
+        const long long F_ = (long long)s * nb - ((long long)(s + 1) * (s + 2) / 2 - 1);
+        const bool ustamp_wg = (F_ % nupd) == u, ustamp_me = ustamp_wg;
+#endif
         // every block row below s has L(:, s) in memory
         if (w == 0) {
             const int i = s + 1 + lane;
@@ -602,6 +754,7 @@ __device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds
                 if (__all(have)) break;
                 if (pp_give_up(sp, q.ctl, q.call_id, q.timeout)) { ok = 0; break; }
             }
+            PP_USTAMP(s, 0);
             if (lane == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // ONE acquire per update step: then plain, L2-served loads
                 ints[s & 1] = ok;
@@ -609,56 +762,77 @@ __device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds
         }
         __syncthreads();
         if (!ints[s & 1]) return;
+        PP_USTAMP(s, 1);
         const long long j0 = (long long)s * PB;
         const long long F = (long long)s * nb - ((long long)(s + 1) * (s + 2) / 2 - 1);   // index of tile (s + 2, s + 2)
-        long long m = (F - 1 - 2 * u) <= 0 ? 0 : (F - 1 - 2 * u + 2 * nupd - 1) / (2 * nupd);
-        for (;; ++m) {
-            const long long pair = 2 * u + 2ll * nupd * m;
-            if (pair >= total) break;
-            const long long idx = pair + half;
-            const bool active = idx >= F && idx < total;
-            long long ti = 0, tq = 0;
-            if (active) {
-                long long rem = idx - F;
-                tq = s + 2;
-                while (rem >= nb - tq) { rem -= nb - tq; ++tq; }
-                ti = tq + rem;
-            }
-            const long long ri = ti * PB, rk = tq * PB;
-            double cin[2][2][4], v[2][2][4];
+        long long m = F <= u ? 0 : (F - u + nupd - 1) / nupd;              // first m with u + nupd m >= F
+        if (u + (long long)nupd * m >= total) continue;
+        PpTile cur = pp_tile(u + (long long)nupd * m, F, total, s, nb);
+        request(cur, j0);
+        stage(lds, cur);
+        double ccur[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) ccur[i][rr] = cin[i][rr];
+        __syncthreads();
+        bool first = true;
+        for (int par = 0;; par ^= 1, ++m) {
+            // the next tile's loads fly during this tile's products (requested unconditionally -- past the end: clamped,
+            // unused -- because a load under a condition has to land at the join)
+            const PpTile nxt = pp_tile(u + (long long)nupd * (m + 1), F, total, s, nb);
+            request(nxt, j0);
+            if (first) PP_USTAMP(s, 2);
+            const double* Aop = lds + par * PP_UPD_HALF;
+            const double* Bop = Aop + 4 * PP_CHUNK;
+            double v[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int rr = 0; rr < 4; ++rr) v[i][rr] = 0.0;
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
-                        const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, rr);
-                        cin[i][j][rr] = (active && gr < n && gc < n && gc <= gr) ? a.A[gr * lda + gc] : 0.0;
-                        v[i][j][rr] = 0.0;
-                    }
-            {
-                double none[2][2][4];
-                apgp_gemm64_tile2_t<false, false, false>(tid, a.A + ri * lda + j0, lda, active ? n - ri : 0, a.A + rk * lda + j0, lda,
-                                                         active ? n - rk : 0, 0, PB, hl, v, none);
-            }
-            if (active) {
+            for (int g = 0; g < 16; ++g) {
+                const double* Ach = Aop + (g >> 2) * PP_CHUNK;
+                const double* Bch = Bop + (g >> 2) * PP_CHUNK;
+                const int ks = g & 3;
+                double af[2], bf[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = Ach[(wr + 16 * i + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) bf[rr] = Bch[(wc + bcol[rr]) * 18 + ks * 4 + (lane >> 4)];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int rr = 0; rr < 4; ++rr) v[i][rr] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf[rr], v[i][rr], 0, 0, 0);
+            }
+            if (first) PP_USTAMP(s, 3);
+            if (cur.active) {
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
-                            const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, rr);
-                            if (gr < n && gc < n && gc <= gr) pp_st_f64(a.A + gr * lda + gc, cin[i][j][rr] - v[i][j][rr]);
-                        }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const long long gr = cur.ri + wr + 16 * i + apgp_mma16_row(lane);
+                        const long long gc = cur.rk + wc + apgp_mma16_col(lane, rr);
+                        if (gr < n && gc < n && gc <= gr) pp_st_f64(a.A + gr * lda + gc, ccur[i][rr] - v[i][rr]);   // (masked elements: never stored)
+                    }
+            }
+            if (nxt.active) {
+                stage(lds + (par ^ 1) * PP_UPD_HALF, nxt);               // (waits for the next tile's operands)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) ccur[i][rr] = cin[i][rr];
             }
             pp_drain();
-            __syncthreads();
+            __syncthreads();                                             // (every wavefront's stores drained; the next operands staged)
+            if (first) PP_USTAMP(s, 4);
+            first = false;
             // column s + 2 now carries every block column the update workgroups owe it
-            if (active && tq == s + 2 && tid == 0) pp_st(q.ctl + PP_CTL_TILEFINAL + ti * 64 + tq, q.call_id);
+            if (cur.active && cur.q == s + 2 && t == 0) pp_st(q.ctl + PP_CTL_TILEFINAL + (cur.ri / PB) * 64 + cur.q, q.call_id);
+            if (!nxt.active) break;
+            cur = nxt;
         }
+        PP_USTAMP(s, 5);
     }
 }
 

@@ -67,7 +67,7 @@ for n in sizes:
         ks = kern(D)
         L1, z1, o1, i1 = nll(X_d, y_d, n, ks, 0.25, 1)
         fb0 = lib.apgp_potrf_fallbacks()
-        L0, z0, o0, i0 = nll(X_d, y_d, n, ks, 0.25, 0)
+        L0, z0, o0, i0 = nll(X_d, y_d, n, ks, 0.25, 3)
         fb1 = lib.apgp_potrf_fallbacks()
         same = torch.equal(L0, L1) and torch.equal(z0, z1) and np.array_equal(o0, o1) and i0 == i1
         nd = int((L0 != L1).sum().item()); ndz = int((z0 != z1).sum().item())
@@ -117,7 +117,7 @@ for it in range(50 if quick else 300):
 print("stress n=%d: %d deviating calls, fallbacks so far %d" % (n, nbad, lib.apgp_potrf_fallbacks()), flush=True)
 bad += nbad
 
-for n in (512, 1152, 2048, 4096):
+for n in (512, 1152, 2048, 2560, 3072, 4096):
     if quick and n > 1152:
         break
     rs = np.random.RandomState(n)
@@ -125,7 +125,7 @@ for n in (512, 1152, 2048, 4096):
     X_d = torch.from_numpy(X).to(dev); y_d = torch.from_numpy(y).to(dev)
     ks = kern(8)
     t1 = timeit(X_d, y_d, n, ks, 0.0, 1, 20)
-    t0 = timeit(X_d, y_d, n, ks, 0.0, 0, 20)
+    t0 = timeit(X_d, y_d, n, ks, 0.0, 3, 20)
     print("apgp_nll_eval n=%4d: multi-launch %.3f ms, persistent %.3f ms" % (n, t1 * 1e3, t0 * 1e3), flush=True)
 lib.apgp_potrf_mode(0)
 print("FAILURES: %d" % bad)
