@@ -848,7 +848,7 @@ static int potrf_device_cus(int dev) {
 static bool potrf_persist_applies(int64_t n, int64_t lda, hipStream_t s) {
     if (g_potrf_mode.load() == 1) return false;
     const int64_t nb = (n + PB - 1) / PB;
-    // (measured, apgp_nll_eval: 0.177 vs 0.208 ms at n = 512, 0.406 vs 0.470 at 1152, 0.782 vs 0.887 at 2048, but 2.08 vs
+    // (measured, apgp_nll_eval: 0.177 vs 0.208 ms at n = 512, 0.406 vs 0.470 at 1152, 0.78 vs 0.88 at 2048, 1.25 vs 1.37 at 3072, but 2.08 vs
     // 1.99 at 4096, where the trailing update's throughput decides and the multi-launch path keeps all 256 CUs on it:
     // mode 0 takes the persistent launch up to PP_AUTO_NB block columns; mode 3 forces it wherever it can run)
     if (nb < 2 || nb > PP_MAX_NB) return false;

@@ -44,7 +44,7 @@ typedef unsigned long long pp_u64;
 typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
 
 #define PP_MAX_NB 64
-#define PP_AUTO_NB 40                                // block columns up to which the persistent launch is the default
+#define PP_AUTO_NB 48                                // block columns up to which the persistent launch is the default
 #define PP_THREADS 512
 #define PP_CHUNK (64 * 18)                        // a 16-column chunk of a 64-row tile, rows padded to 18 (apgp_gemm64_tile's)
 // LDS map of a row workgroup (doubles)
@@ -80,6 +80,7 @@ static_assert(64 * 66 <= 4 * PP_CHUNK, "the handed-over tile fits one parity of 
 // 9 k-step 5 done | 10 first group received | 11 k-step 0 done | 12-14 k-steps 12-14 done | 15 group 14 received
 #ifdef PP_STAMPS
 __device__ unsigned long long pp_stamps[64 * 24];
+#define PP_STAMPP(s_, i_) do { if ((int)blockIdx.x == (s_) + 1 && (threadIdx.x & 63) == 0) pp_stamps[(s_) * 24 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)   /* the step's producer workgroup */
 #define PP_STAMP(s_, i_) do { if ((int)blockIdx.x == q->nb - 1 && (threadIdx.x & 63) == 0) pp_stamps[(s_) * 24 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int apgp_debug_read_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_stamps), sizeof(unsigned long long) * 64 * 24) == hipSuccess ? 0 : -2;
@@ -93,6 +94,7 @@ extern "C" int apgp_debug_read_ustamps(unsigned long long* out) {
 }
 #else
 #define PP_STAMP(s_, i_) do { } while (0)
+#define PP_STAMPP(s_, i_) do { } while (0)
 #define PP_USTAMP(s_, i_) do { } while (0)
 #endif
 
@@ -283,6 +285,7 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     const int bs = p.bs, s = p.s, r = p.r;
     double rowv[PB];                                           // row `lane` of the diagonal block
     PP_STAMP(s, 0);
+    PP_STAMPP(s, 16);
 #pragma unroll
     for (int k = 0; k < PB; k += 2) {
         const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
@@ -366,6 +369,7 @@ __device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
     }
     pp_solve_wave(lane, rowv, Ls, lds + PP_INVD, p.cnt + 0, p.As_cur, p.cnt + 2);
     PP_STAMP(p.s, 2);
+    PP_STAMPP(p.s, 17);
     }
     PP_STEP_LOOP_END()
 }
@@ -460,7 +464,9 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
                 const pp_u32x4 g = {(unsigned)__double2loint(xs[k]), tag, (unsigned)__double2hiint(xs[k]), tag};
                 __builtin_amdgcn_raw_buffer_store_b128(g, rs_strm, (unsigned)(lane * 64 + k * 16), (unsigned)((s * 16 + cc) * 4096), 16);
             }
+            if (cc == 0) PP_STAMPP(s, 19);
         });
+        PP_STAMPP(s, 18);
     }
     if (dead) {
         // release whoever waits for this wavefront; everybody leaves at the next step's head
@@ -534,32 +540,33 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     // the tiles' values in memory (block columns < s applied by the update workgroups) are requested as soon as wavefront 2
     // has seen their flags (an LDS word), and used last
     int* cflag = p.cnt + 5;
-    auto request = [&]() {
+    // one (i, j) block of four elements of both tiles per call: eight 8-byte loads.  The sixteen-row accumulator layout makes
+    // every load touch sixteen cache lines (~60 cycles of address processing each): all 64 in one go held the k-steps up
+    // for 2.5-3 us -- spread over eight k-steps they fit the slack between two arriving groups.
+    auto request = [&](auto b_) {
+        constexpr int b = decltype(b_)::value, i = b >> 1, j = b & 1;
         // (the lane's row / column numbers are recomputed from an opaque copy of the lane number: kept live from the
         // function's head they were spilled, and a scratch reload between the loads waits for every load before it)
         int ln = lane;
         asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    // (UNCONDITIONAL loads from clamped addresses, masked when used: a load under a per-lane condition
-                    // has to land at the join -- hipcc put an s_waitcnt vmcnt(0) behind each, 8 us for the 48 of them)
-                    const int lr = wr + 16 * i + apgp_mma16_row(ln), lc = wc + 16 * j + apgp_mma16_col(ln, rr);
-                    const long long gr = ri0 + lr, gc = base_n + lc;
-                    const long long grc = gr < n ? gr : n - 1, gcc = gc < n ? gc : n - 1;
-                    cin[i][j][rr] = pp_ld_f64(A + grc * lda + gcc);
-                    // (the next diagonal block: full for every consumer; the producer -- whose own tile it is -- loads the
-                    // same clamped element twice rather than branch)
-                    const long long dr = base_n + lr < n ? base_n + lr : n - 1, dc = base_n + lc < n ? base_n + lc : n - 1;
-                    cin2[i][j][rr] = pp_ld_f64(A + dr * lda + dc);
-                }
+        for (int rr = 0; rr < 4; ++rr) {
+            // (UNCONDITIONAL loads from clamped addresses, masked when used: a load under a per-lane condition has to
+            // land at the join -- hipcc put an s_waitcnt vmcnt(0) behind each, 8 us for all of them)
+            const int lr = wr + 16 * i + apgp_mma16_row(ln), lc = wc + 16 * j + apgp_mma16_col(ln, rr);
+            const long long gr = ri0 + lr, gc = base_n + lc;
+            const long long grc = gr < n ? gr : n - 1, gcc = gc < n ? gc : n - 1;
+            cin[i][j][rr] = pp_ld_f64(A + grc * lda + gcc);
+            // (the next diagonal block: full for every consumer; the producer -- whose own tile it is -- loads the same
+            // clamped element twice rather than branch)
+            const long long dr = base_n + lr < n ? base_n + lr : n - 1, dc = base_n + lc < n ? base_n + lc : n - 1;
+            cin2[i][j][rr] = pp_ld_f64(A + dr * lda + dc);
+        }
     };
     // Two straight-line paths, no conditional request in between (a load issued under a condition has to land at the
     // join for the merged registers: every look that fired cost a memory round trip, 2 us per k-step measured):
-    // flags up after k-step 6 (the normal case: they rise ~8 us into the step) -> request there; otherwise before k-step 14.
+    // flags up after k-step 6 (the normal case: they rise ~8 us into the step) -> a quarter of the requests after each of
+    // the k-steps 6 .. 9; otherwise all of them before k-step 14.
     ksteps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
     if (mw == 0) PP_STAMP(s, 11);
     ksteps(std::integral_constant<int, 1>{}, std::integral_constant<int, 6>{});
@@ -567,9 +574,13 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     ksteps(std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{});
     if (mw == 0) PP_STAMP(s, 13);
     if (lds_load_volatile(cflag) == 1) {
-        request();
+        static_for<4>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            request(std::integral_constant<int, b>{});
+            ksteps(std::integral_constant<int, 7 + b>{}, std::integral_constant<int, 8 + b>{});
+        });
         if (mw == 0) PP_STAMP(s, 5);
-        ksteps(std::integral_constant<int, 7>{}, std::integral_constant<int, 13>{});
+        ksteps(std::integral_constant<int, 11>{}, std::integral_constant<int, 13>{});
         if (mw == 0) PP_STAMP(s, 12);
         ksteps(std::integral_constant<int, 13>{}, std::integral_constant<int, 15>{});
     } else {
@@ -577,7 +588,7 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
         if (mw == 0) PP_STAMP(s, 12);
         ksteps(std::integral_constant<int, 13>{}, std::integral_constant<int, 14>{});
         PANEL_SPIN_WHILE(lds_load_volatile(cflag) == 0);
-        if (lds_load_volatile(cflag) == 1) request();
+        if (lds_load_volatile(cflag) == 1) static_for<4>([&](auto b_) { request(b_); });
         else dead = true;
         if (mw == 0) PP_STAMP(s, 5);
         ksteps(std::integral_constant<int, 14>{}, std::integral_constant<int, 15>{});

@@ -153,7 +153,7 @@ int apgp_release_scratch(void* stream);
  * out5_dev are STREAM-ordered (read them from work enqueued on `stream`, or after
  * synchronising it), not host- or other-stream-visible on return.
  * Status as the parts'; a non-PD matrix is reported in out5_host[4] (> 0), not in the status.
- * 64 < n <= 2560: the Cholesky is ONE persistent launch (csrc/potrf_persist.h: row workgroups
+ * 64 < n <= 3072: the Cholesky is ONE persistent launch (csrc/potrf_persist.h: row workgroups
  * chained by in-launch hand-offs instead of a launch per 64-column step; bit-identical to the
  * multi-launch path).  All of its workgroups must be resident at once; if they are not within
  * 50 ms (a foreign kernel holds compute units) the launch gives up and the call transparently
@@ -164,7 +164,7 @@ int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/
                   void* stream);
 
 /* Test / profiling switch for the Cholesky inside apgp_nll_eval (not read from the
- * environment): 0 = persistent launch for 64 < n <= 2560, where it is the faster one
+ * environment): 0 = persistent launch for 64 < n <= 3072, where it is the faster one
  * (default), 1 = multi-launch path only, 2 = persistent launch that gives up at once
  * (exercises the fallback), 3 = persistent launch wherever it can run (64 < n <= 4096).
  * mode < 0 only queries.  Returns the previous mode (-1: bad argument).

@@ -36,7 +36,7 @@ if __name__ == "__main__":
     lib.apgp_debug_read_stamps.argtypes = [ctypes.c_void_p]
     from approxposterior_amd import gp as agp
     dev = torch.device("cuda:0")
-    names = ["start", "factor", "solve", "recv16", "k15", "flags", "handover", "zappl", "L-out", "k11", "recv1", "k0", "k12", "k13", "k14", "recv15", "h-done", "h-flags", "h-tile", "h-diagld", "h-staged"]
+    names = ["start", "factor", "solve", "recv16", "k15", "flags", "handover", "zappl", "L-out", "k11", "recv1", "k0", "k12", "k13", "k14", "recv15", "P-start", "P-solve", "P-fwd16", "P-fwd1"]
     for n in [int(a) for a in sys.argv[1:]] or [1152]:
         D = 8
         rs = np.random.RandomState(n)
@@ -61,7 +61,7 @@ if __name__ == "__main__":
         for s in range(nb):
             t0 = st[s, 0]
             nxt = st[s + 1, 0] if s + 1 < nb else t0
-            print("%4d %6.2f " % (s, (nxt - t0) * 0.01) + " ".join("%8.2f" % ((st[s, i] - t0) * 0.01) if st[s, i] else "       -" for i in range(1, 21)))
+            print("%4d %6.2f " % (s, (nxt - t0) * 0.01) + " ".join("%8.2f" % ((st[s, i] - t0) * 0.01) if st[s, i] else "       -" for i in range(1, 20)))
         print("total (first step start -> last factor done): %.1f us" % ((st[nb - 1, 1] - st[0, 0]) * 0.01))
         us = np.zeros(64 * 8, dtype=np.uint64)
         lib.apgp_debug_read_ustamps.restype = ctypes.c_int
