@@ -283,6 +283,37 @@ class ApproxPosterior(object):
         np.savez(path, chain=self.sampler.get_chain(), log_prob=self.sampler.get_log_prob(),
                  blobs=np.array([]) if blobs is None else blobs)
 
+    def _requireBoxPrior(self):
+        """The on-device sampler (``GP.sample_ensemble``) knows ONE prior: constant inside ``self.bounds``,
+        -inf outside.  ``_gpll`` returns ``mu(theta) + lnprior(theta)`` (approx.py:167-188), so any other
+        ``lnprior`` -- a Gaussian, a tilted box -- would make the device chain sample a different posterior
+        without a word.  ``lnprior`` is probed (own RandomState: the caller's NumPy stream is untouched) at
+        the centre, at seeded points inside, just inside every corner and just outside every face: it must be
+        one finite constant inside and non-finite outside, else ``ValueError``."""
+        lo = np.array([b[0] for b in self.bounds], dtype=np.float64)
+        hi = np.array([b[1] for b in self.bounds], dtype=np.float64)
+        span = hi - lo
+        rs = np.random.RandomState(20260304)
+        inside = [0.5 * (lo + hi)] + list(lo + span * rs.uniform(0.0, 1.0, size=(8, len(lo))))
+        for corner in range(min(2 ** len(lo), 16)):
+            pick = np.array([(corner >> d) & 1 for d in range(len(lo))], dtype=np.float64)
+            inside.append(lo + span * (1e-6 + pick * (1.0 - 2e-6)))
+        vals = np.array([float(np.asarray(self._lnprior(p)).ravel()[0]) for p in inside])
+        ok = np.all(np.isfinite(vals)) and np.all(np.abs(vals - vals[0]) <= 1e-12 * max(1.0, abs(vals[0])))
+        outside = []
+        for d in range(len(lo)):
+            for sign, edge in ((-1.0, lo), (1.0, hi)):
+                p = 0.5 * (lo + hi)
+                p[d] = edge[d] + sign * 1e-2 * span[d]
+                outside.append(p)
+        with np.errstate(all="ignore"):
+            out_vals = np.array([float(np.asarray(self._lnprior(p)).ravel()[0]) for p in outside])
+        ok = ok and not np.any(np.isfinite(out_vals))
+        if not ok:
+            raise ValueError("runMCMC(onDevice=True) samples mu(theta) under the box prior self.bounds only; lnprior is not "
+                             "constant inside / -inf outside these bounds (probed %d + %d points). Use onDevice=False "
+                             "(batched=True keeps the GP on the device)." % (len(inside), len(outside)))
+
     def runMCMC(self, samplerKwargs=None, mcmcKwargs=None, runName="apRun",
                 cache=True, estBurnin=True, thinChains=True, verbose=False,
                 args=None, batched=True, onDevice=False, **kwargs):
@@ -293,13 +324,15 @@ class ApproxPosterior(object):
         (:meth:`_gpllBatch`); ``batched=False`` calls :meth:`_gpll` once per walker as
         emcee does for the reference; ``onDevice=True`` runs the entire chain as one
         persistent kernel (``GP.sample_ensemble``) -- valid when ``lnprior`` is the box
-        prior ``self.bounds`` (constant inside, -inf outside), which the caller asserts.
+        prior ``self.bounds`` (constant inside, -inf outside): checked (:meth:`_requireBoxPrior`,
+        ``ValueError`` otherwise).
         With ``cache`` the chain goes to ``<runName>.npz`` (keys chain, log_prob, blobs)
         where the reference writes ``<runName>.h5``.
         """
         samplerKwargs, mcmcKwargs = mcmcUtils.validateMCMCKwargs(self, samplerKwargs,
                                                                  mcmcKwargs, verbose)
         if onDevice:
+            self._requireBoxPrior()
             result = self.gp.sample_ensemble(self.y, mcmcKwargs["initial_state"],
                                              mcmcKwargs["iterations"], self.bounds,
                                              seed=np.random.randint(0, 2 ** 31 - 1))

@@ -50,6 +50,142 @@ __global__ __launch_bounds__(256) void syrk_wtw_kernel(SyrkArgs a) {
             }
 }
 
+
+// ---------------------------------------------------------------------------
+// K^-1 by the SOLVE route, for factors the explicit inverse must not be trusted on (condition estimate above the
+// gate of gp.py, COND_SOLVE): what george's grad_log_likelihood does -- K^-1 = cho_solve(L, I) (gpUtils.py:110 ->
+// george GP.grad_log_likelihood -> solver.apply_inverse(identity)) -- two triangular solves against the identity,
+// never a product of inverses:
+//   pass 0  X = L^-1 I   blocked forward substitution, block row j = 0 .. nb-1  (X is lower triangular)
+//   pass 1  Y = L^-T X   blocked back substitution,    block row j = nb-1 .. 0  (lower-triangle tiles of K^-1)
+// One launch per block row and pass, one workgroup per 64 x 64 tile (j, c), c <= j: the tile's right-hand side minus
+// the already solved block rows (plain fp64 FMA on LDS-staged 64 x 16 chunks, every index bounds-checked -- this
+// path is rare and not where the time goes), then the 64 x 64 triangular solve by substitution, one column per thread.
+// ---------------------------------------------------------------------------
+struct KinvSolveArgs {
+    const double* L;
+    double* X;        // np x np, ld np (pass 0 output)
+    double* Y;        // n x n, ld n (pass 1 output: K^-1, lower tiles)
+    long long n, ldl, np;
+    int j;
+};
+
+template <int PASS>
+__global__ __launch_bounds__(256) void kinv_solve_step_kernel(KinvSolveArgs a) {
+    __shared__ double As[64][17], Bs[16][65], Rt[64][65], Lj[64][65];
+    const int t = threadIdx.x;
+    const long long j = a.j, c = blockIdx.x, n = a.n, np = a.np;
+    const long long r0 = j * 64, c0 = c * 64;
+    const int ty = t >> 4, tx = t & 15;                   // thread -> outputs rows 4 ty .. +3, columns 4 tx .. +3
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = 0.0;
+    // sum over the solved block rows: pass 0: k in [c0, r0) of L[r0 + i][k] X[k][c0 + q];
+    //                                pass 1: k in [r0 + 64, np) of L[k][r0 + i] Y[k][c0 + q]   (k < n only)
+    const long long kb = PASS == 0 ? c0 : r0 + 64, ke = PASS == 0 ? r0 : np;
+    for (long long kk = kb; kk < ke; kk += 16) {
+        for (int e = t; e < 64 * 16; e += 256) {
+            const int i = e >> 4, k = e & 15;
+            const long long gk = kk + k, gi = r0 + i;
+            double v = 0.0;
+            if (PASS == 0) { if (gi < n && gk < n) v = a.L[gi * a.ldl + gk]; }
+            else { if (gk < n && gi < n) v = a.L[gk * a.ldl + gi]; }
+            As[i][k] = v;
+        }
+        for (int e = t; e < 16 * 64; e += 256) {
+            const int k = e >> 6, q = e & 63;
+            const long long gk = kk + k, gq = c0 + q;
+            double v = 0.0;
+            if (PASS == 0) v = a.X[gk * np + gq];
+            else if (gk < n && gq < n) v = a.Y[gk * n + gq];
+            Bs[k][q] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[i][q] = fma(As[4 * ty + i][k], Bs[k][4 * tx + q], acc[i][q]);
+        __syncthreads();
+    }
+    // right-hand side tile minus the sum; the diagonal block of L (identity rows past n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int li = 4 * ty + i, lq = 4 * tx + q;
+            double b;
+            if (PASS == 0) b = (c == j && li == lq) ? 1.0 : 0.0;
+            else b = a.X[(r0 + li) * np + c0 + lq];
+            Rt[li][lq] = b - acc[i][q];
+        }
+    for (int e = t; e < 64 * 64; e += 256) {
+        const int i = e >> 6, k = e & 63;
+        const long long gi = r0 + i, gk = r0 + k;
+        Lj[i][k] = (gi < n && gk < n && k <= i) ? a.L[gi * a.ldl + gk] : ((i == k) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (t < 64) {
+        double x[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) x[i] = Rt[i][t];
+        if (PASS == 0) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                double v = x[i];
+#pragma unroll
+                for (int m = 0; m < i; ++m) v = fma(-Lj[i][m], x[m], v);
+                x[i] = v / Lj[i][i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 63; i >= 0; --i) {
+                double v = x[i];
+#pragma unroll
+                for (int m = i + 1; m < 64; ++m) v = fma(-Lj[m][i], x[m], v);
+                x[i] = v / Lj[i][i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const long long gi = r0 + i, gq = c0 + t;
+            if (PASS == 0) a.X[gi * np + gq] = (gi < n && gq < n) ? x[i] : 0.0;
+            else if (gi < n && gq < n) a.Y[gi * n + gq] = x[i];
+        }
+    }
+}
+
+extern "C" int64_t apgp_kinv_solve_work_len(int64_t n) {
+    const int64_t np = apgp_round_up(n < 1 ? 1 : n, 64);
+    return np * np;
+}
+
+extern "C" int apgp_kinv_solve(const double* L, int64_t n, int64_t ldl, double* xwork, double* kinv, void* stream) {
+    APGP_CHECK_ARG(L && xwork && kinv, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    hipStream_t s = (hipStream_t)stream;
+    KinvSolveArgs a;
+    a.L = L; a.X = xwork; a.Y = kinv; a.n = n; a.ldl = ldl; a.np = apgp_round_up(n, 64);
+    const int nb = (int)(a.np / 64);
+    if (hipMemsetAsync(xwork, 0, sizeof(double) * (size_t)a.np * (size_t)a.np, s) != hipSuccess) {
+        apgp_set_error("apgp_kinv_solve: memset failed");
+        return -2;
+    }
+    for (int j = 0; j < nb; ++j) {
+        a.j = j;
+        hipLaunchKernelGGL(kinv_solve_step_kernel<0>, dim3((unsigned)(j + 1)), dim3(256), 0, s, a);
+    }
+    for (int j = nb - 1; j >= 0; --j) {
+        a.j = j;
+        hipLaunchKernelGGL(kinv_solve_step_kernel<1>, dim3((unsigned)(j + 1)), dim3(256), 0, s, a);
+    }
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
 struct GradArgs {
     const double* X;
     const double* alpha;
@@ -178,10 +314,11 @@ extern "C" int64_t apgp_grad_work_len(int64_t n) {
 extern "C" int apgp_grad_loglik(const double* X, const double* alpha, const double* winv, int64_t ldw,
                                 int64_t n, const apgp_kernel_t* kern, double* work, double* out,
                                 void* stream) {
-    APGP_CHECK_ARG(X && alpha && winv && kern && work && out, "null pointer");
+    APGP_CHECK_ARG(X && alpha && kern && work && out, "null pointer");
     APGP_CHECK_ARG(n >= 1, "n >= 1 required");
     const long long np = apgp_round_up(n, 64);
-    APGP_CHECK_ARG(ldw >= np, "winv must be the padded dense inverse left in apgp_trtri_pack's work buffer");
+    // winv == NULL: `work` already holds K^-1 (its lower tiles), formed by apgp_kinv_solve (the solve route)
+    APGP_CHECK_ARG(!winv || ldw >= np, "winv must be the padded dense inverse left in apgp_trtri_pack's work buffer");
     GradArgs g;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &g.kc) == 0, "kernel parameters");
     hipStream_t s = (hipStream_t)stream;
@@ -189,7 +326,7 @@ extern "C" int apgp_grad_loglik(const double* X, const double* alpha, const doub
     SyrkArgs sa;
     sa.W = winv; sa.Kinv = work; sa.ldw = ldw; sa.np = np; sa.n = n;
     const unsigned nlow = nb * (nb + 1) / 2;
-    hipLaunchKernelGGL(syrk_wtw_kernel, dim3(nlow), dim3(256), 0, s, sa);
+    if (winv) hipLaunchKernelGGL(syrk_wtw_kernel, dim3(nlow), dim3(256), 0, s, sa);
     g.X = X; g.alpha = alpha; g.Kinv = work; g.partial = work + n * n; g.n = n;
     const int pw = 2 + g.kc.dpad;
     switch (g.kc.dpad) {

@@ -49,15 +49,27 @@ def sharded_acquire(local_acquire, idx_offset, group=None, device=None, records=
     rank's shard and all-gather the winners.
 
     ``local_acquire`` is typically
-    ``lambda off: gp.acquire(y, T_local, kind, bounds=..., idx_offset=off)``.
+    ``lambda off: gp.acquire(y, T_local, kind, bounds=..., idx_offset=off, device_record=True)``
+    (the 16-byte record stays in HBM until the gather) or the same without ``device_record``
+    (a host ``(index, u)`` pair).
     Returns the same (index, u) on every rank.  ``records`` (a list) receives the gathered
     per-rank (u, index) pairs in rank order -- one per rank the collective actually saw.
     """
     import torch
     import torch.distributed as dist
 
-    bi, bu = local_acquire(idx_offset)
+    res = local_acquire(idx_offset)
+    on_device = torch.is_tensor(res)        # the sweep's own 16-byte record, still in HBM (GP.acquire(device_record=True))
+    if on_device:
+        if res.dtype != torch.int64 or res.numel() != 2:
+            raise ValueError("a device record is an int64[2] tensor: bit pattern of best_u, best_index")
+        mine = res.reshape(2)
+    else:
+        bi, bu = res
     if not (dist.is_available() and dist.is_initialized()):
+        if on_device:
+            h = mine.cpu().numpy()
+            bu, bi = float(h[0:1].view(np.float64)[0]), int(h[1])
         if records is not None:
             records[:] = [(float(bu), int(bi))]
         return combine_best([(bu, bi)])
@@ -67,14 +79,17 @@ def sharded_acquire(local_acquire, idx_offset, group=None, device=None, records=
     # one 16-byte record per rank as two int64 words: the utility's bit pattern and the index.
     # (Integer words survive any transport unchanged -- a float64 carrier for the index would be
     # at the mercy of NaN canonicalisation the day someone swaps the gather for a reduction.)
-    mine = torch.tensor([int(np.float64(bu).view(np.int64)), int(bi)], dtype=torch.int64, device=device)
+    # With a device record and the nccl backend nothing touches the host before the gather: the words go from
+    # the arg-min kernel's output straight into the collective, and ONE copy brings all ranks' records back.
+    if not on_device:
+        mine = torch.tensor([int(np.float64(bu).view(np.int64)), int(bi)], dtype=torch.int64, device=device)
+    elif mine.device != device:
+        mine = mine.to(device)
     world = dist.get_world_size(group)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
-    pairs = []
-    for g in gathered:
-        h = g.cpu().numpy()
-        pairs.append((float(h[0:1].view(np.float64)[0]), int(h[1])))
+    h = torch.stack(gathered).cpu().numpy()                 # (world, 2) int64, one copy
+    pairs = [(float(h[r, 0:1].view(np.float64)[0]), int(h[r, 1])) for r in range(world)]
     if records is not None:
         records[:] = pairs
     return combine_best(pairs)

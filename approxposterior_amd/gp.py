@@ -909,7 +909,7 @@ class GP(object):
             return mu, cov.cpu().numpy()
 
     def acquire(self, y, t, kind, bounds=None, mask=None, zeta=0.01, return_all=False,
-                idx_offset=0):
+                idx_offset=0, device_record=False):
         """Fused predict + utility + arg-min over the candidate matrix ``t`` (M,D).
 
         The batched counterpart of utility.minimizeObjective (utility.py:253-372)
@@ -920,20 +920,29 @@ class GP(object):
 
         Returns (best_index, best_u) or, with return_all, additionally the
         arrays (u, mu, var).  best_index is -1 when no candidate is admissible.
+        ``device_record``: return the sweep's 16-byte ``apgp_best_t`` record where the arg-min
+        kernel left it -- a device int64[2] tensor (bit pattern of best_u, best_index), stream-ordered,
+        no copy to the host: what ``dist.sharded_acquire`` hands to the RCCL all-gather.
         """
         if not self.computed:
             raise RuntimeError("ERROR: Need to compute GP before using it!")
         kind_id = UTILITY_KINDS[str(kind).lower()]
         want = ("best", "u", "mu", "var") if return_all else ("best",)
+        if device_record:
+            if return_all:
+                raise ValueError("device_record returns the arg-min record only")
+            want = ("best_device",)
         if hasattr(t, "data_ptr"):      # candidates already resident in HBM (torch tensor)
             if t.dim() != 2 or t.shape[1] != self.kernel.ndim or not t.is_contiguous() \
                     or str(t.dtype) != "torch.float64" or not t.is_cuda:
                 raise ValueError("device candidates must be a contiguous (M, D) float64 CUDA tensor")
-            return self._sweep(y, None, kind=kind_id, want=want, bounds=bounds, mask=mask,
-                               zeta=zeta, idx_offset=idx_offset, cand_device=t)
-        xs = self.parse_samples(t)
-        return self._sweep(y, xs, kind=kind_id, want=want, bounds=bounds, mask=mask,
-                           zeta=zeta, idx_offset=idx_offset)
+            res = self._sweep(y, None, kind=kind_id, want=want, bounds=bounds, mask=mask,
+                              zeta=zeta, idx_offset=idx_offset, cand_device=t)
+        else:
+            xs = self.parse_samples(t)
+            res = self._sweep(y, xs, kind=kind_id, want=want, bounds=bounds, mask=mask,
+                              zeta=zeta, idx_offset=idx_offset)
+        return res[0] if device_record else res
 
     def _sweep(self, y, cand, kind, want, bounds=None, mask=None, zeta=0.01, idx_offset=0,
                cand_device=None):
@@ -987,6 +996,9 @@ class GP(object):
                 # empty candidate set: nothing admissible (index -1, +inf), empty arrays
                 empty = {"best": (-1, float("inf")), "mu": (np.empty(0),), "var": (np.empty(0),),
                          "u": (np.empty(0),)}
+                if "best_device" in want:
+                    empty["best_device"] = (torch.tensor([int(np.float64(np.inf).view(np.int64)), -1],
+                                                         dtype=torch.int64, device=dev),)
                 return tuple(v for w_ in want for v in empty[w_])
             if not need_var:
                 mu = torch.empty(m, dtype=torch.float64, device=dev)
@@ -1037,7 +1049,10 @@ class GP(object):
                 ev.append((e0, e1))
             out = []
             for w in want:
-                if w == "best":
+                if w == "best_device":
+                    import torch as _t
+                    out.append(best.view(_t.int64))
+                elif w == "best":
                     bb = best.cpu().numpy()
                     out.append(int(bb[1:2].view(np.int64)[0]))
                     out.append(float(bb[0]))
@@ -1112,12 +1127,22 @@ class GP(object):
             with torch.cuda.device(dev):
                 st = self._stream(torch)
                 self._solve(y, need_alpha=True)
-                self._ensure_linv()
                 work = torch.empty(lib.apgp_grad_work_len(n), dtype=torch.float64, device=dev)
                 out = torch.empty(4 + _lib.MAX_DIM, dtype=torch.float64, device=dev)
                 np64 = (n + 63) // 64 * 64
+                if self._trust_inverse():
+                    # K^-1 = W^T W with the resident dense W = L^-1 (one MFMA-f64 product)
+                    self._ensure_linv()
+                    winv = self._work.data_ptr()
+                else:
+                    # above the conditioning gate: K^-1 by two triangular solves against the identity, as george's
+                    # cho_solve(L, I) (gpUtils.py:110 -> GP.grad_log_likelihood) -- never a product of inverses
+                    xw = torch.empty(int(lib.apgp_kinv_solve_work_len(n)), dtype=torch.float64, device=dev)
+                    _lib.check(lib.apgp_kinv_solve(self._L.data_ptr(), n, self._ld, xw.data_ptr(), work.data_ptr(), st),
+                               "apgp_kinv_solve")
+                    winv = None
                 _lib.check(lib.apgp_grad_loglik(self._x_d.data_ptr(), self._alpha.data_ptr(),
-                                                self._work.data_ptr(), np64, n, ctypes.byref(ks),
+                                                winv, np64, n, ctypes.byref(ks),
                                                 work.data_ptr(), out.data_ptr(), st),
                            "apgp_grad_loglik")
                 o = out.cpu().numpy()

@@ -353,7 +353,7 @@ def main():
 
     def step():
         return adist.sharded_acquire(
-            lambda off: gp.acquire(y, T, args.utility, bounds=bounds, idx_offset=off), lo_row,
+            lambda off: gp.acquire(y, T, args.utility, bounds=bounds, idx_offset=off, device_record=world > 1), lo_row,
             records=records)
 
     def barrier():

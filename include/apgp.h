@@ -348,6 +348,14 @@ int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kernel_t* kern 
  *   out[3+APGP_MAX_DIM] = 0.5 * sum_ij (alpha alpha^T - K^-1)_ij K_lin_ij: d/d log_constant
  *   of the linear term, and minus d/d log_gamma2.  out: 4 + APGP_MAX_DIM doubles.   */
 int64_t apgp_grad_work_len(int64_t n);
+/* K^-1 by the SOLVE route, for factors whose explicit inverse must not be trusted (the host's
+ * conditioning gate): what george does -- K^-1 = cho_solve(L, I) inside grad_log_likelihood
+ * (gpUtils.py:110) -- two blocked triangular solves against the identity, no product of
+ * inverses.  xwork: apgp_kinv_solve_work_len(n) doubles; kinv: n x n (ld n), the lower
+ * 64 x 64 tiles are written -- pass it as apgp_grad_loglik's `work` with winv = NULL.       */
+int64_t apgp_kinv_solve_work_len(int64_t n);
+int apgp_kinv_solve(const double* L, int64_t n, int64_t ldl, double* xwork, double* kinv, void* stream);
+/* winv == NULL: `work` already holds K^-1 (apgp_kinv_solve); otherwise K^-1 = W^T W is formed there. */
 int apgp_grad_loglik(const double* X, const double* alpha, const double* winv, int64_t ldw,
                      int64_t n, const apgp_kernel_t* kern /*host*/,
                      double* work, double* out, void* stream);

@@ -437,12 +437,60 @@ def cond_ladder(targets=(1e8, 1e11, 1e13)):
         json.dump(meta, fh, indent=1)
 
 
+def _mp_grad_amp2d(theta, y, p, dps=60):
+    """Gradient of the log-likelihood w.r.t. george's parameter vector (mean, log_constant, log_M_0_0, log_M_1_1) of a
+    2-D amplitude * ExpSquared GP (white noise e^-12) in ``dps``-digit mpmath arithmetic, straight from SURVEY.md
+    Appendix A.6: g_mean = sum(alpha), g_k = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_k) with dK/dlog_constant = K
+    (without the white noise) and dK/dlog_M_d = K o (w_d (x_id - x_jd)^2 / 2).  No code shared with the oracle or
+    the HIP path."""
+    import mpmath as mp
+    mp.mp.dps = dps
+    amp = mp.mpf(2) * mp.exp(mp.mpf(float(p[1])))
+    w = [mp.exp(-mp.mpf(float(v))) for v in p[2:]]
+    wn = mp.exp(mp.mpf(-12))
+    X = [[mp.mpf(float(v)) for v in row] for row in theta]
+    n = len(X)
+    Kc = mp.matrix(n, n)           # the kernel part (no white noise)
+    for i in range(n):
+        for j in range(n):
+            Kc[i, j] = amp * mp.exp(-mp.mpf(1) / 2 * sum(w[d] * (X[i][d] - X[j][d]) ** 2 for d in range(2)))
+    K = Kc.copy()
+    for i in range(n):
+        K[i, i] += wn
+    Kinv = mp.inverse(K)
+    r = mp.matrix([mp.mpf(float(v)) - mp.mpf(float(p[0])) for v in y])
+    alpha = Kinv * r
+    g = [sum(alpha[i] for i in range(n))]
+    g.append(sum((alpha[i] * alpha[j] - Kinv[i, j]) * Kc[i, j] for i in range(n) for j in range(n)) / 2)
+    for d in range(2):
+        g.append(sum((alpha[i] * alpha[j] - Kinv[i, j]) * Kc[i, j] * w[d] * (X[i][d] - X[j][d]) ** 2 / 2
+                     for i in range(n) for j in range(n)) / 2)
+    return np.array([float(v) for v in g])
+
+
+def grad_truth():
+    """VERDICT round 3, item 2: every rung of the conditioning ladder and the reference's optimum (8.5e15) get a
+    60-digit mpmath gradient (``grad_truth``) beside the oracle's (``grad``, already in the fixtures), so that the HIP
+    gradient -- through the explicit inverse below the conditioning gate, through triangular solves above it, as george
+    forms K^-1 by cho_solve -- can be judged against exact arithmetic.  Needs no reference import."""
+    for name in ("rosen2d_n50_amp_cond1e8", "rosen2d_n50_amp_cond1e11", "rosen2d_n50_amp_cond1e13",
+                 "rosen2d_n50_amp_opt_illcond"):
+        d = dict(np.load(os.path.join(OUT, name + ".npz")))
+        d["grad_truth"] = _mp_grad_amp2d(d["theta"], d["y"], d["p"])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        err = np.abs(d["grad"] - d["grad_truth"]) / np.abs(d["grad_truth"])
+        print("%s: cond %.3e  gradient truth %s; oracle rel err %s" % (name, float(d["cond"]), d["grad_truth"], err))
+
+
 if __name__ == "__main__":
     if "--d8-truth" in sys.argv:
         d8_truth()          # (augments the committed fixture; needs no reference import)
     elif "--cond-ladder" in sys.argv:
         cond_ladder()       # (adds the three mid-conditioning fixtures; leaves the others alone)
+    elif "--grad-truth" in sys.argv:
+        grad_truth()        # (augments the ladder fixtures and the optimum's; needs no reference import)
     else:
         main()
         d8_truth()
         cond_ladder()
+        grad_truth()

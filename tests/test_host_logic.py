@@ -173,6 +173,28 @@ def test_approxposterior_input_validation():
     assert ap.utility is ut.AGPUtility and ap.ndim == 2
 
 
+def test_on_device_sampler_requires_the_box_prior():
+    """runMCMC(onDevice=True) samples mu(theta) under the box prior only; _gpll adds lnprior(theta)
+    (/root/reference/approxposterior/approx.py:167-188).  Anything but 'constant inside self.bounds, -inf outside'
+    must be refused before the device is touched (the check itself needs no GPU)."""
+    th = np.zeros((3, 2)); y = np.zeros(3)
+    kw = dict(theta=th, y=y, lnlike=lh.rosenbrockLnlike, priorSample=lh.rosenbrockSample, gp=object(), bounds=((-5, 5),) * 2)
+    state = np.random.get_state()[1].copy()
+    approx.ApproxPosterior(lnprior=lh.rosenbrockLnprior, **kw)._requireBoxPrior()            # the box: accepted
+    assert np.array_equal(np.random.get_state()[1], state)                                   # (NumPy's global stream untouched)
+    approx.ApproxPosterior(lnprior=lambda t: lh.rosenbrockLnprior(t) + 3.5, **kw)._requireBoxPrior()   # any constant
+    gauss = lambda t: -0.5 * float(np.sum(np.asarray(t) ** 2)) if np.all(np.abs(t) <= 5) else -np.inf
+    wide = lambda t: 0.0 if np.all(np.abs(t) <= 6) else -np.inf                              # support wider than bounds
+    narrow = lambda t: 0.0 if np.all(np.abs(t) <= 4.999) else -np.inf                        # narrower: corners excluded
+    for bad in (gauss, wide, narrow, lambda t: 0.0):
+        with pytest.raises(ValueError):
+            approx.ApproxPosterior(lnprior=bad, **kw)._requireBoxPrior()
+    ap = approx.ApproxPosterior(lnprior=gauss, **kw)
+    with pytest.raises(ValueError):
+        ap.runMCMC(onDevice=True, cache=False, mcmcKwargs={"iterations": 10, "initial_state": np.zeros((4, 2))},
+                   samplerKwargs={"nwalkers": 4})
+
+
 def test_linear_kernel_sum_protocol_and_flattening():
     """defaultGP(order=...) kernel tree (gpUtils.py:167-173): same names / order / values
     as the oracle's george restatement, and the evaluated form handed to the C ABI."""
