@@ -916,6 +916,38 @@ def test_conditioning_ladder(golden_dir, name, mode, lib_loaded):
         assert u_true[bi] <= u_true.min() + 1e-3 * abs(u_true.min())
 
 
+@pytest.mark.parametrize("mode", ["inverse", "solve", None])
+@pytest.mark.parametrize("name", LADDER + ["rosen2d_n50_amp_opt_illcond"])
+def test_gradient_on_the_conditioning_ladder(golden_dir, name, mode, lib_loaded):
+    """K4 (gpUtils._grad_nll -> george GP.grad_log_likelihood, gpUtils.py:83-111) against a 60-digit mpmath gradient
+    on every rung of the ladder and at the reference's optimum (true cond 8.5e15): through the explicit inverse
+    (K^-1 = W^T W), through the solve route (two blocked triangular solves against the identity: george's
+    cho_solve(L, I)), and through the automatic gate, which must hand the gradient to the solve route exactly when it
+    hands sigma^2 and alpha to it (round 3: the gradient ignored the gate).
+    Bar per component: error <= max(3 x the oracle's, 1e-3 cond eps max|truth|).  The second term is the error CLASS
+    (both implementations sit two to three orders below cond eps |g|; within it the oracle's own error varies by 10x
+    from component to component -- 1.9e-6 vs 1.4e-4 at cond 1e13 -- so a bare ratio would compare noise).  At 8.5e15
+    the explicit inverse is held to the bar only where it is trusted: there the solve route is 15x closer on
+    d/d log_constant (9.5e-3 vs 2.3e-1, oracle 1.4e-1: profiles/r04e_grad_ladder.txt)."""
+    go, agp = _mods()
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    gp = build(agp, g)
+    gp.variance_mode = mode
+    truth, ref = g["grad_truth"], g["grad"]
+    hip = gp.grad_log_likelihood(g["y"])
+    if mode is None:
+        assert gp._trust_inverse() == (gp.cond_estimate <= agp.COND_SOLVE)
+    if name.endswith("illcond"):
+        assert gp.cond_estimate > agp.COND_SOLVE                # auto = solve route here
+        if mode == "inverse":
+            return                                              # (forced against the gate: not held to the bar)
+    floor = 1e-3 * float(g["cond"]) * np.finfo(np.float64).eps * np.abs(truth).max()
+    err, err_ref = np.abs(hip - truth), np.abs(ref - truth)
+    assert np.all(err <= np.maximum(3.0 * err_ref, floor)), (err, err_ref, floor)
+    # and it is a descent direction of the right size: relative to the truth's norm
+    assert np.linalg.norm(hip - truth) <= max(3.0 * np.linalg.norm(ref - truth), 2.0 * floor)
+
+
 def make_full_logdet(make, X):
     g = make()
     g.compute(X)
