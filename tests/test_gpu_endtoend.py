@@ -40,6 +40,34 @@ def test_run_rosenbrock_posterior(tmp_path, monkeypatch):
     assert len(ap.y) >= 50 + 40
 
 
+def test_c1_readme_example_as_written(tmp_path, monkeypatch):
+    """BASELINE.json configs[0] / the README run EXACTLY as the reference writes it
+    (/root/reference/examples/inference/example.py:16-52): seed 57, m0 = 50 prior draws, m = 20, nmax = 2,
+    BAPE, defaultGP(white_noise=-12), 20 walkers x 2e4 iterations, estBurnin, nGPRestarts = 3, onlyLastMCMC -- on
+    the HIP-backed GP, with the statistical assertion of the reference's own run test (test_APRun.py:66-73:
+    posterior means within one 'true sigma' of (0.0, 1.31))."""
+    monkeypatch.chdir(tmp_path)
+    from approxposterior_amd import approx, gpUtils, likelihood as lh
+    m0, m, nmax = 50, 20, 2
+    np.random.seed(57)
+    theta = lh.rosenbrockSample(m0)
+    y = np.zeros(len(theta))
+    for ii in range(len(theta)):
+        y[ii] = lh.rosenbrockLnlike(theta[ii]) + lh.rosenbrockLnprior(theta[ii])
+    gp = gpUtils.defaultGP(theta, y, white_noise=-12)
+    ap = approx.ApproxPosterior(theta=theta, y=y, gp=gp, lnprior=lh.rosenbrockLnprior, lnlike=lh.rosenbrockLnlike,
+                                priorSample=lh.rosenbrockSample, bounds=[(-5, 5), (-5, 5)], algorithm="bape")
+    with np.errstate(all="ignore"):
+        ap.run(m=m, nmax=nmax, estBurnin=True, nGPRestarts=3, mcmcKwargs={"iterations": int(2.0e4)},
+               cache=False, samplerKwargs={"nwalkers": 20}, verbose=False, thinChains=False, onlyLastMCMC=True)
+    assert len(ap.y) == m0 + m * nmax and ap.theta.shape == (m0 + m * nmax, 2)
+    assert ap.sampler.get_chain().shape == (20000, 20, 2)
+    samples = ap.sampler.get_chain(discard=ap.iburns[-1], flat=True, thin=ap.ithins[-1])
+    means = np.mean(samples, axis=0)
+    z = np.fabs((means - np.array([0.0, 1.31])) / np.array([1.5, 1.75]))
+    assert np.all(z < 1), (means, z)
+
+
 def test_bayesopt_1d(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     from approxposterior_amd import approx, gpUtils, likelihood as lh
