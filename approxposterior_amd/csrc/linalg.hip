@@ -804,7 +804,7 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* L, long lo
                                                         double* W, long long ldw) {
     // lane c owns column c of X = L_jj^-1 in registers; row i of L_jj is the same for every lane
     // and comes back as broadcast LDS reads (the bound: ~20 cycles per ds_read_b128 and wavefront,
-    // tools/lat_probe.hip).  Fully unrolled, x[k] = 0 above the diagonal, so the sum runs over all
+    // tools/probes/lat_probe.hip).  Fully unrolled, x[k] = 0 above the diagonal, so the sum runs over all
     // k < i in order: the same operations on the same values as a per-column loop from k = c.
     __shared__ __attribute__((aligned(16))) double Lb[64][66];
     const long long j0 = (long long)blockIdx.x * 64;

@@ -8,7 +8,7 @@
 // section 2).  Operand fragments are those of the 16x16x4 instruction (A: lane = row + 16 k,
 // B: lane = col + 16 k).  The four-block instruction multiplies row group b (rows 4b .. 4b+3)
 // with column group b only, so the product takes four of them with the B fragment rotated by
-// 4 r lanes inside each 16-lane row (DPP row_ror: lane l reads lane l - 4 r, tools/mma16_probe.hip):
+// 4 r lanes inside each 16-lane row (DPP row_ror: lane l reads lane l - 4 r, tools/probes/mma16_probe.hip):
 // rotation r pairs row group b with column group (b - r) & 3.  acc[r] of lane l then holds element
 //     row = 4 * ((l >> 2) & 3) + (l >> 4),   col = 4 * ((((l >> 2) & 3) - r) & 3) + (l & 3).
 // ---------------------------------------------------------------------------

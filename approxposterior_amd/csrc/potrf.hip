@@ -91,7 +91,7 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
 // Wavefront 2 (panel_helper_wave) applies groups 0 .. 7 to columns 32 .. 63 of the diagonal block's
 // rows while wavefront 0 applies them to columns < 32 only, and hands the columns back before
 // group 8: the rank-4 updates are bound by uniform-address LDS reads PER WAVEFRONT (~20 cycles per
-// ds_read_b128, tools/lat_probe.hip), so a second wavefront nearly halves them (factorisation at
+// ds_read_b128, tools/probes/lat_probe.hip), so a second wavefront nearly halves them (factorisation at
 // column 2048: 16.5 -> 12.8 us).
 // Same arithmetic in the same order per element whichever wavefront applies it.
 //

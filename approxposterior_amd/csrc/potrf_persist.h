@@ -31,7 +31,7 @@
 //   whole row step ahead of their use: tile (i, s + 2) is needed at the END of row step s + 1.  Tiles are owned
 //   statically (column-major index modulo the number of update half-workgroups), column s + 2 first.
 //
-// Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility; measured with tools/handoff_probe.hip):
+// Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility; measured with tools/probes/handoff_probe.hip):
 //   payload stores are write-through (sc1), every storing wavefront drains (s_waitcnt vmcnt(0)) before ONE relaxed
 //   agent-scope flag store; consumers poll ONE word relaxed, then either read with sc1 loads (row workgroups) or
 //   take ONE agent-scope acquire per update step and read plainly (update workgroups: operands stay L2-resident).

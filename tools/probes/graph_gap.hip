@@ -1,6 +1,6 @@
 // Developer microbenchmark (GPU box): launch-to-launch time of a chain of dependent tiny kernels on one
 // stream -- plain launches vs one hipGraph replay of the same chain (stream capture).
-//   hipcc --offload-arch=gfx950 -O2 tools/graph_gap.hip -o tools/tmp/graph_gap && tools/tmp/graph_gap
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/graph_gap.hip -o tools/tmp/graph_gap && tools/tmp/graph_gap
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,6 +1,6 @@
 // Probe: do two MFMA wavefronts on one SIMD hide each other's LDS-read issue time, and what
 // does a workgroup barrier per tile cost them?   
-//   build: hipcc --offload-arch=gfx950 -O3 -o tools/mfma_duo tools/mfma_duo.hip ; run: tools/mfma_duo
+//   build: hipcc --offload-arch=gfx950 -O3 -o tools/mfma_duo tools/probes/mfma_duo.hip ; run: tools/mfma_duo
 // Each wavefront runs TILES x [ NG groups of ( 4 x ds_read_b128 , 32 x v_mfma_f64_4x4x4 ) ], the
 // instruction mix of the sweep's matrix role; variants: waves per SIMD (1 or 2), barrier per tile.
 #include <hip/hip_runtime.h>

@@ -1,7 +1,7 @@
 // Probe: what does a feeder wavefront streaming tiles into LDS by LDS-DMA cost the MFMA
 // wavefront on its SIMD, whose own instruction mix (4 ds_read_b128 per 32 MFMAs, one barrier per
-// 256) is within 1 % of the MFMA-only rate in isolation (tools/mfma_duo.hip)?   
-//   build: hipcc --offload-arch=gfx950 -O3 -o tools/mfma_feed tools/mfma_feed.hip ; run: tools/mfma_feed
+// 256) is within 1 % of the MFMA-only rate in isolation (tools/probes/mfma_duo.hip)?   
+//   build: hipcc --offload-arch=gfx950 -O3 -o tools/mfma_feed tools/probes/mfma_feed.hip ; run: tools/mfma_feed
 // Workgroup = 4 matrix wavefronts + 4 feeder wavefronts; per tile each feeder issues NREQ
 // buffer_load ... lds requests (1 KiB each) from a 64 MiB stream, then everybody meets at a barrier.
 #include <hip/hip_runtime.h>

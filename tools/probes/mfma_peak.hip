@@ -1,5 +1,5 @@
 // Micro-benchmark: f64 matrix-core and f64 VALU issue rates on gfx950 (MI355X).
-// hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/mfma_peak && ./tools/mfma_peak
+// hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_peak.hip -o tools/mfma_peak && ./tools/mfma_peak
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef double f64x4 __attribute__((ext_vector_type(4)));
