@@ -948,6 +948,114 @@ def test_gradient_on_the_conditioning_ladder(golden_dir, name, mode, lib_loaded)
     assert np.linalg.norm(hip - truth) <= max(3.0 * np.linalg.norm(ref - truth), 2.0 * floor)
 
 
+# ---- round 4: the Cholesky as ONE persistent launch (csrc/potrf_persist.h) vs the multi-launch path ----------------
+def _nll_eval_raw(lib, torch, X_d, y_d, n, ks, mean, mode):
+    lib.apgp_potrf_mode(mode)
+    try:
+        K = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+        z = torch.empty(n, dtype=torch.float64, device="cuda")
+        info = torch.empty(1, dtype=torch.int32, device="cuda")
+        o5 = torch.empty(5, dtype=torch.float64, device="cuda")
+        o = np.empty(5)
+        rc = lib.apgp_nll_eval(X_d.data_ptr(), n, ctypes.byref(ks), y_d.data_ptr(), mean, K.data_ptr(), z.data_ptr(),
+                               info.data_ptr(), o5.data_ptr(), o.ctypes.data, None)
+        assert rc == 0, lib.apgp_last_error()
+        torch.cuda.synchronize()
+        return torch.tril(K).clone(), z.clone(), o.copy(), int(info.item())
+    finally:
+        lib.apgp_potrf_mode(0)
+
+
+def _persist_case(n, D, seed, wn=-12.0, dup=None):
+    import torch
+    go, agp = _mods()
+    rs = np.random.RandomState(seed)
+    X = rs.uniform(-5, 5, size=(n, D))
+    if dup is not None:
+        X[dup] = X[dup - 1]; X[dup + 1] = X[dup - 1]
+    y = rs.normal(size=n)
+    g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(D, 8.0), ndim=D), fit_mean=True, mean=0.0, white_noise=wn,
+               fit_white_noise=False)
+    g._x = X; g._yerr2 = 0.0
+    return torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda(), g._kernel_struct()
+
+
+@pytest.mark.parametrize("n,D", [(65, 2), (100, 8), (128, 2), (129, 8), (192, 3), (300, 8), (700, 2), (1152, 8), (1153, 8),
+                                 (2048, 8), (3000, 5), (4095, 8), (4096, 8)])
+def test_persistent_cholesky_bit_identical_to_multi_launch(n, D, lib_loaded):
+    """One gpUtils._nll evaluation (gpUtils.py:46-80) through the persistent launch (forced, mode 3: up to n = 4096)
+    and through the launch-per-step path: factor, z = L^-1 (y - mean), the 5-value record and the LAPACK info word are
+    the SAME BITS -- every element sees the same operations in the same order, whatever the hand-offs' timing -- at
+    sizes that are not multiples of the 64-column block, of the 16-column chunk or of anything else; and the
+    persistent launch did not fall back to produce them."""
+    import torch
+    lib = lib_loaded
+    X_d, y_d, ks = _persist_case(n, D, n + D)
+    L1, z1, o1, i1 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.25, 1)
+    fb = lib.apgp_potrf_fallbacks()
+    L3, z3, o3, i3 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.25, 3)
+    assert lib.apgp_potrf_fallbacks() == fb
+    assert i1 == i3 == 0 and np.array_equal(o1, o3)
+    assert torch.equal(L1, L3) and torch.equal(z1, z3)
+    # and the factor is a Cholesky factor: L L^T against the oracle's Gram matrix
+    if n <= 1153:
+        go, agp = _mods()
+        Lh = L3.cpu().numpy()
+        Kh = Lh @ Lh.T
+        Xh = X_d.cpu().numpy()
+        d2 = ((Xh[:, None, :] - Xh[None, :, :]) ** 2).sum(-1) / 8.0
+        Ko = np.exp(-0.5 * d2) + np.exp(-12.0) * np.eye(n)
+        assert np.abs(Kh - Ko).max() <= 1e-12
+
+
+@pytest.mark.parametrize("n,dup", [(200, 70), (700, 650), (1152, 64), (1152, 1100)])
+def test_persistent_cholesky_reports_the_failing_minor(n, dup, lib_loaded):
+    """scipy.linalg.cholesky inside george raises LinAlgError with the order of the first leading minor that is not
+    positive definite; apgp_nll_eval reports it in the record's info slot.  Duplicated points with e^-60 of white
+    noise: the persistent launch must report the multi-launch path's (LAPACK's) order and, like it, never hang on the
+    NaNs that follow the failed pivot."""
+    import torch
+    lib = lib_loaded
+    X_d, y_d, ks = _persist_case(n, 3, 7 * n, wn=-60.0, dup=dup)
+    _, _, o1, i1 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.0, 1)
+    _, _, o3, i3 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.0, 3)
+    assert i1 > 0 and i3 == i1 and o3[4] == o1[4] == i1
+
+
+def test_persistent_cholesky_gives_up_and_falls_back(lib_loaded):
+    """The persistent launch needs all its workgroups resident; when they are not (a foreign kernel holds compute
+    units) it gives up after a bounded wait and apgp_nll_eval re-runs the evaluation on the multi-launch path.
+    Mode 2 makes workgroup 0 give up at once: the call must return the multi-launch result and count one fallback;
+    the next ordinary call runs persistently again (the give-up mark is per call)."""
+    import torch
+    lib = lib_loaded
+    n = 1152
+    X_d, y_d, ks = _persist_case(n, 8, 3)
+    L1, z1, o1, _ = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.0, 1)
+    fb = lib.apgp_potrf_fallbacks()
+    L2, z2, o2, _ = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.0, 2)
+    assert lib.apgp_potrf_fallbacks() == fb + 1
+    assert torch.equal(L2, L1) and torch.equal(z2, z1) and np.array_equal(o2, o1)
+    L0, z0, o0, _ = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.0, 0)
+    assert lib.apgp_potrf_fallbacks() == fb + 1
+    assert torch.equal(L0, L1) and np.array_equal(o0, o1)
+
+
+def test_persistent_cholesky_repeated_calls_leave_no_state(lib_loaded):
+    """Flags and granule tags are call-unique and never zeroed between calls: 120 evaluations in a row -- two
+    training sets of different size alternating on one stream -- must reproduce their first results bit for bit."""
+    import torch
+    lib = lib_loaded
+    cases = [(1152, _persist_case(1152, 8, 3)), (700, _persist_case(700, 2, 4))]
+    first = [_nll_eval_raw(lib, torch, c[0], c[1], n, c[2], 0.0, 0) for n, c in cases]
+    fb = lib.apgp_potrf_fallbacks()
+    for it in range(60):
+        for (n, c), f in zip(cases, first):
+            L, z, o, i = _nll_eval_raw(lib, torch, c[0], c[1], n, c[2], 0.0, 0)
+            assert torch.equal(L, f[0]) and torch.equal(z, f[1]) and np.array_equal(o, f[2])
+    assert lib.apgp_potrf_fallbacks() == fb
+
+
 def make_full_logdet(make, X):
     g = make()
     g.compute(X)
