@@ -241,7 +241,7 @@ struct PpStep {            // what every role derives from (r, s)
     int r, s, bs;
     long long j0;
     bool producer;
-    int* cnt;              // this step's counters: 0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 aprev-free
+    int* cnt;              // this step's counters: 0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 As_prev free
     int* wocnt;
     int* abl;
     double* As_cur;
@@ -255,7 +255,7 @@ __device__ __forceinline__ PpStep pp_step(double* lds, int s_in, long long n) {
     p.bs = (int)((n - p.j0) < PB ? (n - p.j0) : PB);
     p.producer = p.r == p.s + 1;                               // this workgroup's rows are the B operand of the step
     int* ints = (int*)(lds + PP_INTS);
-    // step-parity counters: [par][0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 aprev-free]; others: 16 wocnt | 17, 18 "give up" by
+    // step-parity counters: [par][0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 As_prev free]; others: 16 wocnt | 17, 18 "give up" by
     // step parity (set during step s, read at the head of step s + 1: never while it may still be written)
     p.cnt = ints + 8 * (p.s & 1);
     p.wocnt = ints + 16;
@@ -264,6 +264,7 @@ __device__ __forceinline__ PpStep pp_step(double* lds, int s_in, long long n) {
     p.As_prev = lds + PP_AS + ((p.s & 1) ^ 1) * 4 * PP_CHUNK;  // L(r, s-1); at the step's end: the hand-over of the next tile
     return p;
 }
+
 
 // ---------------- wavefront 0: the diagonal block (s, s); at step r also z_r ----------------
 __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
@@ -276,16 +277,15 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     const PpStep p = pp_step(lds, s_in, n);
     if (lane == 0) {
         int* nx = (int*)(lds + PP_INTS) + 8 * ((s_in + 1) & 1);   // the next step's counters (nobody uses them before the barrier)
-        nx[0] = 0; nx[1] = 0; nx[2] = 0; nx[3] = 0; nx[4] = 0; nx[5] = 0; nx[6] = 0;
+        nx[0] = 0; nx[1] = 0; nx[2] = 0; nx[3] = 0; nx[4] = 0; nx[5] = 0; nx[6] = 0; nx[7] = 0;
     }
     double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
     double* invd = lds + PP_INVD;
     double* zblk = lds + PP_ZBLK;
     const double* zrow = lds + PP_ZROW;
     const int bs = p.bs, s = p.s, r = p.r;
-    double rowv[PB];                                           // row `lane` of the diagonal block
     PP_STAMP(s, 0);
-    PP_STAMPP(s, 16);
+    double rowv[PB];                                           // row `lane` of the diagonal block
 #pragma unroll
     for (int k = 0; k < PB; k += 2) {
         const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
@@ -369,7 +369,6 @@ __device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
     }
     pp_solve_wave(lane, rowv, Ls, lds + PP_INVD, p.cnt + 0, p.As_cur, p.cnt + 2);
     PP_STAMP(p.s, 2);
-    PP_STAMPP(p.s, 17);
     }
     PP_STEP_LOOP_END()
 }
@@ -424,6 +423,7 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
         }
         PP_STAMP(s, 7);
     }
+    lds_store_volatile(p.cnt + 6, 1);                          // (done with As_prev = L(r, s-1): wavefront 2 may stage the next tile's values there)
     if (!dead && r == s) {
         zrow[lane] = rhs_r;
         lds_store_volatile(zflag, 1);
@@ -464,9 +464,7 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
                 const pp_u32x4 g = {(unsigned)__double2loint(xs[k]), tag, (unsigned)__double2hiint(xs[k]), tag};
                 __builtin_amdgcn_raw_buffer_store_b128(g, rs_strm, (unsigned)(lane * 64 + k * 16), (unsigned)((s * 16 + cc) * 4096), 16);
             }
-            if (cc == 0) PP_STAMPP(s, 19);
         });
-        PP_STAMPP(s, 18);
     }
     if (dead) {
         // release whoever waits for this wavefront; everybody leaves at the next step's head
@@ -499,14 +497,13 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     pp_args_ptr q = pp_args(karg);
     double* lds = pp_lds_base(lds_off);
     const int t = threadIdx.x, lane = t & 63;
-    const long long n = q->a.n, lda = q->a.lda;
-    double* A = q->a.A;
+    const long long n = q->a.n;
     PP_STEP_LOOP_BEGIN(lds)
     const PpStep p = pp_step(lds, s_in, n);
     const int s = p.s, r = p.r;
     double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
     const double* Bs = lds + PP_BS;
-    int* prog = p.cnt + 0; int* xprog = p.cnt + 2; int* bprog = p.cnt + 3;
+    int* xprog = p.cnt + 2; int* bprog = p.cnt + 3;
     const int mw = __builtin_amdgcn_readfirstlane((t >> 6) - 4);
     const int wr = (mw >> 1) * 32, wc = (mw & 1) * 32;
     bool dead = false;
@@ -514,15 +511,13 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     int bcol[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) bcol[rr] = ((lane & 15) - 4 * rr) & 15;
-    double v[2][2][4], v2[2][2][4], cin[2][2][4], cin2[2][2][4];
+    double v[2][2][4], v2[2][2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { v[i][j][rr] = 0.0; v2[i][j][rr] = 0.0; cin[i][j][rr] = 0.0; cin2[i][j][rr] = 0.0; }
-    const long long base_n = p.j0 + PB;                        // first row / column of the next block column
-    const long long ri0 = (long long)r * PB;
+            for (int rr = 0; rr < 4; ++rr) { v[i][j][rr] = 0.0; v2[i][j][rr] = 0.0; }
     const bool producer = p.producer;
     auto ksteps = [&](auto lo_, auto hi_) {
         constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
@@ -537,69 +532,24 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
             }
         });
     };
-    // the tiles' values in memory (block columns < s applied by the update workgroups) are requested as soon as wavefront 2
-    // has seen their flags (an LDS word), and used last
-    int* cflag = p.cnt + 5;
-    // one (i, j) block of four elements of both tiles per call: eight 8-byte loads.  The sixteen-row accumulator layout makes
-    // every load touch sixteen cache lines (~60 cycles of address processing each): all 64 in one go held the k-steps up
-    // for 2.5-3 us -- spread over eight k-steps they fit the slack between two arriving groups.
-    auto request = [&](auto b_) {
-        constexpr int b = decltype(b_)::value, i = b >> 1, j = b & 1;
-        // (the lane's row / column numbers are recomputed from an opaque copy of the lane number: kept live from the
-        // function's head they were spilled, and a scratch reload between the loads waits for every load before it)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            // (UNCONDITIONAL loads from clamped addresses, masked when used: a load under a per-lane condition has to
-            // land at the join -- hipcc put an s_waitcnt vmcnt(0) behind each, 8 us for all of them)
-            const int lr = wr + 16 * i + apgp_mma16_row(ln), lc = wc + 16 * j + apgp_mma16_col(ln, rr);
-            const long long gr = ri0 + lr, gc = base_n + lc;
-            const long long grc = gr < n ? gr : n - 1, gcc = gc < n ? gc : n - 1;
-            cin[i][j][rr] = pp_ld_f64(A + grc * lda + gcc);
-            // (the next diagonal block: full for every consumer; the producer -- whose own tile it is -- loads the same
-            // clamped element twice rather than branch)
-            const long long dr = base_n + lr < n ? base_n + lr : n - 1, dc = base_n + lc < n ? base_n + lc : n - 1;
-            cin2[i][j][rr] = pp_ld_f64(A + dr * lda + dc);
-        }
-    };
-    // Two straight-line paths, no conditional request in between (a load issued under a condition has to land at the
-    // join for the merged registers: every look that fired cost a memory round trip, 2 us per k-step measured):
-    // flags up after k-step 6 (the normal case: they rise ~8 us into the step) -> a quarter of the requests after each of
-    // the k-steps 6 .. 9; otherwise all of them before k-step 14.
+    // No memory access in these wavefronts: the tiles' values in memory are fetched by wavefront 2 once its helper duty is
+    // over (coalesced, into the LDS places of the hand-over) and the products are subtracted from them there.  (With the 64 requests here, in the accumulator layout -- sixteen cache lines per
+    // load -- the k-steps stood still for 2.5-3 us and were three groups behind when the last group arrived.)
     ksteps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
     if (mw == 0) PP_STAMP(s, 11);
     ksteps(std::integral_constant<int, 1>{}, std::integral_constant<int, 6>{});
     if (mw == 0) PP_STAMP(s, 9);
-    ksteps(std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{});
-    if (mw == 0) PP_STAMP(s, 13);
-    if (lds_load_volatile(cflag) == 1) {
-        static_for<4>([&](auto b_) {
-            constexpr int b = decltype(b_)::value;
-            request(std::integral_constant<int, b>{});
-            ksteps(std::integral_constant<int, 7 + b>{}, std::integral_constant<int, 8 + b>{});
-        });
-        if (mw == 0) PP_STAMP(s, 5);
-        ksteps(std::integral_constant<int, 11>{}, std::integral_constant<int, 13>{});
-        if (mw == 0) PP_STAMP(s, 12);
-        ksteps(std::integral_constant<int, 13>{}, std::integral_constant<int, 15>{});
-    } else {
-        ksteps(std::integral_constant<int, 7>{}, std::integral_constant<int, 13>{});
-        if (mw == 0) PP_STAMP(s, 12);
-        ksteps(std::integral_constant<int, 13>{}, std::integral_constant<int, 14>{});
-        PANEL_SPIN_WHILE(lds_load_volatile(cflag) == 0);
-        if (lds_load_volatile(cflag) == 1) static_for<4>([&](auto b_) { request(b_); });
-        else dead = true;
-        if (mw == 0) PP_STAMP(s, 5);
-        ksteps(std::integral_constant<int, 14>{}, std::integral_constant<int, 15>{});
-    }
+    ksteps(std::integral_constant<int, 6>{}, std::integral_constant<int, 13>{});
+    if (mw == 0) PP_STAMP(s, 12);
+    ksteps(std::integral_constant<int, 13>{}, std::integral_constant<int, 15>{});
     if (mw == 0) PP_STAMP(s, 14);
-    // (what the hand-over below waits for besides the last group -- polled here, where it costs nothing)
-    pp_lds_wait_ge(prog, PB + 1);                              // (wavefronts 0 / 2 are done with Ls: the factorisation ends before the last solved group is out)
     ksteps(std::integral_constant<int, 15>{}, std::integral_constant<int, 16>{});
     if (mw == 0) PP_STAMP(s, 4);
-    // hand-over: next tile -> the free parity of As ([64][66]) for wavefront 1, next diagonal block -> Ls
-    pp_lds_wait_ge(bprog, 16);                                 // (wavefront 3 is done with As_prev and -- forwarding or receiving -- with the groups; wavefront 1: xprog = 16 above)
+    // hand-over: the staged values minus the products, in place -- the next tile in the free parity of As ([64][66]) for
+    // wavefront 1, the next diagonal block in Ls (staged there by wavefront 2)
+    pp_lds_wait_ge(p.cnt + 5, 1);
+    if (lds_load_volatile(p.cnt + 5) != 1) dead = true;
+    if (mw == 0) PP_STAMP(s, 5);
     double (*St)[PB + 2] = (double (*)[PB + 2])p.As_prev;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -608,16 +558,134 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
-                const long long gr = ri0 + lr, gc = base_n + lc;
-                if (producer) Ls[lr][lc] = ((gr < n && gc < n && gc <= gr) ? cin[i][j][rr] : 0.0) - v[i][j][rr];
+                if (producer) Ls[lr][lc] = Ls[lr][lc] - v[i][j][rr];
                 else {
-                    St[lr][lc] = (gr < n ? cin[i][j][rr] : 0.0) - v[i][j][rr];       // (gc < ri0 <= gr, gc < n)
-                    Ls[lr][lc] = (lc <= lr ? cin2[i][j][rr] : 0.0) - v2[i][j][rr];
+                    St[lr][lc] = St[lr][lc] - v[i][j][rr];
+                    Ls[lr][lc] = Ls[lr][lc] - v2[i][j][rr];
                 }
             }
     if (mw == 0) PP_STAMP(s, 6);
     if (dead) lds_store_volatile(p.abl, 1);
     }
+    PP_STEP_LOOP_END()
+}
+
+// ---------------- wavefront 2: the factorisation's helper for the first eight column groups; then -- idle otherwise -- it
+// watches the flags of the two tiles the matrix wavefronts subtract their products from (tile (r, s+1) and the next
+// diagonal block, finished by the update workgroups during this step), fetches their values and stages them in LDS
+// exactly where the hand-over puts the differences: the tile in the free parity of As as soon as wavefront 3 is done
+// with it, the diagonal block -- held in registers meanwhile -- in Ls once the factorisation and the solving wavefront
+// have left it.  The matrix wavefronts then touch no memory at all (with the requests in their own stream -- sixteen
+// cache lines per accumulator-layout load -- the k-steps stood still for 2.5-3 us and were three groups behind when
+// the last group arrived).  The staging is a function of its own, called once per step: inlined beside
+// panel_helper_wave its 128 registers of tile values made the helper's loop spill, and the factorisation waits for
+// the helper; the call's register saves fall into idle time.
+__device__ PP_NOINLINE void pp_stage_tiles(unsigned lds_off, PpKarg karg, int s_arg) {
+    pp_args_ptr q = pp_args(karg);
+    double* lds = pp_lds_base(lds_off);
+    const int lane = threadIdx.x & 63;
+    const int r = (int)blockIdx.x;
+    const int s = __builtin_amdgcn_readfirstlane(s_arg);
+    const long long n = q->a.n, lda = q->a.lda;
+    pp_u64* ctl = q->ctl;
+    const pp_u64 call_id = q->call_id, timeout = q->timeout;
+    int* ints = (int*)(lds + PP_INTS);
+    int* cnt = ints + 8 * (s & 1);
+    const long long base_n = (long long)(s + 1) * PB;
+    bool up = s + 1 < 2;
+    if (!up) {
+        const pp_u64* f0 = ctl + PP_CTL_TILEFINAL + (long long)r * 64 + (s + 1);
+        const pp_u64* f1 = ctl + PP_CTL_TILEFINAL + (long long)(s + 1) * 64 + (s + 1);
+        PpSpin sp;
+        for (;;) {
+            const pp_u64 f = lane == 0 ? pp_ld(f0) : (lane == 1 ? pp_ld(f1) : call_id);
+            if (__all(f == call_id)) { up = true; break; }
+            if (pp_give_up(sp, ctl, call_id, timeout)) break;
+        }
+    }
+    PP_STAMP(s, 17);
+    if (!up) lds_store_volatile(ints + 17 + (s & 1), 1);       // (gave up: everybody leaves at the next step's head)
+    else {
+        const __amdgpu_buffer_rsrc_t rs_A = __builtin_amdgcn_make_buffer_rsrc((void*)q->a.A, 0, (int)(lda * n * 8), 0x00020000);
+        // (address arithmetic from an opaque lane copy: step-invariant, it would be hoisted, spilled and reloaded between
+        // the loads -- each scratch reload waits for every earlier load; loads unconditional, masks at the LDS writes)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        // (32-bit index arithmetic throughout: the byte offsets fit the 2 GiB buffer descriptor, and 64-bit row / column
+        // numbers beside the 128 registers of tile values made the diagonal block's writes spill -- each scratch reload
+        // a memory round trip, 4 us for the block)
+        const int ni = (int)n, ldai = (int)lda, bn = (int)base_n;
+        f64x2 tv[32];
+        if (r > s + 1) {
+            double (*St)[PB + 2] = (double (*)[PB + 2])(lds + PP_AS + ((s & 1) ^ 1) * 4 * PP_CHUNK);
+            const int ri0 = r * PB, nrow = ni - ri0;           // rows of the tile inside the matrix
+#pragma unroll
+            for (int it = 0; it < 32; ++it) {
+                const int e = it * 64 + ln, rw = e >> 5, col = 2 * (e & 31);
+                const int gr = rw < nrow ? ri0 + rw : ni - 1;
+                tv[it] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_A, (unsigned)(gr * ldai + bn + col) * 8u, 0, 16));
+            }
+            pp_lds_wait_ge(cnt + 6, 1);                        // (wavefront 3 is done with L(r, s-1) in this parity of As)
+#pragma unroll
+            for (int it = 0; it < 32; ++it) {
+                const int e = it * 64 + ln, rw = e >> 5, col = 2 * (e & 31);
+                const f64x2 zero = {0.0, 0.0};
+                *(f64x2*)(&St[rw][col]) = rw < nrow ? tv[it] : zero;
+            }
+            PP_STAMP(s, 18);
+        }
+        double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
+        const int nrem = ni - bn;                              // rows = columns of the next diagonal block inside the matrix
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            const int e = it * 64 + ln, rw = e >> 5, col = 2 * (e & 31);
+            const int gr = rw < nrem ? bn + rw : ni - 1;
+            const int gc = col + 1 < nrem ? bn + col : (ni >= 2 ? ni - 2 : 0);   // (a pair past the matrix: one column to the left)
+            tv[it] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_A, (unsigned)(gr * ldai + gc) * 8u, 0, 16));
+        }
+        // the masks while the factorisation is still running (this wavefront shares its SIMD with a matrix wavefront: its
+        // VALU instructions get a slot every ~32 cycles -- done after the wait they cost 2.5 us of critical path) ...
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            const int e = it * 64 + ln, rw = e >> 5, col = 2 * (e & 31);
+            const int lim = rw < nrem ? (rw < nrem - 1 ? rw : nrem - 1) : -1;   // last column kept in this row (lower triangle, inside the matrix)
+            f64x2 x;
+            x.x = col <= lim ? (col + 1 == nrem ? tv[it].y : tv[it].x) : 0.0;   // (col + 1 == nrem: the pair was loaded one column to the left)
+            x.y = col + 1 <= lim ? tv[it].y : 0.0;
+            tv[it] = x;
+        }
+        unsigned la[32];                                       // (... and the LDS addresses)
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            const int e = it * 64 + ln, rw = e >> 5, col = 2 * (e & 31);
+            la[it] = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&Ls[rw][col];
+        }
+#pragma unroll
+        for (int it = 0; it < 32; ++it) asm volatile("" : "+v"(tv[it]), "+v"(la[it]));
+        pp_lds_wait_ge(cnt + 0, PB + 1);                       // (the factorisation has left Ls ...)
+        pp_lds_wait_ge(cnt + 2, PB / CB);                      // (... and the solving wavefront has read its last group of the factor)
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int it = 0; it < 32; ++it)
+            *(__attribute__((address_space(3))) f64x2*)(size_t)la[it] = tv[it];
+        __builtin_amdgcn_s_setprio(0);
+        PP_STAMP(s, 19);
+    }
+    lds_store_volatile(cnt + 5, up ? 1 : 2);                   // 1: the tiles' values are where the differences go | 2: gave up
+}
+
+__device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
+    pp_args_ptr q = pp_args(karg);
+    double* lds = pp_lds_base(lds_off);
+    const int lane = threadIdx.x & 63;
+    const long long n = q->a.n;
+    double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
+    PP_STEP_LOOP_BEGIN(lds)
+    const long long j0 = (long long)s_in * PB;
+    int* cnt = (int*)(lds + PP_INTS) + 8 * (s_in & 1);
+    panel_helper_wave((int)((n - j0) < PB ? (n - j0) : PB), lane, Ls, cnt + 0, cnt + 1);
+    PP_STAMP(s_in, 16);
+    if (r_ > s_in) pp_stage_tiles(lds_off, karg, s_in);
     PP_STEP_LOOP_END()
 }
 
@@ -655,31 +723,7 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
     else if (w == 1) pp_role_solve(lds_off, karg);
     else if (w == 3) pp_role_recv(lds_off, karg, rhs_r);
     else if (w >= 4) pp_role_matrix(lds_off, karg);
-    else {
-        PP_STEP_LOOP_BEGIN(lds)
-        const long long j0 = (long long)s_in * PB;
-        int* cnt = ints + 8 * (s_in & 1);
-        panel_helper_wave((int)((n - j0) < PB ? (n - j0) : PB), lane, Ls, cnt + 0, cnt + 1);
-        // ... then -- idle otherwise -- it watches the flags of the two tiles the matrix wavefronts subtract their products
-        // from (tile (r, s+1) and the next diagonal block, finished by the update workgroups during this step) and raises an
-        // LDS word: a global poll in a matrix wavefront costs it a memory round trip per look (2 us per k-step measured)
-        if (r > s_in) {
-            bool up = s_in + 1 < 2;
-            if (!up) {
-                const pp_u64* f0 = q.ctl + PP_CTL_TILEFINAL + (long long)r * 64 + (s_in + 1);
-                const pp_u64* f1 = q.ctl + PP_CTL_TILEFINAL + (long long)(s_in + 1) * 64 + (s_in + 1);
-                PpSpin sp;
-                for (;;) {
-                    const pp_u64 f = lane == 0 ? pp_ld(f0) : (lane == 1 ? pp_ld(f1) : q.call_id);
-                    if (__all(f == q.call_id)) { up = true; break; }
-                    if (pp_give_up(sp, q.ctl, q.call_id, q.timeout)) break;
-                }
-            }
-            if (!up) lds_store_volatile(ints + 17 + (s_in & 1), 1);      // (gave up: everybody leaves at the next step's head)
-            lds_store_volatile(cnt + 5, up ? 1 : 2);                   // 1: the tiles' values may be requested | 2: never
-        }
-        PP_STEP_LOOP_END()
-    }
+    else pp_role_helper(lds_off, karg);
 }
 
 // ---------------------------------------------------------------------------
