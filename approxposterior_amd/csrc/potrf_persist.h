@@ -878,15 +878,19 @@ __device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) ccur[i][rr] = cin[i][rr];
             }
-            pp_drain();
-            __syncthreads();                                             // (every wavefront's stores drained; the next operands staged)
+            // column s + 2 is awaited by the row workgroups: its stores are drained (every wavefront, then the barrier) before
+            // the flag.  The other tiles' stores only have to be in memory before this workgroup reads the tiles again, an
+            // update step later: ONE drain at the end of the step (a write-through store's acknowledgement takes 1-2 us)
+            const bool fin = cur.active && cur.q == s + 2;
+            if (fin) pp_drain();
+            __syncthreads();                                             // (the next operands staged; this buffer free)
             if (first) PP_USTAMP(s, 4);
             first = false;
-            // column s + 2 now carries every block column the update workgroups owe it
-            if (cur.active && cur.q == s + 2 && t == 0) pp_st(q.ctl + PP_CTL_TILEFINAL + (cur.ri / PB) * 64 + cur.q, q.call_id);
+            if (fin && t == 0) pp_st(q.ctl + PP_CTL_TILEFINAL + (cur.ri / PB) * 64 + cur.q, q.call_id);
             if (!nxt.active) break;
             cur = nxt;
         }
+        pp_drain();
         PP_USTAMP(s, 5);
     }
 }
