@@ -58,6 +58,7 @@ SIGNATURES = {
     "apgp_potrf_fallbacks": (_I64, []),
     "apgp_nll_eval_batch": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "apgp_trsv": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, ctypes.c_int, _P, _P, _P]),
+    "apgp_trsv_mode": (ctypes.c_int, [ctypes.c_int]),
     "apgp_append_diag": (ctypes.c_int, [_P, _P, _F64, _P, _I64, _P]),
     "apgp_winv_apply_work_len": (_I64, [_I64]),
     "apgp_winv_apply": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, ctypes.c_int, _P, _P, _P, _P]),

@@ -6,6 +6,7 @@
 #include "apgp_common.h"
 #include "mma16.h"
 #include "scratch.h"
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <type_traits>
@@ -435,11 +436,225 @@ __global__ __launch_bounds__(256) void trsv_step4_kernel(TrsvStepArgs a) {
     if (w == 0 && (TRANS || i0 + lane < n)) a.r[i0 + lane] = racc;
 }
 
+// ---------------------------------------------------------------------------
+// K3, persistent (round 4): the blocked solve as ONE launch.  The launch-per-256-rows chain above costs its dependency
+// (~7 us store -> first load of the next launch) 16 times at N = 4096 (0.59 / 0.43 ms); here workgroup j owns block row
+// j (transposed: block column j), keeps its right-hand side block in a register per row, and is handed the solved
+// blocks it depends on as data-tagged granules ({value half, tag} in one 8-byte word, 16 bytes per value, 1 KB per
+// block: no flag, no fence; tools/probes/handoff_probe.hip: ~1 us idle) in dependency order; its tiles are requested
+// one ahead.  A block costs its producer the 64-step diagonal solve + one hand-off instead of a launch.
+// Roles come from a ticket (one atomic add per workgroup), not from blockIdx: a workgroup only ever waits for blocks
+// whose tickets were drawn before its own, i.e. for workgroups that are already running -- no assumption about
+// dispatch order or residency, so the spins cannot deadlock (they are bounded anyway: on timeout the block is written
+// as NaN and *err set).
+// Arithmetic per element = trsv_step4_kernel's (a tile's product is the four wavefronts' 16-term FMA chains added
+// pairwise, tiles subtracted in block order, the diagonal block by the same substitution; x.x accumulated block by
+// block in solving order), so the solution carries the same bits.
+// ---------------------------------------------------------------------------
+static std::atomic<int> g_trsv_multi_launch{0};
+// test / profiling switch: 1 = the launch-per-256-rows path (not read from the environment); returns the previous value
+extern "C" int apgp_trsv_mode(int multi_launch) {
+    if (multi_launch < 0) return g_trsv_multi_launch.load();
+    return g_trsv_multi_launch.exchange(multi_launch ? 1 : 0);
+}
+
+struct TrsvPArgs {
+    const double* L;
+    const double* b;
+    double* x;
+    double* sumsq;
+    long long n, ldl;
+    double shift;
+    unsigned long long* ticket;          // monotonic across calls; this call's tickets start at ticket_base
+    unsigned long long ticket_base;
+    unsigned long long* gran;            // [256 blocks][65 values][2 words]
+    unsigned long long timeout;          // 100 MHz ticks
+    int* err;
+    unsigned tag;
+};
+
+template <int TRANS>
+__global__ __launch_bounds__(256) void trsv_persist_kernel(TrsvPArgs a) {
+    __shared__ double Lb[64][65];
+    __shared__ double zb[64];
+    __shared__ double part[4][64];
+    __shared__ int ord_s, bad_s;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long n = a.n;
+    const int nb = (int)((n + 63) / 64);
+    if (t == 0) {
+        ord_s = (int)(__hip_atomic_fetch_add(a.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ticket_base);
+        bad_s = 0;
+    }
+    __syncthreads();
+    const int ord = ord_s;                                     // position in solving order
+    if (ord < 0 || ord >= nb) return;
+    const int j = TRANS ? nb - 1 - ord : ord;
+    const long long j0 = (long long)j * 64;
+    const int bs = (int)((n - j0) < 64 ? (n - j0) : 64);
+    double dg[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = 16 * w + q;
+        dg[q] = (r < bs && lane <= r) ? a.L[(j0 + r) * a.ldl + j0 + lane] : ((r == lane) ? 1.0 : 0.0);
+    }
+    double rj = (w == 0 && lane < bs) ? a.b[j0 + lane] - a.shift : 0.0;
+    double srun = 0.0;                                         // x.x of the blocks solved before this one (wavefront 0)
+    // this workgroup's tile against solved block p (in solving order): forward element (row j0 + lane, column k0 + 16 w + q)
+    // -- one 128-byte line per lane --, transposed element (row k0 + 16 w + q, column j0 + lane)
+    auto tile = [&](int p, double (&ob)[16]) {
+        const int k = TRANS ? nb - 1 - p : p;
+        const long long k0 = (long long)k * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const long long kk = k0 + 16 * w + q;
+            if (!TRANS) ob[q] = (lane < bs) ? a.L[(j0 + lane) * a.ldl + kk] : 0.0;             // (kk < j0 <= n)
+            else ob[q] = (kk < n && lane < bs) ? a.L[kk * a.ldl + j0 + lane] : 0.0;
+        }
+    };
+    // the diagonal block's row / column of this lane and its reciprocal pivot are in registers BEFORE the solved blocks
+    // arrive (wavefront 0): after the last one only its tile's product and the 64-step substitution remain
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Lb[16 * w + q][lane] = dg[q];                 // (coalesced: lane = column)
+    __syncthreads();
+    double v[64], inv = 1.0;
+    if (w == 0) {
+        inv = 1.0 / Lb[lane][lane];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) v[k] = TRANS ? Lb[k][lane] : Lb[lane][k];   // column / row `lane` of the block
+    }
+    double obn[16];
+    if (ord > 0) tile(0, obn);
+    for (int p = 0; p < ord; ++p) {
+        double ob[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ob[q] = obn[q];
+        if (p + 1 < ord) tile(p + 1, obn);                      // (the next tile's loads fly while this block is awaited)
+        if (w == 0) {
+            const int k = TRANS ? nb - 1 - p : p;
+            // ONE 16-byte write-through-coherent load per lane and look (lane 0: a second one for the running sum), no sleep
+            // between looks: this wavefront has nothing else to do, and the block it waits for is the critical path
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, 256 * 65 * 16, 0x00020000);
+            const bool want_s = p == ord - 1;                   // (the running x.x travels with the immediate predecessor)
+            u32x4_t g, gs = {0u, a.tag, 0u, a.tag};
+            unsigned long long t0 = 0;
+            unsigned it = 0;
+            bool gave_up = false;
+            for (;;) {
+                g = __builtin_amdgcn_raw_buffer_load_b128(rsg, (unsigned)(lane * 16), (unsigned)(k * 65 * 16), 16);
+                if (want_s) gs = __builtin_amdgcn_raw_buffer_load_b128(rsg, (unsigned)(64 * 16), (unsigned)(k * 65 * 16), 16);
+                const bool ok = g.y == a.tag && g.w == a.tag && gs.y == a.tag && gs.w == a.tag;
+                if (__all(ok)) break;
+                if ((++it & 63u) == 0) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > a.timeout) { gave_up = true; break; }
+                }
+            }
+            const unsigned long long g0 = g.x, g1 = g.z, s0 = gs.x, s1 = gs.z;
+            if (gave_up) {
+                if (lane == 0) { bad_s = 1; atomicExch(a.err, 1); }
+                zb[lane] = __builtin_nan("");
+            } else {
+                zb[lane] = __hiloint2double((int)(unsigned)g1, (int)(unsigned)g0);
+                if (want_s) srun = __hiloint2double((int)(unsigned)s1, (int)(unsigned)s0);
+            }
+        }
+        __syncthreads();                                         // (zb in place; part free: the previous tile's sum was consumed)
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = fma(ob[q], zb[16 * w + q], acc);
+        part[w][lane] = acc;
+        __syncthreads();
+        if (w == 0) rj = rj - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    }
+    if (w != 0) return;
+    double ri = rj;
+    if (!TRANS) {
+        trtri_static_for<64>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double zk = trsv_bcast(ri, k) * trsv_bcast(inv, k);
+            ri = lane == k ? zk : (lane > k ? fma(-v[k], zk, ri) : ri);
+        });
+    } else {
+        trtri_static_for<64>([&](auto kc) {
+            constexpr int k = 63 - decltype(kc)::value;
+            const double xk = trsv_bcast(ri, k) * trsv_bcast(inv, k);
+            ri = lane == k ? xk : (lane < k ? fma(-v[k], xk, ri) : ri);   // (L^T)[lane][k] = L[k][lane]
+        });
+    }
+    const double xo = lane < bs ? ri : 0.0;
+    double ss = lane < bs ? ri * ri : 0.0;
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const double snew = srun + ss;                               // (*sumsq += ss, block after block in solving order)
+    if (ord + 1 < nb) {
+        // hand the block on: 16 bytes per value, one write-through store per lane; the running sum as the 65th value
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, 256 * 65 * 16, 0x00020000);
+        const u32x4_t g = {(unsigned)__double2loint(xo), a.tag, (unsigned)__double2hiint(xo), a.tag};
+        __builtin_amdgcn_raw_buffer_store_b128(g, rs, (unsigned)(lane * 16), (unsigned)(j * 65 * 16), 16);
+        if (lane == 0) {
+            const u32x4_t gs = {(unsigned)__double2loint(snew), a.tag, (unsigned)__double2hiint(snew), a.tag};
+            __builtin_amdgcn_raw_buffer_store_b128(gs, rs, (unsigned)(64 * 16), (unsigned)(j * 65 * 16), 16);
+        }
+    }
+    if (lane < bs) a.x[j0 + lane] = bad_s ? __builtin_nan("") : ri;
+    if (a.sumsq && ord + 1 == nb && lane == 0) *a.sumsq = bad_s ? __builtin_nan("") : snew;
+}
+
+// words of stream scratch (slot 3) the persistent solve keeps: [0] ticket counter, [8 ...] granules
+#define TRSV_P_WORDS (8 + 256 * 65 * 2)
+#define TRSV_P_MAX_NB 256
+
 extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
                          int trans, double* x, double* sumsq, void* stream) {
     APGP_CHECK_ARG(L && b && x, "null pointer");
     APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
     hipStream_t st = (hipStream_t)stream;
+    if (n >= 256 && (n + 63) / 64 <= TRSV_P_MAX_NB && !g_trsv_multi_launch.load()) {
+        // ONE persistent launch (trsv_persist_kernel): flags-free granule hand-offs, call-unique tags and tickets (the
+        // scratch is zeroed when it is allocated, never between calls); b may alias x (a block's owner alone touches it)
+        std::lock_guard<std::mutex> enqueue_lock(apgp_stream_lock(st));
+        bool fresh = false;
+        unsigned long long* calls = nullptr;
+        unsigned long long* pw = (unsigned long long*)apgp_stream_scratch_ex(3, st, (size_t)TRSV_P_WORDS + 8, &fresh, &calls);
+        if (!pw) {
+            apgp_set_error("apgp_trsv: scratch allocation failed");
+            return -2;
+        }
+        // calls[0] doubles as the ticket base (tickets handed out so far); the tag is a second counter kept in word 1..
+        // (both live with the scratch entry: a fresh buffer starts them over)
+        if (fresh) {
+            if (hipMemsetAsync(pw, 0, ((size_t)TRSV_P_WORDS + 8) * 8, st) != hipSuccess) {
+                apgp_set_error("apgp_trsv: memset failed");
+                return -2;
+            }
+            *calls = 0;
+        }
+        const long long nb = (n + 63) / 64;
+        TrsvPArgs pa;
+        pa.L = L; pa.b = b; pa.x = x; pa.sumsq = sumsq; pa.n = n; pa.ldl = ldl; pa.shift = shift;
+        pa.ticket = pw; pa.ticket_base = *calls & 0xffffffffffull;          // low 40 bits: tickets drawn by earlier calls
+        pa.gran = pw + 8;
+        pa.timeout = 5000000ull;                                           // 50 ms of the 100 MHz clock
+        pa.err = (int*)(pw + 4);
+        unsigned long long ncall = (*calls >> 40) + 1;                     // high bits: calls so far -> the granule tag
+        if ((unsigned)ncall == 0u || ncall >= (1ull << 23)) {
+            // (the tag space of this buffer is used up: start over on a zeroed buffer)
+            if (hipMemsetAsync(pw, 0, ((size_t)TRSV_P_WORDS + 8) * 8, st) != hipSuccess) {
+                apgp_set_error("apgp_trsv: memset failed");
+                return -2;
+            }
+            *calls = 0; ncall = 1; pa.ticket_base = 0;
+        }
+        pa.tag = (unsigned)ncall;
+        *calls = (ncall << 40) | ((pa.ticket_base + (unsigned long long)nb) & 0xffffffffffull);
+        if (!trans) hipLaunchKernelGGL(trsv_persist_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, pa);
+        else hipLaunchKernelGGL(trsv_persist_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, pa);
+        APGP_CHECK_LAUNCH();
+        return 0;
+    }
     if (n >= 256) {
         // blocked form (trsv_step4_kernel): one small launch per 256 rows (round 2, trsv_step_kernel: per 64-row block (~10 us each, bound by the
         // launch-to-launch dependency; the single-workgroup form below costs ~10 us per block at N = 512

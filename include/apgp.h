@@ -193,6 +193,11 @@ int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch,
  * library per (device, stream) (hipMallocAsync); below that one workgroup, right-hand side in LDS. */
 int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
               int trans, double* x, double* sumsq, void* stream);
+/* Round 4: for 256 <= n <= 16384 the blocked solve is ONE persistent launch (a workgroup per 64-row
+ * block, solved blocks handed on as data-tagged granules; same bits as the launch-per-256-rows
+ * path).  Test / profiling switch (not read from the environment): 1 = that multi-launch path,
+ * 0 = default; < 0 queries.  Returns the previous value.                                        */
+int apgp_trsv_mode(int multi_launch);
 
 /* ---- pivot of an appended factor row -----------------------------------------
  * Incremental fit when ApproxPosterior.findNextPoint appends a design point

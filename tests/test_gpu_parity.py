@@ -1056,6 +1056,43 @@ def test_persistent_cholesky_repeated_calls_leave_no_state(lib_loaded):
     assert lib.apgp_potrf_fallbacks() == fb
 
 
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("n", [256, 300, 1100, 1153, 2048, 4095, 8000])
+def test_persistent_trsv_bit_identical_to_multi_launch(n, trans, lib_loaded):
+    """K3 (george BasicSolver.apply_inverse on a vector: gpUtils.py:78, utility.py:131): the blocked triangular solve as
+    ONE persistent launch (trsv_persist_kernel: a workgroup per 64-row block, solved blocks handed on as tagged granules,
+    roles by ticket) against the launch-per-256-rows path -- x and x.x the same bits, forward and transposed, ld > n,
+    b aliasing x -- and against LAPACK."""
+    import torch
+    lib = lib_loaded
+    rs = np.random.RandomState(n)
+    ld = n + (3 if n % 2 else 0)
+    Lh = np.tril(rs.normal(size=(n, n)) * 0.05) + np.diag(1.0 + rs.uniform(size=n))
+    Lbuf = np.zeros((n, ld)); Lbuf[:, :n] = Lh
+    L = torch.from_numpy(Lbuf).cuda()
+    b = torch.from_numpy(rs.normal(size=n)).cuda()
+
+    def run(mode, alias):
+        lib.apgp_trsv_mode(mode)
+        try:
+            x = b.clone() if alias else torch.empty(n, dtype=torch.float64, device="cuda")
+            ss = torch.full((1,), -1.0, dtype=torch.float64, device="cuda")
+            rc = lib.apgp_trsv(L.data_ptr(), n, ld, (x if alias else b).data_ptr(), 0.125, trans, x.data_ptr(), ss.data_ptr(), None)
+            assert rc == 0, lib.apgp_last_error()
+            torch.cuda.synchronize()
+            return x, float(ss.item())
+        finally:
+            lib.apgp_trsv_mode(0)
+    x1, s1 = run(1, False)
+    for alias in (False, True):
+        for _ in range(3):                                   # (repeated: tickets and tags are call-unique, never reset)
+            x0, s0 = run(0, alias)
+            assert torch.equal(x0, x1) and s0 == s1
+    ref = np.linalg.solve(Lh.T if trans else Lh, b.cpu().numpy() - 0.125)
+    assert np.abs(x1.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.isclose(s1, float(ref @ ref), rtol=1e-12)
+
+
 def make_full_logdet(make, X):
     g = make()
     g.compute(X)
