@@ -683,7 +683,9 @@ __device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
     PP_STEP_LOOP_BEGIN(lds)
     const long long j0 = (long long)s_in * PB;
     int* cnt = (int*)(lds + PP_INTS) + 8 * (s_in & 1);
+    __builtin_amdgcn_s_setprio(3);         // (the factorisation waits for these columns at group 8)
     panel_helper_wave((int)((n - j0) < PB ? (n - j0) : PB), lane, Ls, cnt + 0, cnt + 1);
+    __builtin_amdgcn_s_setprio(0);
     PP_STAMP(s_in, 16);
     if (r_ > s_in) pp_stage_tiles(lds_off, karg, s_in);
     PP_STEP_LOOP_END()
