@@ -89,7 +89,8 @@ inline ApgpMailbox* apgp_stream_mailbox(hipStream_t s) {
     if (!m.host) {
         void* h = nullptr;
         void* d = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return &m;
+        // (Portable: the mailbox is keyed by the STREAM's device, which need not be the caller's current one)
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) return &m;
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return &m; }
         for (int i = 0; i < 8; ++i) ((volatile double*)h)[i] = 0.0;
         m.host = (volatile double*)h;
@@ -110,7 +111,7 @@ inline double* apgp_stream_pinned_io(hipStream_t s, size_t doubles, double** dev
         const size_t want = doubles + doubles / 2 + 512;
         void* h = nullptr;
         void* d = nullptr;
-        if (hipHostMalloc(&h, want * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+        if (hipHostMalloc(&h, want * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) return nullptr;
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
         m->io_host = (double*)h; m->io_dev = (double*)d; m->io_doubles = want;
     }
@@ -118,7 +119,9 @@ inline double* apgp_stream_pinned_io(hipStream_t s, size_t doubles, double** dev
     return m->io_host;
 }
 
-// frees (stream-ordered) every scratch buffer of `s`; returns the number of buffers released
+// frees (stream-ordered) every scratch buffer of `s`; returns the number of buffers released.  Must not run
+// concurrently with library calls on `s` (a caller polling the stream's mailbox would lose it under its feet):
+// synchronise the stream and stop using it first, as before destroying it.
 inline int apgp_stream_scratch_release(hipStream_t s) {
     ApgpScratchTable& t = apgp_scratch_table();
     const int dev = apgp_stream_device(s);

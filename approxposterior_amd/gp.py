@@ -564,6 +564,7 @@ class GP(object):
                                and np.array_equal(self._alpha_y, yv)) else None
         keep_nll = (self._L, self._z) if (self._L is not None and self._z is not None and self._L_store is None
                                           and self._nll_owned) else None
+        keep_stream = getattr(self, "_nll_stream", None)
         self._reset_device_state()
         self._computed = False
         ks = self._kernel_struct()
@@ -576,7 +577,11 @@ class GP(object):
             # An optimiser's evaluations (set_parameter_vector + log_likelihood, over and over) refactorise in
             # the SAME buffers: the previous factor is dead once its hyper-parameters are, and nothing else
             # references an exactly-sized private factor (appended chains share a store: never reused here).
-            reuse = keep_nll if (keep_nll is not None and yv is not None and keep_nll[0].shape[0] == n) else None
+            # ... on the SAME stream only: the in-place refactorisation (memset + Gram) is ordered behind the previous
+            # evaluation's readers by stream order, not by the caching allocator -- a caller that switched the current
+            # stream between two evaluations gets fresh buffers
+            reuse = keep_nll if (keep_nll is not None and yv is not None and keep_nll[0].shape[0] == n
+                                 and keep_stream == st.value) else None
             if reuse is not None:
                 K, z = reuse
                 if n > 64:
@@ -631,6 +636,7 @@ class GP(object):
             self._alpha_y = np.array(yv, copy=True)
             self._alpha_mean = self.mean.value
             self._nll_owned = True    # (K, z) came from an _nll evaluation: the next one may refactorise in place
+            self._nll_stream = st.value
 
     def recompute(self, quiet=False, **kwargs):
         if self.kernel.dirty or not self._computed:
