@@ -428,22 +428,33 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
         zrow[lane] = rhs_r;
         lds_store_volatile(zflag, 1);
     } else if (!dead && !p.producer) {
+        const __amdgpu_buffer_rsrc_t rs_strm = __builtin_amdgcn_make_buffer_rsrc((void*)q->strm, 0, (int)(PP_STRM_WORDS * 8), 0x00020000);
         static_for<PB / CB>([&](auto cc_) {
             constexpr int cc = decltype(cc_)::value;
             if (dead) return;
-            const pp_u64* src = q->strm + (((long long)s * 16 + cc) * 64 + lane) * 8;
-            pp_u64 g[8];
-            PpSpin sp;
+            // four 16-byte write-through-coherent loads per lane and look ({lo, tag, hi, tag} per value), no sleep between
+            // looks: the group this wavefront waits for paces the whole step
+            pp_u32x4 g[4];
+            unsigned it = 0;
+            pp_u64 t0 = 0;
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { g[k] = pp_ld(src + k); ok = ok && (unsigned)(g[k] >> 32) == tag; }
+                for (int k = 0; k < 4; ++k) {
+                    g[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_strm, (unsigned)(lane * 64 + k * 16), (unsigned)((s * 16 + cc) * 4096), 16);
+                    ok = ok && g[k].y == tag && g[k].w == tag;
+                }
                 if (__all(ok)) break;
-                if (pp_give_up(sp, ctl, call_id, timeout)) { dead = true; return; }
+                if ((++it & 31u) == 0) {
+                    if (pp_ld(ctl + PP_CTL_ABORT) == call_id) { dead = true; return; }
+                    const pp_u64 now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > timeout) { pp_st(ctl + PP_CTL_ABORT, call_id); dead = true; return; }
+                }
             }
             double* dst = Bs + (cc >> 2) * PP_CHUNK + lane * 18 + 4 * (cc & 3);
-            *(f64x2*)dst = (f64x2){__hiloint2double((int)(unsigned)g[1], (int)(unsigned)g[0]), __hiloint2double((int)(unsigned)g[3], (int)(unsigned)g[2])};
-            *(f64x2*)(dst + 2) = (f64x2){__hiloint2double((int)(unsigned)g[5], (int)(unsigned)g[4]), __hiloint2double((int)(unsigned)g[7], (int)(unsigned)g[6])};
+            *(f64x2*)dst = (f64x2){__hiloint2double((int)g[0].z, (int)g[0].x), __hiloint2double((int)g[1].z, (int)g[1].x)};
+            *(f64x2*)(dst + 2) = (f64x2){__hiloint2double((int)g[2].z, (int)g[2].x), __hiloint2double((int)g[3].z, (int)g[3].x)};
             lds_store_volatile(bprog, cc + 1);
             if (cc == 0) PP_STAMP(s, 10);
             if (cc == 14) PP_STAMP(s, 15);
@@ -662,7 +673,9 @@ __device__ PP_NOINLINE void pp_stage_tiles(unsigned lds_off, PpKarg karg, int s_
         }
 #pragma unroll
         for (int it = 0; it < 32; ++it) asm volatile("" : "+v"(tv[it]), "+v"(la[it]));
-        pp_lds_wait_ge(cnt + 0, PB + 1);                       // (the factorisation has left Ls ...)
+        // (prog = PB: the factorisation has published its last group and touches Ls no more in a workgroup that is not the
+        // step's diagonal one -- not PB + 1: hipcc sinks the 64 pivot checks behind the last publish, 1.1 us before that)
+        pp_lds_wait_ge(cnt + 0, PB);
         pp_lds_wait_ge(cnt + 2, PB / CB);                      // (... and the solving wavefront has read its last group of the factor)
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
