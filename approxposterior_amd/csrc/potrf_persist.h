@@ -516,7 +516,7 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     const double* Bs = lds + PP_BS;
     int* xprog = p.cnt + 2; int* bprog = p.cnt + 3;
     const int mw = __builtin_amdgcn_readfirstlane((t >> 6) - 4);
-    const int wr = (mw >> 1) * 32, wc = (mw & 1) * 32;
+    const int wr = (mw >> 1) * 32, wc = (mw & 1) * 32;         // this wavefront's 32 x 32 quadrant of both products
     bool dead = false;
     if (r > s) {
     int bcol[4];
@@ -530,51 +530,67 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) { v[i][j][rr] = 0.0; v2[i][j][rr] = 0.0; }
     const bool producer = p.producer;
-    auto ksteps = [&](auto lo_, auto hi_) {
-        constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
-        static_for<hi - lo>([&](auto g_) {
-            constexpr int g = lo + decltype(g_)::value;
-            pp_lds_wait_ge(xprog, g + 1);
-            if (producer) {
-                pp_kstep<false>(p.As_cur + (g >> 2) * PP_CHUNK, p.As_cur + (g >> 2) * PP_CHUNK, g & 3, lane, wr, wc, bcol, v, v2);
-            } else {
-                pp_lds_wait_ge(bprog, g + 1);
-                pp_kstep<true>(p.As_cur + (g >> 2) * PP_CHUNK, Bs + (g >> 2) * PP_CHUNK, g & 3, lane, wr, wc, bcol, v, v2);
-            }
-        });
-    };
     // No memory access in these wavefronts: the tiles' values in memory are fetched by wavefront 2 once its helper duty is
-    // over (coalesced, into the LDS places of the hand-over) and the products are subtracted from them there.  (With the 64 requests here, in the accumulator layout -- sixteen cache lines per
-    // load -- the k-steps stood still for 2.5-3 us and were three groups behind when the last group arrived.)
-    ksteps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-    if (mw == 0) PP_STAMP(s, 11);
-    ksteps(std::integral_constant<int, 1>{}, std::integral_constant<int, 6>{});
-    if (mw == 0) PP_STAMP(s, 9);
-    ksteps(std::integral_constant<int, 6>{}, std::integral_constant<int, 13>{});
-    if (mw == 0) PP_STAMP(s, 12);
-    ksteps(std::integral_constant<int, 13>{}, std::integral_constant<int, 15>{});
-    if (mw == 0) PP_STAMP(s, 14);
-    ksteps(std::integral_constant<int, 15>{}, std::integral_constant<int, 16>{});
-    if (mw == 0) PP_STAMP(s, 4);
+    // over (coalesced, into the LDS places of the hand-over) and the products are subtracted from them there.  (With the 64
+    // requests here, in the accumulator layout -- sixteen cache lines per load -- the k-steps stood still for 2.5-3 us and
+    // were three groups behind when the last group arrived.)  A rolled loop: the sixteen k-steps differ in LDS addresses only.
+#ifdef PP_STAMPS
+#define PP_KSTAMPS() do { if (mw == 0) { if (g == 0) PP_STAMP(s, 11); if (g == 5) PP_STAMP(s, 9); if (g == 12) PP_STAMP(s, 12); if (g == 14) PP_STAMP(s, 14); if (g == 15) PP_STAMP(s, 4); } } while (0)
+#else
+#define PP_KSTAMPS() do { } while (0)
+#endif
+    if (producer) {
+#pragma unroll 1
+        for (int g = 0; g < PB / CB; ++g) {
+            pp_lds_wait_ge(xprog, g + 1);
+            const double* Ach = p.As_cur + (g >> 2) * PP_CHUNK;
+            pp_kstep<false>(Ach, Ach, g & 3, lane, wr, wc, bcol, v, v2);
+            PP_KSTAMPS();
+        }
+    } else {
+#pragma unroll 1
+        for (int g = 0; g < PB / CB; ++g) {
+            pp_lds_wait_ge(xprog, g + 1);
+            pp_lds_wait_ge(bprog, g + 1);
+            pp_kstep<true>(p.As_cur + (g >> 2) * PP_CHUNK, Bs + (g >> 2) * PP_CHUNK, g & 3, lane, wr, wc, bcol, v, v2);
+            PP_KSTAMPS();
+        }
+    }
     // hand-over: the staged values minus the products, in place -- the next tile in the free parity of As ([64][66]) for
     // wavefront 1, the next diagonal block in Ls (staged there by wavefront 2)
     pp_lds_wait_ge(p.cnt + 5, 1);
     if (lds_load_volatile(p.cnt + 5) != 1) dead = true;
     if (mw == 0) PP_STAMP(s, 5);
     double (*St)[PB + 2] = (double (*)[PB + 2])p.As_prev;
+    {
+        // all the reads first, then the differences, then the stores (St and Ls may alias as far as the compiler knows: written
+        // element by element every read waited for the store before it -- 64 LDS round trips, 1.5 us)
+        double sv[2][2][4], lv[2][2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
-                if (producer) Ls[lr][lc] = Ls[lr][lc] - v[i][j][rr];
-                else {
-                    St[lr][lc] = St[lr][lc] - v[i][j][rr];
-                    Ls[lr][lc] = Ls[lr][lc] - v2[i][j][rr];
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
+                    lv[i][j][rr] = Ls[lr][lc];
+                    sv[i][j][rr] = St[lr][lc];       // (the producer's own tile is not in St: read, unused)
                 }
-            }
+        PANEL_FENCE();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
+                    if (producer) Ls[lr][lc] = lv[i][j][rr] - v[i][j][rr];
+                    else {
+                        St[lr][lc] = sv[i][j][rr] - v[i][j][rr];
+                        Ls[lr][lc] = lv[i][j][rr] - v2[i][j][rr];
+                    }
+                }
+    }
     if (mw == 0) PP_STAMP(s, 6);
     if (dead) lds_store_volatile(p.abl, 1);
     }
@@ -734,6 +750,9 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
         const unsigned long long kp = (unsigned long long)(size_t)__builtin_amdgcn_kernarg_segment_ptr();
         karg.lo = (unsigned)kp; karg.hi = (unsigned)(kp >> 32);
     }
+#ifdef PP_STAMPS
+    if (r == q.nb - 1 && lane == 0) pp_stamps[63 * 24 + w] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: SIMD in bits 5:4
+#endif
     if (w == 0) pp_role_factor(lds_off, karg);
     else if (w == 1) pp_role_solve(lds_off, karg);
     else if (w == 3) pp_role_recv(lds_off, karg, rhs_r);

@@ -57,6 +57,7 @@ if __name__ == "__main__":
         st = st.reshape(64, 24).astype(np.int64)
         nb = (n + 63) // 64
         print("n = %d (%d block columns), fallbacks %d; microseconds after the step's start (last row workgroup)" % (n, nb, lib.apgp_potrf_fallbacks()))
+        print("SIMD of wavefronts 0..7 (HW_ID bits 5:4): " + " ".join(str((int(v) >> 4) & 3) for v in st[63, :8]))
         print("step  len   " + " ".join("%8s" % s for s in names[1:]))
         for s in range(nb):
             t0 = st[s, 0]
