@@ -115,6 +115,15 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
+#ifdef PP_STAMPS     // (persistent kernel, stamped build: the factorising wavefront of the last row workgroup)
+__device__ unsigned long long pp_fstamps[64 * 8];
+#define PANEL_HOOK(i_) do { if ((int)blockIdx.x == (int)((a.n + PB - 1) / PB) - 1 && lane == 0) pp_fstamps[(j0 / PB) * 8 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int apgp_debug_read_fstamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_fstamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -2;
+}
+#else
+#define PANEL_HOOK(i_) do { } while (0)
+#endif
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 // every LDS spin between wavefronts is bounded (2^18 polls, tens of ms): a role that never publishes makes the result wrong,
 // never the GPU hang
@@ -191,11 +200,22 @@ __device__ __forceinline__ void panel_helper_wave(const int bs, const int lane, 
             xs[k + 1] = q.y;
         }
         PANEL_FENCE();
-        panel_trailing<c0, HELPER_COL0, PB, HELPER_COL0, PB - HELPER_COL0>(hi, xs, Ls);
+        if constexpr (c0 + CB < HELPER_COL0) panel_trailing<c0, HELPER_COL0, PB, HELPER_COL0, PB - HELPER_COL0>(hi, xs, Ls);
+        else {
+            // the last group: the factorising wavefront is about to wait for these columns -- the four it needs for its
+            // next group go back first (hflag = 1), the rest while it factorises that group (hflag = 2).  Handing all 32
+            // back at once left it waiting 1.5-2 us per panel step.
+            panel_trailing<c0, HELPER_COL0, HELPER_COL0 + CB, HELPER_COL0, PB - HELPER_COL0>(hi, xs, Ls);
+#pragma unroll
+            for (int k = HELPER_COL0; k < HELPER_COL0 + CB; k += 2) *(f64x2*)(&Ls[lane][k]) = (f64x2){hi[k - HELPER_COL0], hi[k + 1 - HELPER_COL0]};
+            lds_store_volatile(hflag_p, 1);              // (same wavefront: LDS stores stay in order)
+            PANEL_FENCE();
+            panel_trailing<c0, HELPER_COL0 + CB, PB, HELPER_COL0, PB - HELPER_COL0>(hi, xs, Ls);
+        }
     });
 #pragma unroll
-    for (int k = HELPER_COL0; k < PB; k += 2) *(f64x2*)(&Ls[lane][k]) = (f64x2){hi[k - HELPER_COL0], hi[k + 1 - HELPER_COL0]};
-    lds_store_volatile(hflag_p, 1);                      // (same wavefront: LDS stores stay in order)
+    for (int k = HELPER_COL0 + CB; k < PB; k += 2) *(f64x2*)(&Ls[lane][k]) = (f64x2){hi[k - HELPER_COL0], hi[k + 1 - HELPER_COL0]};
+    lds_store_volatile(hflag_p, 2);
 #undef prog
 }
 
@@ -203,6 +223,8 @@ __device__ __forceinline__ void panel_helper_wave(const int bs, const int lane, 
 // the operands: `ar` = row `lane` of the diagonal block (zero above the diagonal, identity rows
 // past bs), `ri` = the right-hand-side entry of that row; `x` = panel row `row` of the workgroup.
 // Ls / invd / zblk / prog: the workgroup's LDS exchange area (prog zeroed before the first use).
+// RHS = false: no right-hand side rides along (the persistent kernel's forward solve is a pass of its own)
+template <bool RHS = true>
 __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long j0, const int bs, const int lane,
                                                   double (&ar)[PB], double ri, double (*Ls)[PB + 2], double* invd,
                                                   double* zblk, int* prog_p, const int* hflag_p, const int wb_index,
@@ -210,16 +232,20 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
 #define prog (*prog_p)
     PANEL_FENCE();
     PANEL_STAMP(1);
+    PANEL_HOOK(0);
     int firstbad = 0x7fffffff;               // (uniform) first pivot that is not positive and finite
     static_for<PB / CB>([&](auto cc_) {
         constexpr int c0 = CB * decltype(cc_)::value;
         if constexpr (c0 == HELPER_COL0) {
             // columns HELPER_COL0 .. of this row come back from the helper wavefront, updated with
             // the groups before this one (panel_helper_wave)
+            // (the four columns of this group first; the others are awaited before this group's trailing update)
+            PANEL_HOOK(1);
             PANEL_SPIN_WHILE(lds_load_volatile(hflag_p) == 0);
             PANEL_FENCE();
+            PANEL_HOOK(2);
 #pragma unroll
-            for (int k = HELPER_COL0; k < PB; k += 2) {
+            for (int k = HELPER_COL0; k < HELPER_COL0 + CB; k += 2) {
                 const f64x2 q = *(const f64x2*)(&Ls[lane][k]);
                 ar[k] = q.x;
                 ar[k + 1] = q.y;
@@ -233,7 +259,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
         for (int r = 0; r < CB; ++r) {
 #pragma unroll
             for (int q = 0; q <= r; ++q) d[r][q] = bcast_lane(ar[c0 + q], c0 + r);
-            zb[r] = bcast_lane(ri, c0 + r);
+            if constexpr (RHS) zb[r] = bcast_lane(ri, c0 + r);
         }
         if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(6); }
         // (2) its factor, computed by all lanes alike: the serial chain of CB pivots runs on
@@ -261,10 +287,12 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
                 for (int i = j; i < CB; ++i) d[i][j] = fma(-d[i][k], d[j][k], d[i][j]);
             double dd = pv * r;                                  // (off the chain) sqrt(p), one Newton step
             sq[k] = fma(0.5 * r, fma(-dd, dd, pv), dd);
-            double zacc = zb[k];                                 // forward solve riding along
+            if constexpr (RHS) {
+                double zacc = zb[k];                             // forward solve riding along
 #pragma unroll
-            for (int m = 0; m < k; ++m) zacc = fma(-zb[m], d[k][m], zacc);
-            zb[k] = zacc * r;
+                for (int m = 0; m < k; ++m) zacc = fma(-zb[m], d[k][m], zacc);
+                zb[k] = zacc * r;
+            }
         }
         if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(7); }
         // (3) every lane solves its own row against it (rows of the block itself reproduce the
@@ -279,7 +307,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
             x[k] = lane == c0 + k ? sq[k] : (lane > c0 + k ? sacc : 0.0);
             ar[c0 + k] = x[k];
         }
-        {
+        if constexpr (RHS) {
             double racc = ri;
 #pragma unroll
             for (int k = 0; k < CB; ++k) racc = fma(-x[k], zb[k], racc);
@@ -299,6 +327,20 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
         }
         PANEL_FENCE();
         if (c0 == 0) { PANEL_STAMP(9); }
+        if (c0 == 16) PANEL_HOOK(3);
+        if (c0 == 48) PANEL_HOOK(4);
+        if (c0 == 60) PANEL_HOOK(5);
+        if constexpr (c0 == HELPER_COL0) {
+            PANEL_SPIN_WHILE(lds_load_volatile(hflag_p) < 2);
+            PANEL_FENCE();
+#pragma unroll
+            for (int k = HELPER_COL0 + CB; k < PB; k += 2) {
+                const f64x2 q = *(const f64x2*)(&Ls[lane][k]);
+                ar[k] = q.x;
+                ar[k + 1] = q.y;
+            }
+            PANEL_FENCE();
+        }
         // (5) rank-CB update of the columns to the right; row j of the new columns comes back
         // as broadcast reads, requested TR_AHEAD columns before their use
         panel_trailing<c0, c0 + CB, (c0 < HELPER_COL0 ? HELPER_COL0 : PB), 0, PB>(ar, x, Ls);
@@ -307,9 +349,11 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
     PANEL_STAMP(2);
     if (firstbad != 0x7fffffff && wb_index == 0 && lane == 0)
         atomicMin((unsigned int*)a.info, (unsigned int)(j0 + firstbad));
-    if (a.rhs) {
-        zblk[lane] = ri;
-        if (wb_index == 0 && lane < bs) (a.dscr ? a.dscr + a.zoff : a.rhs)[j0 + lane] = ri;
+    if constexpr (RHS) {
+        if (a.rhs) {
+            zblk[lane] = ri;
+            if (wb_index == 0 && lane < bs) (a.dscr ? a.dscr + a.zoff : a.rhs)[j0 + lane] = ri;
+        }
     }
     lds_store_volatile(&prog, PB + 1);
     {

@@ -296,7 +296,7 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     pa.A = q->a.A; pa.rhs = nullptr;                           // (the forward solve is a separate pass below)
     pa.n = n; pa.lda = q->a.lda; pa.j0 = p.j0; pa.shift = 0.0; pa.info = q->a.info; pa.out5 = nullptr; pa.mail = nullptr; pa.seq = 0;
     pa.dscr = q->a.dscr; pa.batch_dscr = 0; pa.zoff = q->a.zoff; pa.batch_A = 0; pa.batch_rhs = 0; pa.abort_word = nullptr; pa.abort_id = 0;
-    panel_factor_wave(pa, p.j0, bs, lane, rowv, 0.0, Ls, invd, zblk, p.cnt + 0, p.cnt + 1, r == s ? 0 : PB, 1);
+    panel_factor_wave<false>(pa, p.j0, bs, lane, rowv, 0.0, Ls, invd, zblk, p.cnt + 0, p.cnt + 1, r == s ? 0 : PB, 1);
     PP_STAMP(s, 1);
     if (r == s && q->a.rhs) {
         // z_s = L_ss^-1 (rhs block s): the operations of the pass that rides along in panel_factor_wave, in its

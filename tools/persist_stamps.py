@@ -57,6 +57,14 @@ if __name__ == "__main__":
         st = st.reshape(64, 24).astype(np.int64)
         nb = (n + 63) // 64
         print("n = %d (%d block columns), fallbacks %d; microseconds after the step's start (last row workgroup)" % (n, nb, lib.apgp_potrf_fallbacks()))
+        fs = np.zeros(64 * 8, dtype=np.uint64)
+        if hasattr(lib, "apgp_debug_read_fstamps"):
+            lib.apgp_debug_read_fstamps.argtypes = [ctypes.c_void_p]
+            assert lib.apgp_debug_read_fstamps(fs.ctypes.data) == 0
+            fs = fs.reshape(64, 8).astype(np.int64)
+            print("factorising wavefront, us after ITS entry: at the helper wait | columns back | group 4 / 12 / 15 published;  entry after step start")
+            for sidx in range(4, min(nb - 1, 10)):
+                print("  step %2d: %s ; %6.2f" % (sidx, " ".join("%6.2f" % ((fs[sidx, i] - fs[sidx, 0]) / 100.0) for i in (1, 2, 3, 4, 5)), (fs[sidx, 0] - st[sidx, 0]) / 100.0))
         print("SIMD of wavefronts 0..7 (HW_ID bits 5:4): " + " ".join(str((int(v) >> 4) & 3) for v in st[63, :8]))
         print("step  len   " + " ".join("%8s" % s for s in names[1:]))
         for s in range(nb):
