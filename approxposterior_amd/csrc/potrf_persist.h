@@ -87,6 +87,11 @@ extern "C" int apgp_debug_read_stamps(unsigned long long* out) {
 }
 // the update half-workgroup that owns tile (s + 2, s + 2), per update step: 0 rows seen | 1 acquired | 2 first tile pair: operands in LDS | 3 products done |
 // 4 stored and drained | 5 step done
+__device__ unsigned long long pp_wstamps[64 * 8];      // arrival of each wavefront of the last row workgroup at the step's barrier
+#define PP_WSTAMP(s_) do { if ((int)blockIdx.x == q->nb - 1 && (threadIdx.x & 63) == 0) pp_wstamps[(s_) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int apgp_debug_read_wstamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_wstamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -2;
+}
 __device__ unsigned long long pp_ustamps[64 * 8];
 #define PP_USTAMP(s_, i_) do { if (((i_) >= 2 && (i_) <= 4) ? (ustamp_me && (threadIdx.x & 255) == 0) : (ustamp_wg && threadIdx.x == 0)) pp_ustamps[(s_) * 8 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int apgp_debug_read_ustamps(unsigned long long* out) {
@@ -94,6 +99,7 @@ extern "C" int apgp_debug_read_ustamps(unsigned long long* out) {
 }
 #else
 #define PP_STAMP(s_, i_) do { } while (0)
+#define PP_WSTAMP(s_) do { } while (0)
 #define PP_STAMPP(s_, i_) do { } while (0)
 #define PP_USTAMP(s_, i_) do { } while (0)
 #endif
@@ -234,6 +240,7 @@ __device__ __forceinline__ double* pp_lds_base(unsigned off) {
     for (int s_in = 0, r_ = (int)blockIdx.x; s_in <= r_; ++s_in) {                                   \
         if (lds_load_volatile((int*)((lds_) + PP_INTS) + 17 + ((s_in + 1) & 1))) return;   /* somebody gave up during the previous step (uniform) */
 #define PP_STEP_LOOP_END()                                                                           \
+        PP_WSTAMP(s_in);                                                                             \
         if (s_in < r_) __syncthreads();                                                              \
     }
 
@@ -285,6 +292,7 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     const double* zrow = lds + PP_ZROW;
     const int bs = p.bs, s = p.s, r = p.r;
     PP_STAMP(s, 0);
+    PP_STAMPP(s, 20);
     double rowv[PB];                                           // row `lane` of the diagonal block
 #pragma unroll
     for (int k = 0; k < PB; k += 2) {
@@ -348,6 +356,12 @@ __device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
     __builtin_amdgcn_s_setprio(3);
     PP_STEP_LOOP_BEGIN(lds)
     const PpStep p = pp_step(lds, s_in, n);
+    if (p.s >= 1) {
+        // L(r, s-1) went to memory at the end of the previous step (below): drained by now -- publish it
+        pp_drain();
+        if (lane == 0) pp_st(q->ctl + PP_CTL_ROWDONE + p.r, (q->call_id << 8) | (pp_u64)p.s);
+        PP_STAMP(p.s, 8);
+    }
     if (p.r > p.s) {
     const double (*Ls)[PB + 2] = (const double (*)[PB + 2])(lds + PP_LS);
     const long long row = (long long)p.r * PB + lane;
@@ -369,6 +383,32 @@ __device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
     }
     pp_solve_wave(lane, rowv, Ls, lds + PP_INVD, p.cnt + 0, p.As_cur, p.cnt + 2);
     PP_STAMP(p.s, 2);
+    PP_STAMPP(p.s, 21);
+    {
+        // L(r, s) from LDS (this wavefront's published groups) to memory, coalesced write-through stores: this wavefront
+        // is idle until the step ends, and the update workgroups need the rows as early as possible (they have one step
+        // to apply them to column s + 2).  The flag follows at the head of the next step, once the stores have drained.
+        // (The receiving wavefront did this until the hand-over got shorter: it starts ~2 us later, when the last group has
+        // arrived, and was the last one at the step's barrier.)
+        const int r = p.r, s = p.s;
+        const __amdgpu_buffer_rsrc_t rs_A = __builtin_amdgcn_make_buffer_rsrc((void*)q->a.A, 0, (int)(q->a.lda * n * 8), 0x00020000);
+        // (eight LDS reads in flight, then their eight stores; rows past n fall outside the buffer descriptor and are
+        // dropped by its range check -- with a branch per row every store waited for its own LDS read: 2.5 us)
+        const unsigned row_b = (unsigned)(lda * 8);
+        const unsigned off0 = (unsigned)((((long long)r * PB + (lane >> 5)) * lda + (long long)s * PB + 2 * (lane & 31)) * 8);
+        const double* src0 = p.As_cur + ((lane & 31) >> 3) * PP_CHUNK + (lane >> 5) * 18 + (2 * (lane & 31) & 15);
+#pragma unroll
+        for (int b8 = 0; b8 < 4; ++b8) {
+            f64x2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *(const f64x2*)(src0 + (b8 * 8 + k) * 2 * 18);
+            PANEL_FENCE();
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_u32x4, v[k]), rs_A, off0 + (unsigned)(b8 * 8 + k) * 2u * row_b, 0, 16);
+            PANEL_FENCE();
+        }
+    }
     }
     PP_STEP_LOOP_END()
 }
@@ -393,12 +433,6 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
     int* bprog = p.cnt + 3;
     int* zflag = p.cnt + 4;
     bool dead = false;
-    if (s >= 1) {
-        // L(r, s-1) went to memory at the end of the previous step (below): drained by now -- publish it
-        pp_drain();
-        if (lane == 0) pp_st(ctl + PP_CTL_ROWDONE + r, (call_id << 8) | (pp_u64)s);
-        PP_STAMP(s, 8);
-    }
     if (q->a.rhs && s >= 1) {
         const pp_u64* src = q->zstrm + ((long long)(s - 1) * 64 + lane) * 2;
         pp_u64 g0, g1;
@@ -475,6 +509,7 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
                 const pp_u32x4 g = {(unsigned)__double2loint(xs[k]), tag, (unsigned)__double2hiint(xs[k]), tag};
                 __builtin_amdgcn_raw_buffer_store_b128(g, rs_strm, (unsigned)(lane * 64 + k * 16), (unsigned)((s * 16 + cc) * 4096), 16);
             }
+            if (cc == 15) PP_STAMPP(s, 22);
         });
     }
     if (dead) {
@@ -483,23 +518,6 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
         lds_store_volatile(zflag, 1);
     }
     lds_store_volatile(bprog, PB);                             // (>= 16: also "this wavefront is done with As_prev")
-    if (r > s) {
-        // L(r, s) from LDS to memory, coalesced write-through stores (this wavefront is idle until the step ends; the
-        // update workgroups need the rows as early as possible: they have one step to apply them to column s + 2).
-        // The flag follows at the head of the next step, once the stores have drained.
-        pp_lds_wait_ge(p.cnt + 2, PB / CB);
-        const __amdgpu_buffer_rsrc_t rs_A = __builtin_amdgcn_make_buffer_rsrc((void*)q->a.A, 0, (int)(q->a.lda * n * 8), 0x00020000);
-        const long long lda = q->a.lda;
-#pragma unroll 8
-        for (int it = 0; it < 32; ++it) {
-            const int e = it * 64 + lane, rw = e >> 5, col = 2 * (e & 31);
-            const f64x2 v = *(const f64x2*)(p.As_cur + (col >> 4) * PP_CHUNK + rw * 18 + (col & 15));
-            const long long gr = (long long)r * PB + rw;
-            if (gr < n)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_u32x4, v), rs_A,
-                                                       (unsigned)((gr * lda + (long long)s * PB + col) * 8), 0, 16);
-        }
-    }
     PP_STEP_LOOP_END()
 }
 
@@ -557,7 +575,10 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
         }
     }
     // hand-over: the staged values minus the products, in place -- the next tile in the free parity of As ([64][66]) for
-    // wavefront 1, the next diagonal block in Ls (staged there by wavefront 2)
+    // wavefront 1, the next diagonal block in Ls (staged there by wavefront 2).  (Reading the staged values before the last
+    // k-step, while the wavefront waits for the last group anyway, changed nothing: the hand-over is bound by its 32
+    // scattered ds_write_b64 per wavefront -- 3-4-way bank conflicts of the accumulator layout at a row stride of 66
+    // doubles, which is the conflict-free stride for the row-per-lane accesses of the panel code.)
     pp_lds_wait_ge(p.cnt + 5, 1);
     if (lds_load_volatile(p.cnt + 5) != 1) dead = true;
     if (mw == 0) PP_STAMP(s, 5);
@@ -701,6 +722,8 @@ __device__ PP_NOINLINE void pp_stage_tiles(unsigned lds_off, PpKarg karg, int s_
         PP_STAMP(s, 19);
     }
     lds_store_volatile(cnt + 5, up ? 1 : 2);                   // 1: the tiles' values are where the differences go | 2: gave up
+    PP_WSTAMP(s);
+    __syncthreads();                                           // the step's barrier (see pp_role_helper)
 }
 
 __device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
@@ -716,8 +739,11 @@ __device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
     panel_helper_wave((int)((n - j0) < PB ? (n - j0) : PB), lane, Ls, cnt + 0, cnt + 1);
     __builtin_amdgcn_s_setprio(0);
     PP_STAMP(s_in, 16);
+    // (the step's barrier is the last thing pp_stage_tiles does -- it is called exactly when the step has one -- so that the
+    // reloads of the registers the call saved, 115 of them, come after the barrier instead of before it: this wavefront
+    // was the last one to arrive)
     if (r_ > s_in) pp_stage_tiles(lds_off, karg, s_in);
-    PP_STEP_LOOP_END()
+    }
 }
 
 __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, const unsigned lds_off) {

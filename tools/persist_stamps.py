@@ -65,6 +65,16 @@ if __name__ == "__main__":
             print("factorising wavefront, us after ITS entry: at the helper wait | columns back | group 4 / 12 / 15 published;  entry after step start")
             for sidx in range(4, min(nb - 1, 10)):
                 print("  step %2d: %s ; %6.2f" % (sidx, " ".join("%6.2f" % ((fs[sidx, i] - fs[sidx, 0]) / 100.0) for i in (1, 2, 3, 4, 5)), (fs[sidx, 0] - st[sidx, 0]) / 100.0))
+        print("the step's producer workgroup (s + 1), us after the last workgroup's step start: its step start | its solve done | last group's granules stored")
+        for sidx in range(4, min(nb - 2, 10)):
+            print("  step %2d: %s" % (sidx, " ".join("%6.2f" % ((st[sidx, i] - st[sidx, 0]) / 100.0) for i in (20, 21, 22))))
+        ws = np.zeros(64 * 8, dtype=np.uint64)
+        lib.apgp_debug_read_wstamps.argtypes = [ctypes.c_void_p]
+        assert lib.apgp_debug_read_wstamps(ws.ctypes.data) == 0
+        ws = ws.reshape(64, 8).astype(np.int64)
+        print("arrival at the step's barrier, us after the step's start: wavefronts 0 .. 7 (factor, solve, helper, receiver, matrix x 4) | next step's start")
+        for sidx in range(4, min(nb - 2, 10)):
+            print("  step %2d: %s | %6.2f" % (sidx, " ".join("%6.2f" % ((ws[sidx, i] - st[sidx, 0]) / 100.0) for i in range(8)), (st[sidx + 1, 0] - st[sidx, 0]) / 100.0))
         print("SIMD of wavefronts 0..7 (HW_ID bits 5:4): " + " ".join(str((int(v) >> 4) & 3) for v in st[63, :8]))
         print("step  len   " + " ".join("%8s" % s for s in names[1:]))
         for s in range(nb):
