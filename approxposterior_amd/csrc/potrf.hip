@@ -118,11 +118,17 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
 #ifdef PP_STAMPS     // (persistent kernel, stamped build: the factorising wavefront of the last row workgroup)
 __device__ unsigned long long pp_fstamps[64 * 8];
 #define PANEL_HOOK(i_) do { if ((int)blockIdx.x == (int)((a.n + PB - 1) / PB) - 1 && lane == 0) pp_fstamps[(j0 / PB) * 8 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long pp_gstamps[64 * 8];   // shader-clock stamps inside the group of columns 52 .. 55
+#define PANEL_GHOOK(i_) do { if (c0 == 52 && (int)blockIdx.x == (int)((a.n + PB - 1) / PB) - 1 && lane == 0) pp_gstamps[(j0 / PB) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int apgp_debug_read_gstamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_gstamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -2;
+}
 extern "C" int apgp_debug_read_fstamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_fstamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -2;
 }
 #else
 #define PANEL_HOOK(i_) do { } while (0)
+#define PANEL_GHOOK(i_) do { } while (0)
 #endif
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 // every LDS spin between wavefronts is bounded (2^18 polls, tens of ms): a role that never publishes makes the result wrong,
@@ -255,6 +261,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
         // (1) the CB x CB diagonal block, as updated so far, and the CB right-hand-side entries
         // into every lane (uniform registers)
         double d[CB][CB], zb[CB];
+        if (c0 == 52) { PANEL_FENCE(); PANEL_GHOOK(0); PANEL_FENCE(); }
 #pragma unroll
         for (int r = 0; r < CB; ++r) {
 #pragma unroll
@@ -262,6 +269,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
             if constexpr (RHS) zb[r] = bcast_lane(ri, c0 + r);
         }
         if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(6); }
+        if (c0 == 52) { PANEL_FENCE(); PANEL_GHOOK(1); PANEL_FENCE(); }
         // (2) its factor, computed by all lanes alike: the serial chain of CB pivots runs on
         // registers alone -- no cross-lane step, no LDS round trip, no branch per pivot.  Per
         // pivot: v_rsq_f64 seed, one third-order step (r (1 + e/2 + 3 e^2/8), e = 1 - p r^2:
@@ -295,16 +303,22 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
             }
         }
         if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(7); }
+        if (c0 == 52) { PANEL_FENCE(); PANEL_GHOOK(2); PANEL_FENCE(); }
         // (3) every lane solves its own row against it (rows of the block itself reproduce the
         // factor bit for bit: same operations in the same order)
         double x[CB];
+        // (the lane comparisons from an opaque copy of the lane number: step- and launch-invariant, hipcc computes all 128
+        // masks of the 16 groups once, keeps them in SGPRs spilled to VGPR lanes and restores each with two v_readlane +
+        // s_nop -- three instructions where one v_cmp does)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
             double sacc = ar[c0 + k];
 #pragma unroll
             for (int m = 0; m < k; ++m) sacc = fma(-x[m], d[k][m], sacc);
             sacc *= inv[k];
-            x[k] = lane == c0 + k ? sq[k] : (lane > c0 + k ? sacc : 0.0);
+            x[k] = ln == c0 + k ? sq[k] : (ln > c0 + k ? sacc : 0.0);
             ar[c0 + k] = x[k];
         }
         if constexpr (RHS) {
@@ -316,6 +330,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
             for (int k = 0; k < CB; ++k) ri = lane == c0 + k ? zb[k] : ri;
         }
         if (c0 == 0) { PANEL_FENCE(); PANEL_STAMP(8); }
+        if (c0 == 52) { PANEL_FENCE(); PANEL_GHOOK(3); PANEL_FENCE(); }
         // (4) publish columns c0 .. c0 + CB - 1 of L_jj and their reciprocal pivots (one lane:
         // 64 lanes storing to one address serialise)
 #pragma unroll
@@ -327,6 +342,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
         }
         PANEL_FENCE();
         if (c0 == 0) { PANEL_STAMP(9); }
+        if (c0 == 52) { PANEL_GHOOK(4); PANEL_FENCE(); }
         if (c0 == 16) PANEL_HOOK(3);
         if (c0 == 48) PANEL_HOOK(4);
         if (c0 == 60) PANEL_HOOK(5);
@@ -345,6 +361,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
         // as broadcast reads, requested TR_AHEAD columns before their use
         panel_trailing<c0, c0 + CB, (c0 < HELPER_COL0 ? HELPER_COL0 : PB), 0, PB>(ar, x, Ls);
         if (c0 == 0) { PANEL_STAMP(10); }
+        if (c0 == 52) { PANEL_FENCE(); PANEL_GHOOK(5); PANEL_FENCE(); }
     });
     PANEL_STAMP(2);
     if (firstbad != 0x7fffffff && wb_index == 0 && lane == 0)

@@ -119,6 +119,17 @@ __device__ __forceinline__ pp_u64 pp_ld(const pp_u64* p) { return __hip_atomic_l
 __device__ __forceinline__ void pp_st(pp_u64* p, pp_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double pp_ld_f64(const double* p) { return __longlong_as_double((long long)pp_ld((const pp_u64*)p)); }
 __device__ __forceinline__ void pp_st_f64(double* p, double v) { pp_st((pp_u64*)p, (pp_u64)__double_as_longlong(v)); }
+// 16-byte buffer store whose data registers stay untouched for two more issue slots.  gfx9's rule "a VMEM store of more
+// than 64 bits followed by a VALU write of its data registers needs a wait state" has an exception in the ISA manual --
+// and in LLVM's hazard recogniser -- for MUBUF stores whose soffset is an SGPR; on this chip the store still reads its
+// data late: hipcc recycled the forwarder's data registers in the very next instruction (v_mov into the first dword)
+// and, whenever no other wavefront's instruction happened to fall in between, lanes 12-15 of every 16 stored the NEXT
+// value's low word under THIS value's tag (found when the receiver moved to a SIMD it shares with a wavefront that
+// rarely yields: factor off by 1e-7 relative, silently).  The empty-looking asm keeps the registers live across the nop.
+#define PP_STORE16(data_, rs_, voff_, soff_, aux_) do {                                              \
+        __builtin_amdgcn_raw_buffer_store_b128((data_), (rs_), (voff_), (soff_), (aux_));            \
+        asm volatile("s_nop 1" : : "v"(data_));                                                      \
+    } while (0)
 __device__ __forceinline__ void pp_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // one failed poll of a global spin: sleeps; every 32nd time looks at the abort word and the clock.
@@ -189,12 +200,30 @@ __device__ __forceinline__ void pp_kstep(const double* Ach, const double* Bch, c
     return;
 #endif
     double af[2], bf[2][4];
+#ifdef PP_EXP_NOLDS      // (timing experiment: the products without their LDS operand reads)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { af[i] = (double)(lane + i + ks); asm volatile("" : "+v"(af[i])); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { bf[j][r] = (double)(lane + r + j); asm volatile("" : "+v"(bf[j][r])); }
+#else
 #pragma unroll
     for (int i = 0; i < 2; ++i) af[i] = Ach[(wr + 16 * i + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int j = 0; j < 2; ++j) bf[j][r] = Bch[(wc + 16 * j + bcol[r]) * 18 + ks * 4 + (lane >> 4)];
+#endif
+#ifdef PP_EXP_LDSONLY    // (timing experiment: the operand reads without the products)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : : "v"(af[i]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : : "v"(bf[j][r]));
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -341,7 +370,7 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
             const unsigned tag = (unsigned)q->call_id;
             const pp_u32x4 g = {(unsigned)__double2loint(ri), tag, (unsigned)__double2hiint(ri), tag};
             const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)q->zstrm, 0, (int)(PP_ZSTRM_WORDS * 8), 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(g, rs_z, (unsigned)(lane * 16), (unsigned)(s * 1024), 16);
+            PP_STORE16(g, rs_z, (unsigned)(lane * 16), (unsigned)(s * 1024), 16);
         }
     }
     PP_STEP_LOOP_END()
@@ -404,8 +433,10 @@ __device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
             for (int k = 0; k < 8; ++k) v[k] = *(const f64x2*)(src0 + (b8 * 8 + k) * 2 * 18);
             PANEL_FENCE();
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_u32x4, v[k]), rs_A, off0 + (unsigned)(b8 * 8 + k) * 2u * row_b, 0, 16);
+            for (int k = 0; k < 8; ++k) {
+                const pp_u32x4 w4 = __builtin_bit_cast(pp_u32x4, v[k]);
+                PP_STORE16(w4, rs_A, off0 + (unsigned)(b8 * 8 + k) * 2u * row_b, 0, 16);
+            }
             PANEL_FENCE();
         }
     }
@@ -507,7 +538,7 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
 #pragma unroll
             for (int k = 0; k < CB; ++k) {
                 const pp_u32x4 g = {(unsigned)__double2loint(xs[k]), tag, (unsigned)__double2hiint(xs[k]), tag};
-                __builtin_amdgcn_raw_buffer_store_b128(g, rs_strm, (unsigned)(lane * 64 + k * 16), (unsigned)((s * 16 + cc) * 4096), 16);
+                PP_STORE16(g, rs_strm, (unsigned)(lane * 64 + k * 16), (unsigned)((s * 16 + cc) * 4096), 16);
             }
             if (cc == 15) PP_STAMPP(s, 22);
         });
@@ -533,7 +564,8 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
     const double* Bs = lds + PP_BS;
     int* xprog = p.cnt + 2; int* bprog = p.cnt + 3;
-    const int mw = __builtin_amdgcn_readfirstlane((t >> 6) - 4);
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int mw = wv - 4;
     const int wr = (mw >> 1) * 32, wc = (mw & 1) * 32;         // this wavefront's 32 x 32 quadrant of both products
     bool dead = false;
     if (r > s) {
@@ -556,6 +588,10 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
 #define PP_KSTAMPS() do { if (mw == 0) { if (g == 0) PP_STAMP(s, 11); if (g == 5) PP_STAMP(s, 9); if (g == 12) PP_STAMP(s, 12); if (g == 14) PP_STAMP(s, 14); if (g == 15) PP_STAMP(s, 4); } } while (0)
 #else
 #define PP_KSTAMPS() do { } while (0)
+#endif
+#ifdef PP_EXP_LATEK      // (debug experiment: no k-step before every group is there)
+    pp_lds_wait_ge(xprog, PB / CB);
+    if (!producer) pp_lds_wait_ge(bprog, PB / CB);
 #endif
     if (producer) {
 #pragma unroll 1
@@ -755,7 +791,7 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
     int* ints = (int*)(lds + PP_INTS);
     const long long n = a.n, lda = a.lda;
     if (t < 24) ints[t] = 0;
-    double rhs_r = 0.0;     // wavefront 3: running right-hand side of the forward solve for matrix row r * 64 + lane
+    double rhs_r = 0.0;     // receiving wavefront: running right-hand side of the forward solve for matrix row r * 64 + lane
     if (w == 0) {
         // block (0, 0), coalesced (lane = column), transposed to lane = row through Ls (n > 64: the block is full)
         const double* src = a.A + lane;
@@ -779,11 +815,21 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
 #ifdef PP_STAMPS
     if (r == q.nb - 1 && lane == 0) pp_stamps[63 * 24 + w] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: SIMD in bits 5:4
 #endif
-    if (w == 0) pp_role_factor(lds_off, karg);
-    else if (w == 1) pp_role_solve(lds_off, karg);
-    else if (w == 3) pp_role_recv(lds_off, karg, rhs_r);
-    else if (w >= 4) pp_role_matrix(lds_off, karg);
-    else pp_role_helper(lds_off, karg);
+    // (the LDS offset through an opaque register: passed as the constant it is, hipcc propagates the dynamic-LDS symbol into
+    // the role functions, where every use becomes a lookup in its dynamic-LDS offset table -- an s_load + s_waitcnt
+    // lgkmcnt(0) twice per 4-column group of the factorisation, behind the LDS stores just issued)
+    unsigned lo = lds_off;
+    asm volatile("" : "+s"(lo));
+    // Roles by wavefront.  Wavefronts w and w + 4 share a SIMD (HW_ID: SIMD = {0, 2, 1, 3}[w & 3]), and a burst of MFMAs holds
+    // that SIMD's double-precision pipe against the other wavefront's fp64 instructions whatever the priorities: the
+    // factorisation loses ~500 cycles whenever a k-step's 32 MFMAs meet one of its column groups.  Other pairings were
+    // measured (factorisation + receiver, solver + helper, matrix wavefronts with each other; receiver and helper swapped;
+    // ...): the factorisation gets faster, the helper or the last k-step slower, the step stays within 2 %.
+    if (w == 0) pp_role_factor(lo, karg);
+    else if (w == 1) pp_role_solve(lo, karg);
+    else if (w == 3) pp_role_recv(lo, karg, rhs_r);
+    else if (w >= 4) pp_role_matrix(lo, karg);
+    else pp_role_helper(lo, karg);
 }
 
 // ---------------------------------------------------------------------------

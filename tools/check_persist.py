@@ -1,6 +1,7 @@
 """Persistent Cholesky (csrc/potrf_persist.h) against the multi-launch path on the GPU box: bit-identity of the
 factor, z and the 5-value record over ragged sizes, non-positive-definite inputs (LAPACK info), the give-up /
-fallback path, a repeated-call stress, and timings of both paths.  Usage: python tools/check_persist.py [quick]"""
+fallback path, a repeated-call stress, and timings of both paths.
+Usage: python tools/check_persist.py [quick] [--lib path/to/an/experimental/libapgp.so]"""
 import ctypes, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +10,10 @@ import torch
 from approxposterior_amd import _lib
 from approxposterior_amd import gp as agp
 
+if "--lib" in sys.argv:
+    i = sys.argv.index("--lib")
+    _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 lib = _lib.load()
 dev = torch.device("cuda:0")
 st = None
@@ -77,6 +82,13 @@ for n in sizes:
             idx = None
         print("n=%5d D=%d  identical=%s  (L diffs %d, first at %s; z diffs %d; record %s vs %s; info %d/%d; fallbacks +%d)" %
               (n, D, same, nd, idx, ndz, o0.tolist() if not same else "=", o1.tolist() if not same else "=", i0, i1, fb1 - fb0), flush=True)
+        if nd and "--diffs" in sys.argv:
+            dd = (L0 - L1).abs()
+            rows = (L0 != L1).any(dim=1).nonzero().flatten().tolist()
+            r0 = rows[0]
+            cols = (L0[r0] != L1[r0]).nonzero().flatten().tolist()
+            print("      max |dL| %.3e (max |L| %.3e); first differing row %d: columns %s, |dL| there %s" %
+                  (dd.max().item(), L1.abs().max().item(), r0, cols[:8], ["%.2e" % dd[r0, c].item() for c in cols[:8]]), flush=True)
         bad += (not same) or (fb1 != fb0)
 
 # non-positive-definite: duplicated points, no white noise to speak of -> a pivot fails somewhere

@@ -75,6 +75,14 @@ if __name__ == "__main__":
         print("arrival at the step's barrier, us after the step's start: wavefronts 0 .. 7 (factor, solve, helper, receiver, matrix x 4) | next step's start")
         for sidx in range(4, min(nb - 2, 10)):
             print("  step %2d: %s | %6.2f" % (sidx, " ".join("%6.2f" % ((ws[sidx, i] - st[sidx, 0]) / 100.0) for i in range(8)), (st[sidx + 1, 0] - st[sidx, 0]) / 100.0))
+        gs = np.zeros(64 * 8, dtype=np.uint64)
+        if hasattr(lib, "apgp_debug_read_gstamps"):
+            lib.apgp_debug_read_gstamps.argtypes = [ctypes.c_void_p]
+            assert lib.apgp_debug_read_gstamps(gs.ctypes.data) == 0
+            gs = gs.reshape(64, 8).astype(np.int64)
+            print("group of columns 52 .. 55 of the factorising wavefront, shader cycles: broadcast | 4 pivots | own entries | publish | trailing (2 groups of 4 columns)")
+            for sidx in range(4, min(nb - 1, 10)):
+                print("  step %2d: %s" % (sidx, " ".join("%6d" % (gs[sidx, i + 1] - gs[sidx, i]) for i in range(5))))
         print("SIMD of wavefronts 0..7 (HW_ID bits 5:4): " + " ".join(str((int(v) >> 4) & 3) for v in st[63, :8]))
         print("step  len   " + " ".join("%8s" % s for s in names[1:]))
         for s in range(nb):
