@@ -1056,6 +1056,47 @@ def test_persistent_cholesky_repeated_calls_leave_no_state(lib_loaded):
     assert lib.apgp_potrf_fallbacks() == fb
 
 
+def test_persistent_cholesky_two_streams_at_once(lib_loaded):
+    """Two host threads evaluate on two streams at the same time.  A persistent launch needs all its workgroups
+    resident; two of them can hold each other's CUs, in which case the bounded spins give up and the evaluation is
+    redone on the launch-per-step path -- slower, never wrong, never hung: every result must be the single-stream one
+    bit for bit, whichever path produced it."""
+    import threading
+    import torch
+    lib = lib_loaded
+    cases = [(1152, _persist_case(1152, 8, 5)), (900, _persist_case(900, 3, 6))]
+    ref = [_nll_eval_raw(lib, torch, c[0], c[1], n, c[2], 0.0, 0) for n, c in cases]
+    streams = [torch.cuda.Stream() for _ in cases]
+    errors = []
+
+    def worker(k):
+        n, c = cases[k]
+        try:
+            with torch.cuda.stream(streams[k]):
+                K = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+                z = torch.empty(n, dtype=torch.float64, device="cuda")
+                info = torch.empty(1, dtype=torch.int32, device="cuda")
+                o5 = torch.empty(5, dtype=torch.float64, device="cuda")
+                o = np.empty(5)
+                for _ in range(40):
+                    rc = lib.apgp_nll_eval(c[0].data_ptr(), n, ctypes.byref(c[2]), c[1].data_ptr(), 0.0, K.data_ptr(), z.data_ptr(),
+                                           info.data_ptr(), o5.data_ptr(), o.ctypes.data, ctypes.c_void_p(streams[k].cuda_stream))
+                    assert rc == 0, lib.apgp_last_error()
+                    streams[k].synchronize()
+                    assert torch.equal(torch.tril(K), ref[k][0]) and torch.equal(z, ref[k][1]) and np.array_equal(o, ref[k][2])
+        except BaseException as e:      # noqa: BLE001  (reported by the main thread)
+            errors.append(e)
+
+    torch.cuda.synchronize()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(len(cases))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "an evaluation hangs"
+    assert not errors, errors[0]
+
+
 @pytest.mark.parametrize("trans", [0, 1])
 @pytest.mark.parametrize("n", [256, 300, 1100, 1153, 2048, 4095, 8000])
 def test_persistent_trsv_bit_identical_to_multi_launch(n, trans, lib_loaded):
