@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o shapes -- $B > $out/trace.log 2>&1; echo "trace rc=$?"
 timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -o shapes -- $B > $out/pmc_sq.log 2>&1; echo "pmc_sq rc=$?"
 timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mem -o shapes -- $B > $out/pmc_mem.log 2>&1; echo "pmc_mem rc=$?"
+timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS --output-format csv -d $out/pmc_write -o shapes -- $B > $out/pmc_write.log 2>&1; echo "pmc_write rc=$?"
 python3 - "$out" <<'PY'
 import csv, glob, json, os, sys, collections
 root = sys.argv[1]
@@ -18,7 +19,7 @@ res = collections.OrderedDict()
 def rows(pat):
     f = glob.glob(os.path.join(root, pat, "**", "*counter_collection.csv"), recursive=True)
     return list(csv.DictReader(open(f[0]))) if f else []
-for pat in ("pmc_sq", "pmc_mem"):
+for pat in ("pmc_sq", "pmc_mem", "pmc_write"):
     per = collections.OrderedDict()
     for r in rows(pat):
         if "sweep2_kernel<" not in r["Kernel_Name"]:
