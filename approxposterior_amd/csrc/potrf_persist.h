@@ -12,24 +12,29 @@
 // Row workgroup r lives through the steps s = 0 .. r.  At step s < r it holds T = tile (r, s) and D = the diagonal
 // block (s, s), both updated with the block columns < s, and runs the panel step of the multi-launch path:
 //   wavefront 0  factorises D (redundantly in every row workgroup, as before: no workgroup waits for a factor);
-//   wavefront 2  is its helper (columns 32 .. 63 of groups 0 .. 7);
-//   wavefront 1  solves the 64 rows of T one 4-column group behind, and PUBLISHES each solved group: to LDS (the A
-//                operand of this workgroup's next products) and -- in workgroup s + 1 only, whose rows are the B
-//                operand of everybody's next products -- to global memory as data-tagged granules
-//                ({value half, tag} in one 8-byte word; the consumer needs no flag, the producer no fence or wait);
-//   wavefront 3  receives the groups of L(s+1, s) (one 8-byte agent-scope load per granule, polled) into LDS, and
+//   wavefront 2  is its helper (columns 32 .. 63 of groups 0 .. 7; it hands the next group's four columns back first);
+//                afterwards it stages the NEXT step's two tiles -- tile (r, s+1) and the diagonal block (s+1, s+1),
+//                final in memory once the update workgroups have flagged them -- in LDS, coalesced, exactly where the
+//                hand-over puts the differences (pp_stage_tiles);
+//   wavefront 1  solves the 64 rows of T one 4-column group behind and publishes each solved group to LDS (the A
+//                operand of this workgroup's next products); once done it stores L(r, s) to memory (write-through;
+//                the flag for the update workgroups follows at the head of the next step, when the stores have drained);
+//   wavefront 3  in workgroup s + 1 -- whose rows are the B operand of everybody's next products -- forwards every
+//                solved group to global memory as data-tagged granules (16 bytes per value: {low word, tag, high
+//                word, tag}; the consumer needs no flag, the producer no fence or wait); in every other workgroup it
+//                receives them (four 16-byte write-through-coherent loads per lane and look) into LDS; it also
 //                carries this block row's right-hand side of the forward solve z = L^-1 (y - mean);
 //   wavefronts 4-7 multiply: tile (r, s+1) -= L(r, s) L(s+1, s)^T and the next diagonal block (s+1, s+1) -=
-//                L(s+1, s) L(s+1, s)^T, one k = 4 step of v_mfma_f64_4x4x4_4b per published group, so that when the
-//                last group of the factorisation is out only ONE k-step, the subtraction from the tiles' values in
-//                memory (requested four groups earlier) and the LDS hand-over to wavefronts 0 / 1 remain.
+//                L(s+1, s) L(s+1, s)^T, one k = 4 step of v_mfma_f64_4x4x4_4b per published group (no memory access),
+//                so that when the last group of the factorisation is out only ONE k-step, the subtraction from the
+//                staged values and the workgroup's one barrier per step remain.
 //   The critical path per 64-column step is then the factorisation itself + one granule hand-off + one k-step
 //   (the multi-launch path: launch boundary + operand loads + two 64^3 products + factorisation).
 //   At step r the workgroup factorises its own diagonal block for the output (L_rr, info, z_r): nobody waits for that.
-// Update workgroups apply block column s to the tiles (i, q), q >= s + 2 ("update step" s), two tiles at a time,
-//   as soon as all rows of L(:, s) are in memory (row workgroups store them at the start of their next step) -- one
-//   whole row step ahead of their use: tile (i, s + 2) is needed at the END of row step s + 1.  Tiles are owned
-//   statically (column-major index modulo the number of update half-workgroups), column s + 2 first.
+// Update workgroups apply block column s to the tiles (i, q), q >= s + 2 ("update step" s), one tile at a time on all
+//   eight wavefronts, as soon as all rows of L(:, s) are in memory -- one whole row step ahead of their use: tile
+//   (i, s + 2) is needed at the END of row step s + 1.  Tiles are owned statically (column-major index modulo the
+//   number of update workgroups), column s + 2 first.
 //
 // Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility; measured with tools/probes/handoff_probe.hip):
 //   payload stores are write-through (sc1), every storing wavefront drains (s_waitcnt vmcnt(0)) before ONE relaxed
@@ -156,7 +161,7 @@ __device__ __forceinline__ void pp_lds_wait_ge(const int* p, int need) {
 // wavefront 1 of a row workgroup: panel_solve_wave with every solved 4-column group published at once to As (this
 // workgroup's A operand, chunk layout).  In the workgroup whose rows are everybody's B operand wavefront 3 forwards
 // the groups from there to the granule stream (the stores would cost the solving wavefront ~1 us per step, and its
-// groups pace everybody).  The rows themselves go to memory from As at the start of the next step (matrix wavefronts).
+// groups pace everybody).  The rows themselves go to memory from As once all sixteen groups are solved (pp_role_solve).
 __device__ __forceinline__ void pp_solve_wave(const int lane, double (&x)[PB], const double (*Ls)[PB + 2], const double* invd,
                                               int* prog_p, double* As_par, int* xprog_p) {
     static_for<PB / CB>([&](auto cc_) {
@@ -278,7 +283,6 @@ struct PpStep {            // what every role derives from (r, s)
     long long j0;
     bool producer;
     int* cnt;              // this step's counters: 0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 As_prev free
-    int* wocnt;
     int* abl;
     double* As_cur;
     double* As_prev;
@@ -291,10 +295,9 @@ __device__ __forceinline__ PpStep pp_step(double* lds, int s_in, long long n) {
     p.bs = (int)((n - p.j0) < PB ? (n - p.j0) : PB);
     p.producer = p.r == p.s + 1;                               // this workgroup's rows are the B operand of the step
     int* ints = (int*)(lds + PP_INTS);
-    // step-parity counters: [par][0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 As_prev free]; others: 16 wocnt | 17, 18 "give up" by
+    // step-parity counters: [par][0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 As_prev free]; others: 17, 18 "give up" by
     // step parity (set during step s, read at the head of step s + 1: never while it may still be written)
     p.cnt = ints + 8 * (p.s & 1);
-    p.wocnt = ints + 16;
     p.abl = ints + 17 + (p.s & 1);
     p.As_cur = lds + PP_AS + (p.s & 1) * 4 * PP_CHUNK;         // this step's solved tile; at the step's start: the handed-over tile [64][66]
     p.As_prev = lds + PP_AS + ((p.s & 1) ^ 1) * 4 * PP_CHUNK;  // L(r, s-1); at the step's end: the hand-over of the next tile
@@ -588,10 +591,6 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
 #define PP_KSTAMPS() do { if (mw == 0) { if (g == 0) PP_STAMP(s, 11); if (g == 5) PP_STAMP(s, 9); if (g == 12) PP_STAMP(s, 12); if (g == 14) PP_STAMP(s, 14); if (g == 15) PP_STAMP(s, 4); } } while (0)
 #else
 #define PP_KSTAMPS() do { } while (0)
-#endif
-#ifdef PP_EXP_LATEK      // (debug experiment: no k-step before every group is there)
-    pp_lds_wait_ge(xprog, PB / CB);
-    if (!producer) pp_lds_wait_ge(bprog, PB / CB);
 #endif
     if (producer) {
 #pragma unroll 1

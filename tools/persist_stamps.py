@@ -36,7 +36,7 @@ if __name__ == "__main__":
     lib.apgp_debug_read_stamps.argtypes = [ctypes.c_void_p]
     from approxposterior_amd import gp as agp
     dev = torch.device("cuda:0")
-    names = ["start", "factor", "solve", "recv16", "k15", "flags", "handover", "zappl", "L-out", "k11", "recv1", "k0", "k12", "k13", "k14", "recv15", "P-start", "P-solve", "P-fwd16", "P-fwd1"]
+    names = ["start", "factor", "solve", "recv16", "k15", "flags", "handover", "zappl", "L-out", "k11", "recv1", "k0", "k12", "k13", "k14", "recv15", "helper-done", "tiles-final", "tile-staged", "diag-staged"]
     for n in [int(a) for a in sys.argv[1:]] or [1152]:
         D = 8
         rs = np.random.RandomState(n)
