@@ -60,6 +60,12 @@ struct PotrfArgs {
     // then reports PP_ABORTED in the summary's info slot and the host re-runs on the multi-launch path
     const unsigned long long* abort_word;
     unsigned long long abort_id;
+    // hybrid factorisation (large n: the first block columns by the launch-per-step path, the rest by ONE persistent
+    // launch on the trailing matrix): the step that hands over applies its block column to the whole trailing matrix and
+    // writes the first tile column back instead of carrying on with the panel (no_panel); the persistent launch sees the
+    // trailing matrix as its own (A, rhs, dscr shifted) and reports failing pivots in the full matrix's numbering (info_j0)
+    int no_panel;
+    long long info_j0;
 };
 
 // matrix of this workgroup in a batched launch (gridDim.y = batch size; strides 0 otherwise)
@@ -365,7 +371,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
     });
     PANEL_STAMP(2);
     if (firstbad != 0x7fffffff && wb_index == 0 && lane == 0)
-        atomicMin((unsigned int*)a.info, (unsigned int)(j0 + firstbad));
+        atomicMin((unsigned int*)a.info, (unsigned int)(a.info_j0 + j0 + firstbad));
     if constexpr (RHS) {
         if (a.rhs) {
             zblk[lane] = ri;
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
     a.A = q.K; a.rhs = q.z; a.n = q.n; a.lda = q.n; a.j0 = 0; a.shift = 0.0; a.info = q.info; a.out5 = nullptr;
     a.mail = nullptr; a.seq = 0;
     a.dscr = nullptr; a.batch_dscr = 0; a.zoff = 0; a.batch_A = 0; a.batch_rhs = 0;
-    a.abort_word = nullptr; a.abort_id = 0;
+    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0;
     double ar[PB];
     const double ri = lane < bs ? q.y[lane] - q.shift : 0.0;
 #pragma unroll
@@ -730,6 +736,20 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
                     v[i][j][r] = cin[i][j][r] - v[i][j][r];
                     v2[i][j][r] = cin2[i][j][r] - v2[i][j][r];
                 }
+    }
+    if (a.no_panel) {
+        // hand-over to the persistent launch (hybrid): the updated first tile column goes to memory like any other tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long gr = ri + wr + 16 * i + apgp_mma16_row(lane);
+                    const long long gc = rk + wc + 16 * j + apgp_mma16_col(lane, r);
+                    if (gr < a.n && gc < a.n && gc <= gr) a.A[gr * a.lda + gc] = v[i][j][r];
+                }
+        return;
     }
     // ---------------- first tile column: the panel step of block column `base` ----------------
     STEP_STAMP(1);
@@ -906,29 +926,44 @@ static int potrf_device_cus(int dev) {
 
 // the persistent launch serves one matrix of 64 < n <= 4096 whose byte offsets fit the buffer descriptor, on a device
 // with a CU for every row workgroup and at least one more
-static bool potrf_persist_applies(int64_t n, int64_t lda, hipStream_t s) {
-    if (g_potrf_mode.load() == 1) return false;
+// How an n x n factorisation (n > 64) is run: -1 = a launch per 64-column step; 0 = ONE persistent launch;
+// s0 > 0 = hybrid: the first s0 block columns a launch per step, the trailing (nb - s0) x (nb - s0) blocks as one
+// persistent launch.
+// (measured, apgp_nll_eval: 0.169 vs 0.208 ms at n = 512, 0.371 vs 0.466 at 1152, 0.717 vs 0.881 at 2048, 1.18 vs 1.38 at 3072, 1.68 vs 1.73 at
+// 3712, but 1.84 vs 1.80 at 3840 and 2.08 vs 1.99 at 4096: while the trailing matrix is large a step is bound by the update's
+// memory traffic (45 us at 4096 against 23.5 once it is small), and there the multi-launch path has all 256 CUs on it -- so
+// above PP_AUTO_NB block columns the first steps are its launches and the persistent launch takes over for the last
+// PP_HYBRID_NB block columns, where a step is a latency chain)
+#define PP_HYBRID_NB 48
+static long long potrf_plan(int64_t n, int64_t lda, hipStream_t s) {
+    const int mode = g_potrf_mode.load();
+    if (mode == 1) return -1;
     const int64_t nb = (n + PB - 1) / PB;
-    // (measured, apgp_nll_eval: 0.177 vs 0.208 ms at n = 512, 0.406 vs 0.470 at 1152, 0.78 vs 0.88 at 2048, 1.25 vs 1.37 at 3072, but 2.08 vs
-    // 1.99 at 4096, where the trailing update's throughput decides and the multi-launch path keeps all 256 CUs on it:
-    // mode 0 takes the persistent launch up to PP_AUTO_NB block columns; mode 3 forces it wherever it can run)
-    if (nb < 2 || nb > PP_MAX_NB) return false;
-    if (nb > PP_AUTO_NB && g_potrf_mode.load() != 3) return false;
-    if (lda * n * 8 >= (1ll << 31)) return false;
-    return potrf_device_cus(apgp_stream_device(s)) >= nb + 1;
+    if (nb < 2) return -1;
+    const int cus = potrf_device_cus(apgp_stream_device(s));
+    if (nb <= PP_MAX_NB && (nb <= PP_AUTO_NB || mode == 3)) {
+        if (lda * n * 8 >= (1ll << 31) || cus < nb + 1) return -1;
+        return 0;
+    }
+    if (mode == 2) return -1;                                            // (the fallback test runs whole persistent launches)
+    const long long s0 = nb - PP_HYBRID_NB;
+    if (lda * (n - s0 * PB) * 8 >= (1ll << 31) || cus < PP_HYBRID_NB + 1) return -1;
+    return s0;
 }
 
 // gram (pre_init) -> ONE persistent launch -> potrf_finish_kernel (summary, factored diagonal blocks into place).
 // Caller holds apgp_stream_lock(s).  The summary's info slot reads PP_ABORTED if the launch gave up.
+// s0 > 0 (hybrid): block columns 0 .. s0 - 1 were factorised and applied to the whole trailing matrix by the
+// launch-per-step path (z blocks and running right-hand side included); this launch factorises the trailing matrix.
 static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, int32_t* info_dev, hipStream_t s,
-                                double* out5, double* mail, long long seq) {
+                                double* out5, double* mail, long long seq, long long s0 = 0) {
     const int dev = apgp_stream_device(s);
-    const long long nb = (n + PB - 1) / PB;
+    const long long nb_all = (n + PB - 1) / PB, nb = nb_all - s0;
     PersistArgs q;
     PotrfArgs& a = q.a;
     a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.j0 = 0; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
-    a.mail = mail; a.seq = seq; a.batch_A = 0; a.batch_rhs = n;
-    a.zoff = nb * (long long)(PB * PB); a.batch_dscr = a.zoff + nb * PB;
+    a.mail = mail; a.seq = seq; a.batch_A = 0; a.batch_rhs = n; a.no_panel = 0; a.info_j0 = 0;
+    a.zoff = nb_all * (long long)(PB * PB); a.batch_dscr = a.zoff + nb_all * PB;
     a.dscr = apgp_stream_scratch(0, s, (size_t)a.batch_dscr);
     bool fresh = false;
     unsigned long long* calls = nullptr;
@@ -949,6 +984,16 @@ static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, in
     q.nb = (int)nb;
     q.debug = g_potrf_mode.load() == 2 ? 1 : 0;
     a.abort_word = pw + PP_CTL_ABORT; a.abort_id = id;
+    const PotrfArgs full = a;                                           // (the finish kernel works on the whole matrix)
+    if (s0 > 0) {
+        const long long off = s0 * PB;
+        a.A = A + off * lda + off;
+        a.n = n - off;
+        if (z) a.rhs = z + off;
+        a.zoff = full.zoff - s0 * (long long)(PB * PB) + off;           // (dscr + zoff addresses the same z array)
+        a.dscr = full.dscr + s0 * (long long)(PB * PB);
+        a.info_j0 = off;
+    }
     {
         static std::mutex attr_mu;
         static bool attr_set[64] = {false};
@@ -967,7 +1012,7 @@ static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, in
     if (nupd > room) nupd = room;
     if (nupd < 1) nupd = 1;
     hipLaunchKernelGGL(potrf_persist_kernel, dim3((unsigned)(nb + nupd)), dim3(PP_THREADS), PP_LDS_BYTES, s, q);
-    hipLaunchKernelGGL(potrf_finish_kernel, dim3((unsigned)nb, 1u), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(potrf_finish_kernel, dim3((unsigned)nb_all, 1u), dim3(256), 0, s, full);
     APGP_CHECK_LAUNCH();
     return 0;
 }
@@ -980,7 +1025,9 @@ static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, in
 // (caller holds apgp_stream_lock(s))
 static int potrf_run_locked(double* A, int64_t n, int64_t lda, int64_t batch, int64_t batch_A, const double* y,
                             const double* shifts, double* z, int32_t* info_dev, hipStream_t s, bool pre_init = false,
-                            double* out5 = nullptr, double* mail = nullptr, long long seq = 0) {
+                            double* out5 = nullptr, double* mail = nullptr, long long seq = 0, long long stop_at = 0) {
+    // stop_at = s0 > 0 (hybrid, batch 1): block columns 0 .. s0 - 1 only; the last step applies column s0 - 1 to the whole
+    // trailing matrix, writes the first tile column back and leaves the rest -- and the finish kernel -- to the caller
     // info = UINT_MAX means "no failure yet"; normalised to 0 by the caller-visible finish kernel
     if (!pre_init && hipMemsetAsync(info_dev, 0xff, sizeof(int32_t) * batch, s) != hipSuccess) {
         apgp_set_error("apgp_potrf: memset failed");
@@ -990,7 +1037,7 @@ static int potrf_run_locked(double* A, int64_t n, int64_t lda, int64_t batch, in
     a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
     a.mail = mail; a.seq = seq;
     a.batch_A = batch_A; a.batch_rhs = n;
-    a.abort_word = nullptr; a.abort_id = 0;
+    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0;
     if (z && !pre_init)
         for (int64_t b = 0; b < batch; ++b)
             hipLaunchKernelGGL(potrf_rhs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, shifts[b],
@@ -1014,8 +1061,13 @@ static int potrf_run_locked(double* A, int64_t n, int64_t lda, int64_t batch, in
     }
     for (long long jb = 0; jb + 1 < nb; ++jb) {
         a.j0 = jb * PB;
+        a.no_panel = (stop_at > 0 && jb == stop_at - 1) ? 1 : 0;
         const long long tb = (n - (a.j0 + PB) + PB - 1) / PB;
         hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(tb + tb * (tb - 1) / 2), (unsigned)batch), dim3(256), 0, s, a);
+        if (a.no_panel) {
+            APGP_CHECK_LAUNCH();
+            return 0;
+        }
     }
     hipLaunchKernelGGL(potrf_finish_kernel, dim3((unsigned)nb, (unsigned)batch), dim3(256), 0, s, a);
     APGP_CHECK_LAUNCH();
@@ -1104,8 +1156,13 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
         // and the info word, the Cholesky's last launch writes the summary
         rc = apgp_gram_with_rhs(X, n, kern, K, n, y, mean, z, info_dev, stream);
         if (rc != 0) return rc;
-        const bool persist = potrf_persist_applies(n, n, s);
-        rc = persist ? potrf_persist_locked(K, n, n, z, info_dev, s, out5_dev, mail ? mb->dev : nullptr, seq)
+        const long long plan = potrf_plan(n, n, s);
+        const bool persist = plan >= 0;
+        if (plan > 0) {
+            rc = potrf_run_locked(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, nullptr, nullptr, 0, plan);
+            if (rc != 0) return rc;
+        }
+        rc = persist ? potrf_persist_locked(K, n, n, z, info_dev, s, out5_dev, mail ? mb->dev : nullptr, seq, plan)
                      : potrf_run_locked(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, out5_dev, mail ? mb->dev : nullptr, seq);
         if (rc != 0) return rc;
         if (persist) {

@@ -49,7 +49,7 @@ typedef unsigned long long pp_u64;
 typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
 
 #define PP_MAX_NB 64
-#define PP_AUTO_NB 48                                // block columns up to which the persistent launch is the default
+#define PP_AUTO_NB 58                                // block columns up to which the persistent launch is the default
 #define PP_THREADS 512
 #define PP_CHUNK (64 * 18)                        // a 16-column chunk of a 64-row tile, rows padded to 18 (apgp_gemm64_tile's)
 // LDS map of a row workgroup (doubles)
@@ -335,7 +335,7 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     PotrfArgs pa;
     pa.A = q->a.A; pa.rhs = nullptr;                           // (the forward solve is a separate pass below)
     pa.n = n; pa.lda = q->a.lda; pa.j0 = p.j0; pa.shift = 0.0; pa.info = q->a.info; pa.out5 = nullptr; pa.mail = nullptr; pa.seq = 0;
-    pa.dscr = q->a.dscr; pa.batch_dscr = 0; pa.zoff = q->a.zoff; pa.batch_A = 0; pa.batch_rhs = 0; pa.abort_word = nullptr; pa.abort_id = 0;
+    pa.dscr = q->a.dscr; pa.batch_dscr = 0; pa.zoff = q->a.zoff; pa.batch_A = 0; pa.batch_rhs = 0; pa.abort_word = nullptr; pa.abort_id = 0; pa.no_panel = 0; pa.info_j0 = q->a.info_j0;
     panel_factor_wave<false>(pa, p.j0, bs, lane, rowv, 0.0, Ls, invd, zblk, p.cnt + 0, p.cnt + 1, r == s ? 0 : PB, 1);
     PP_STAMP(s, 1);
     if (r == s && q->a.rhs) {

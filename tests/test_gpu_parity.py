@@ -1056,6 +1056,27 @@ def test_persistent_cholesky_repeated_calls_leave_no_state(lib_loaded):
     assert lib.apgp_potrf_fallbacks() == fb
 
 
+@pytest.mark.parametrize("n,D,dup", [(3800, 8, None), (4096, 8, None), (5000, 5, None), (4096, 3, 3000)])
+def test_hybrid_cholesky_bit_identical_to_multi_launch(n, D, dup, lib_loaded):
+    """Above 58 block columns the default is the hybrid (round 4): the first block columns a launch per 64-column step --
+    while the trailing update's memory traffic bounds a step -- and the last 48 as ONE persistent launch on the trailing
+    matrix (shifted base pointers, pivot numbering of the full matrix, the running right-hand side handed over in
+    place).  Same bits as the launch-per-step path all the way: factor, z, record, LAPACK info (also on a matrix that
+    is not positive definite inside the persistent part's range)."""
+    import torch
+    lib = lib_loaded
+    X_d, y_d, ks = _persist_case(n, D, n + D, wn=-60.0 if dup is not None else -12.0, dup=dup)
+    L1, z1, o1, i1 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.25, 1)
+    fb = lib.apgp_potrf_fallbacks()
+    L0, z0, o0, i0 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.25, 0)
+    assert lib.apgp_potrf_fallbacks() == fb
+    assert i0 == i1 and o0[4] == o1[4]
+    if dup is None:
+        assert i0 == 0 and np.array_equal(o0, o1) and torch.equal(L0, L1) and torch.equal(z0, z1)
+    else:
+        assert i0 > 0
+
+
 def test_persistent_cholesky_two_streams_at_once(lib_loaded):
     """Two host threads evaluate on two streams at the same time.  A persistent launch needs all its workgroups
     resident; two of them can hold each other's CUs, in which case the bounded spins give up and the evaluation is

@@ -104,6 +104,30 @@ for n, dup_at in ((200, 70), (700, 650), (1152, 64), (1152, 1100)):
     print("non-PD n=%d dup at %d: info persistent %d, multi-launch %d -> %s" % (n, dup_at, i0, i1, "ok" if ok else "MISMATCH"), flush=True)
     bad += not ok
 
+# hybrid (default mode above PP_AUTO_NB = 58 block columns): the first block columns a launch per step, the last 48 as one
+# persistent launch on the trailing matrix -- against the launch-per-step path
+if not quick:
+    for n, D, dup in ((3800, 8, None), (4095, 5, None), (4096, 8, None), (5000, 8, None), (4096, 3, 3000), (4096, 3, 500)):
+        rs = np.random.RandomState(n + D)
+        X = rs.uniform(-5, 5, size=(n, D))
+        if dup is not None:
+            X[dup] = X[dup - 1]; X[dup + 1] = X[dup - 1]
+        y = rs.normal(size=n)
+        X_d = torch.from_numpy(X).to(dev); y_d = torch.from_numpy(y).to(dev)
+        ks = kern(D, wn=-60.0) if dup is not None else kern(D)
+        L1, z1, o1, i1 = nll(X_d, y_d, n, ks, 0.25, 1)
+        fb0 = lib.apgp_potrf_fallbacks()
+        L0, z0, o0, i0 = nll(X_d, y_d, n, ks, 0.25, 0)
+        fb1 = lib.apgp_potrf_fallbacks()
+        if dup is None:
+            same = torch.equal(L0, L1) and torch.equal(z0, z1) and np.array_equal(o0, o1) and i0 == i1 and fb1 == fb0
+        else:
+            same = i0 == i1 and o0[4] == o1[4] and i0 > 0 and fb1 == fb0
+        print("hybrid n=%5d D=%d%s  %s  (L diffs %d, z diffs %d, info %d/%d, fallbacks +%d)" %
+              (n, D, "" if dup is None else " non-PD (dup at %d)" % dup, "identical" if same else "MISMATCH",
+               int((L0 != L1).sum().item()), int((z0 != z1).sum().item()), i0, i1, fb1 - fb0), flush=True)
+        bad += not same
+
 # give-up path: mode 2 makes workgroup 0 abort at once; the call must come back with the multi-launch result
 n, D = 1152, 8
 rs = np.random.RandomState(3)
@@ -129,7 +153,7 @@ for it in range(50 if quick else 300):
 print("stress n=%d: %d deviating calls, fallbacks so far %d" % (n, nbad, lib.apgp_potrf_fallbacks()), flush=True)
 bad += nbad
 
-for n in (512, 1152, 2048, 2560, 3072, 4096):
+for n in (512, 1152, 2048, 2560, 3072, 3712, 4096, 6144):
     if quick and n > 1152:
         break
     rs = np.random.RandomState(n)
@@ -138,7 +162,8 @@ for n in (512, 1152, 2048, 2560, 3072, 4096):
     ks = kern(8)
     t1 = timeit(X_d, y_d, n, ks, 0.0, 1, 20)
     t0 = timeit(X_d, y_d, n, ks, 0.0, 3, 20)
-    print("apgp_nll_eval n=%4d: multi-launch %.3f ms, persistent %.3f ms" % (n, t1 * 1e3, t0 * 1e3), flush=True)
+    td = timeit(X_d, y_d, n, ks, 0.0, 0, 20)
+    print("apgp_nll_eval n=%4d: multi-launch %.3f ms, persistent %.3f ms, default %.3f ms" % (n, t1 * 1e3, t0 * 1e3, td * 1e3), flush=True)
 lib.apgp_potrf_mode(0)
 print("FAILURES: %d" % bad)
 sys.exit(1 if bad else 0)
