@@ -66,6 +66,11 @@ struct PotrfArgs {
     // trailing matrix as its own (A, rhs, dscr shifted) and reports failing pivots in the full matrix's numbering (info_j0)
     int no_panel;
     long long info_j0;
+    // paired trailing updates (large trailing matrices, where a step is bound by the update's memory traffic): a NARROW
+    // step (pair_mode 1) applies its block column to the first TWO tile columns only, the WIDE step after it (2) applies
+    // both block columns to every other tile in ONE pass over the tile -- two products, each accumulated from zero and
+    // subtracted in turn: the bits of two separate passes, half their traffic.  0 = every step applies its own column.
+    int pair_mode;
 };
 
 // matrix of this workgroup in a batched launch (gridDim.y = batch size; strides 0 otherwise)
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
     a.A = q.K; a.rhs = q.z; a.n = q.n; a.lda = q.n; a.j0 = 0; a.shift = 0.0; a.info = q.info; a.out5 = nullptr;
     a.mail = nullptr; a.seq = 0;
     a.dscr = nullptr; a.batch_dscr = 0; a.zoff = 0; a.batch_A = 0; a.batch_rhs = 0;
-    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0;
+    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0;
     double ar[PB];
     const double ri = lane < bs ? q.y[lane] - q.shift : 0.0;
 #pragma unroll
@@ -663,6 +668,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
     const bool first = (long long)blockIdx.x < tb;
     long long bi, bk;
     if (first) { bi = blockIdx.x; bk = 0; }
+    else if (a.pair_mode == 1) { bi = (long long)blockIdx.x - tb + 1; bk = 1; }      // narrow step: the second tile column only
     else {
         // the other tiles: lower triangle of the (tb - 1) x (tb - 1) blocks below / right of tile (0, 0)
         const long long tix = (long long)blockIdx.x - tb;
@@ -692,6 +698,20 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
                     cin[i][j][r] = (gr < a.n && gc < a.n && gc <= gr) ? a.A[gr * a.lda + gc] : 0.0;
                     v[i][j][r] = 0.0;
                 }
+        if (a.pair_mode == 2) {
+            // wide step: the previous block column first (its narrow step left these tiles alone), then this one
+            apgp_gemm64_tile<false, false>(a.A + ri * a.lda + a.j0 - PB, a.lda, a.n - ri, a.A + rk * a.lda + a.j0 - PB, a.lda, a.n - rk,
+                                           0, PB, lds, v);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        cin[i][j][r] = cin[i][j][r] - v[i][j][r];
+                        v[i][j][r] = 0.0;
+                    }
+        }
         apgp_gemm64_tile<false, false>(a.A + ri * a.lda + a.j0, a.lda, a.n - ri, a.A + rk * a.lda + a.j0, a.lda, a.n - rk,
                                        0, PB, lds, v);
 #pragma unroll
@@ -903,11 +923,16 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
 // once (exercises the fallback) | 3 = persistent wherever it can run (n <= 4096).  A test / profiling switch
 // (apgp_potrf_mode), not read from the environment.
 static std::atomic<int> g_potrf_mode{0};
+// paired trailing updates of the launch-per-step path (PotrfArgs::pair_mode) from this many trailing block rows on;
+// apgp_potrf_mode(mode | 16) switches them off (A/B and bit-identity tests), plain modes switch them on again
+#define POTRF_PAIR_MIN_TB 24
+static std::atomic<int> g_potrf_pairs{1};
 static std::atomic<long long> g_potrf_fallbacks{0};
 extern "C" int apgp_potrf_mode(int mode) {
-    if (mode < 0) return g_potrf_mode.load();
-    if (mode > 3) { apgp_set_error("apgp_potrf_mode: bad argument: mode 0 .. 3"); return -1; }
-    return g_potrf_mode.exchange(mode);
+    if (mode < 0) return g_potrf_mode.load() | (g_potrf_pairs.load() ? 0 : 16);
+    if ((mode & ~16) > 3) { apgp_set_error("apgp_potrf_mode: bad argument: mode 0 .. 3 (+ 16: no paired trailing updates)"); return -1; }
+    const int prev = g_potrf_mode.exchange(mode & 15) | (g_potrf_pairs.exchange((mode & 16) ? 0 : 1) ? 0 : 16);
+    return prev;
 }
 extern "C" int64_t apgp_potrf_fallbacks(void) { return g_potrf_fallbacks.load(); }
 
@@ -962,7 +987,7 @@ static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, in
     PersistArgs q;
     PotrfArgs& a = q.a;
     a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.j0 = 0; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
-    a.mail = mail; a.seq = seq; a.batch_A = 0; a.batch_rhs = n; a.no_panel = 0; a.info_j0 = 0;
+    a.mail = mail; a.seq = seq; a.batch_A = 0; a.batch_rhs = n; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0;
     a.zoff = nb_all * (long long)(PB * PB); a.batch_dscr = a.zoff + nb_all * PB;
     a.dscr = apgp_stream_scratch(0, s, (size_t)a.batch_dscr);
     bool fresh = false;
@@ -1037,7 +1062,7 @@ static int potrf_run_locked(double* A, int64_t n, int64_t lda, int64_t batch, in
     a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
     a.mail = mail; a.seq = seq;
     a.batch_A = batch_A; a.batch_rhs = n;
-    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0;
+    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0;
     if (z && !pre_init)
         for (int64_t b = 0; b < batch; ++b)
             hipLaunchKernelGGL(potrf_rhs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, shifts[b],
@@ -1059,11 +1084,18 @@ static int potrf_run_locked(double* A, int64_t n, int64_t lda, int64_t batch, in
         const unsigned pg = below > 0 ? (unsigned)((below + PB - 1) / PB) : 1u;
         hipLaunchKernelGGL(potrf_panel_kernel, dim3(pg, (unsigned)batch), dim3(3 * PB), 0, s, a);
     }
+    // steps are paired (narrow, wide) while the trailing matrix is large; the step that hands over to the persistent
+    // launch -- and the step before an unpaired one -- is never a narrow one (its deferred tiles would be missing)
+    const long long last = (stop_at > 0 ? stop_at : nb - 1) - 1;         // last step launched here
+    int prev_mode = 0;
     for (long long jb = 0; jb + 1 < nb; ++jb) {
         a.j0 = jb * PB;
         a.no_panel = (stop_at > 0 && jb == stop_at - 1) ? 1 : 0;
         const long long tb = (n - (a.j0 + PB) + PB - 1) / PB;
-        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(tb + tb * (tb - 1) / 2), (unsigned)batch), dim3(256), 0, s, a);
+        a.pair_mode = prev_mode == 1 ? 2 : ((g_potrf_pairs.load() && tb >= POTRF_PAIR_MIN_TB && jb + 1 <= last) ? 1 : 0);
+        prev_mode = a.pair_mode;
+        const long long tiles = a.pair_mode == 1 ? tb + (tb - 1) : tb + tb * (tb - 1) / 2;
+        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(256), 0, s, a);
         if (a.no_panel) {
             APGP_CHECK_LAUNCH();
             return 0;

@@ -1077,6 +1077,20 @@ def test_hybrid_cholesky_bit_identical_to_multi_launch(n, D, dup, lib_loaded):
         assert i0 > 0
 
 
+@pytest.mark.parametrize("n,D", [(1700, 3), (3000, 8), (5000, 5)])
+def test_paired_trailing_updates_bit_identical(n, D, lib_loaded):
+    """Launch-per-step Cholesky with its paired trailing updates (a narrow step applies its block column to the first two
+    tile columns, the wide step after it applies both block columns to every other tile in one pass, each product
+    accumulated from zero and subtracted in turn) against the same path with every step applying its own column
+    (mode + 16): factor, z, record the same bits."""
+    import torch
+    lib = lib_loaded
+    X_d, y_d, ks = _persist_case(n, D, n + D)
+    L1, z1, o1, i1 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.25, 1)
+    L0, z0, o0, i0 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.25, 17)
+    assert i0 == i1 == 0 and np.array_equal(o0, o1) and torch.equal(L0, L1) and torch.equal(z0, z1)
+
+
 def test_persistent_cholesky_two_streams_at_once(lib_loaded):
     """Two host threads evaluate on two streams at the same time.  A persistent launch needs all its workgroups
     resident; two of them can hold each other's CUs, in which case the bounded spins give up and the evaluation is
