@@ -1039,7 +1039,10 @@ static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, in
     // update workgroup costs the row workgroups memory latency -- 30 % of the first step's tiles + 8 measured best:
     // 0.361 vs 0.369 ms at n = 1152, 0.521 vs 0.550 at 1600, 0.689 vs 0.716 at 2048, unchanged from 2560 on, where the
     // CUs left beside the row workgroups are the limit)
-    { const long long want = (tiles0 * 30 + 99) / 100 + 8; if (nupd > want) nupd = want; }
+#ifndef PP_NUPD_PCT
+#define PP_NUPD_PCT 30
+#endif
+    { const long long want = (tiles0 * PP_NUPD_PCT + 99) / 100 + 8; if (nupd > want) nupd = want; }
     if (nupd < 1) nupd = 1;
     hipLaunchKernelGGL(potrf_persist_kernel, dim3((unsigned)(nb + nupd)), dim3(PP_THREADS), PP_LDS_BYTES, s, q);
     hipLaunchKernelGGL(potrf_finish_kernel, dim3((unsigned)nb_all, 1u), dim3(256), 0, s, full);

@@ -38,8 +38,9 @@
 //
 // Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility; measured with tools/probes/handoff_probe.hip):
 //   payload stores are write-through (sc1), every storing wavefront drains (s_waitcnt vmcnt(0)) before ONE relaxed
-//   agent-scope flag store; consumers poll ONE word relaxed, then either read with sc1 loads (row workgroups) or
-//   take ONE agent-scope acquire per update step and read plainly (update workgroups: operands stay L2-resident).
+//   agent-scope flag store; consumers poll ONE word relaxed, then read with sc1 (write-through-coherent) loads -- no
+//   acquire anywhere: buffer_inv sc1 empties the XCD's whole L2 for everybody (update workgroups took one per step until
+//   it was measured: 4-5 % of the evaluation at n = 2048 .. 3712).
 //   Flags and granule tags are call-unique (a per-stream call counter), so nothing is zeroed between calls.
 // Every global spin is bounded: on timeout (the workgroups are not all resident -- a foreign kernel holds CUs --
 //   or a bug) the call is marked aborted and the host re-runs the evaluation on the multi-launch path.
@@ -872,14 +873,18 @@ __device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds
     // (a second register set / loads two tiles ahead measured slower: 0.85 vs 0.81 ms at n = 2048, 3.8 vs 2.2 at 4096)
     f64x2 ra[4], rb[4];
     double cin[2][4];
+    const __amdgpu_buffer_rsrc_t rs_Au = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)(lda * n * 8), 0x00020000);
     auto request = [&](const PpTile& tl, long long j0) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int e = it * 512 + t, rw = e >> 5, col = 2 * (e & 31);
             // (unconditional loads from clamped rows, masked when staged / used: see the matrix wavefronts' request)
             const long long ar = tl.ri + rw < n ? tl.ri + rw : n - 1, br = tl.rk + rw < n ? tl.rk + rw : n - 1;
-            ra[it] = *(const f64x2_g*)(a.A + ar * lda + j0 + col);
-            rb[it] = *(const f64x2_g*)(a.A + br * lda + j0 + col);
+            // (write-through-coherent loads, no acquire: an agent-scope acquire per update step and workgroup -- buffer_inv sc1
+            // -- empties the XCD's L2 for everybody some thirty times per row step; with it and plain loads: 0.692 / 0.917 /
+            // 1.18 ms at n = 2048 / 2560 / 3072 instead of 0.670 / 0.874 / 1.13)
+            ra[it] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_Au, (unsigned)((ar * lda + j0 + col) * 8), 0, 16));
+            rb[it] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_Au, (unsigned)((br * lda + j0 + col) * 8), 0, 16));
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -887,7 +892,7 @@ __device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds
             for (int rr = 0; rr < 4; ++rr) {
                 const long long gr = tl.ri + wr + 16 * i + apgp_mma16_row(lane);
                 const long long gc = tl.rk + wc + apgp_mma16_col(lane, rr);
-                cin[i][rr] = a.A[(gr < n ? gr : n - 1) * lda + (gc < n ? gc : n - 1)];
+                cin[i][rr] = pp_ld_f64(a.A + (gr < n ? gr : n - 1) * lda + (gc < n ? gc : n - 1));
             }
     };
     auto stage = [&](double* buf, const PpTile& tl) {
@@ -916,7 +921,7 @@ __device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds
             }
             PP_USTAMP(s, 0);
             if (lane == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // ONE acquire per update step: then plain, L2-served loads
+                // (no acquire: the operands are read with write-through-coherent loads -- see request)
                 ints[s & 1] = ok;
             }
         }
