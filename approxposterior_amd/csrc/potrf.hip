@@ -954,12 +954,15 @@ static int potrf_device_cus(int dev) {
 // How an n x n factorisation (n > 64) is run: -1 = a launch per 64-column step; 0 = ONE persistent launch;
 // s0 > 0 = hybrid: the first s0 block columns a launch per step, the trailing (nb - s0) x (nb - s0) blocks as one
 // persistent launch.
-// (measured, apgp_nll_eval: 0.169 vs 0.208 ms at n = 512, 0.371 vs 0.466 at 1152, 0.717 vs 0.881 at 2048, 1.18 vs 1.38 at 3072, 1.68 vs 1.73 at
-// 3712, but 1.84 vs 1.80 at 3840 and 2.08 vs 1.99 at 4096: while the trailing matrix is large a step is bound by the update's
-// memory traffic (45 us at 4096 against 23.5 once it is small), and there the multi-launch path has all 256 CUs on it -- so
-// above PP_AUTO_NB block columns the first steps are its launches and the persistent launch takes over for the last
-// PP_HYBRID_NB block columns, where a step is a latency chain)
-#define PP_HYBRID_NB 48
+// (measured, apgp_nll_eval, persistent vs launch per step: 0.165 vs 0.208 ms at n = 512, 0.357 vs 0.464 at 1152, 0.670 vs 0.859 at 2048,
+// 1.13 vs 1.34 at 3072, 1.63 vs 1.71 at 3712, but 2.03 vs 1.96 at 4096: while the trailing matrix is large a step is bound by the
+// update (45 us at 4096 against 23.5 once it is small), and there the launch-per-step path has all 256 CUs on it -- so above
+// PP_AUTO_NB block columns the first steps are its launches and the persistent launch takes over for the last PP_HYBRID_NB
+// block columns, where a step is a latency chain.  Thresholds measured: (50, 44) against (58, 48): 1.28 vs 1.31 ms at n = 3328,
+// 1.53 vs 1.63 at 3712, 1.79 vs 1.80 at 4096, 2.59 vs 2.62 at 5000)
+#ifndef PP_HYBRID_NB
+#define PP_HYBRID_NB 44
+#endif
 static long long potrf_plan(int64_t n, int64_t lda, hipStream_t s) {
     const int mode = g_potrf_mode.load();
     if (mode == 1) return -1;

@@ -50,7 +50,10 @@ typedef unsigned long long pp_u64;
 typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
 
 #define PP_MAX_NB 64
-#define PP_AUTO_NB 58                                // block columns up to which the persistent launch is the default
+#ifndef PP_AUTO_NB
+#define PP_AUTO_NB 50
+#endif
+//                              // block columns up to which the persistent launch is the default
 #define PP_THREADS 512
 #define PP_CHUNK (64 * 18)                        // a 16-column chunk of a 64-row tile, rows padded to 18 (apgp_gemm64_tile's)
 // LDS map of a row workgroup (doubles)

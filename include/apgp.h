@@ -164,9 +164,9 @@ int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/
                   void* stream);
 
 /* Test / profiling switch for the Cholesky inside apgp_nll_eval (not read from the
- * environment): 0 = default: ONE persistent launch for 64 < n <= 3712, above that a hybrid
+ * environment): 0 = default: ONE persistent launch for 64 < n <= 3200, above that a hybrid
  * (a launch per 64-column step for the first block columns, one persistent launch for the
- * trailing 48 x 48 blocks); 1 = a launch per step only; 2 = persistent launch that gives up
+ * trailing 44 x 44 blocks); 1 = a launch per step only; 2 = persistent launch that gives up
  * at once (exercises the fallback); 3 = persistent launch wherever it can run (64 < n <= 4096).
  * + 16: the launch-per-step path without its paired trailing updates (two block columns per
  * pass over a tile while the trailing matrix is large) -- all variants return the same bits.

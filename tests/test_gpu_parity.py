@@ -1056,10 +1056,10 @@ def test_persistent_cholesky_repeated_calls_leave_no_state(lib_loaded):
     assert lib.apgp_potrf_fallbacks() == fb
 
 
-@pytest.mark.parametrize("n,D,dup", [(3800, 8, None), (4096, 8, None), (5000, 5, None), (4096, 3, 3000)])
+@pytest.mark.parametrize("n,D,dup", [(3264, 8, None), (3800, 8, None), (4096, 8, None), (5000, 5, None), (4096, 3, 3000)])
 def test_hybrid_cholesky_bit_identical_to_multi_launch(n, D, dup, lib_loaded):
-    """Above 58 block columns the default is the hybrid (round 4): the first block columns a launch per 64-column step --
-    while the trailing update's memory traffic bounds a step -- and the last 48 as ONE persistent launch on the trailing
+    """Above 50 block columns the default is the hybrid (round 4): the first block columns a launch per 64-column step --
+    while the trailing update bounds a step -- and the last 44 as ONE persistent launch on the trailing
     matrix (shifted base pointers, pivot numbering of the full matrix, the running right-hand side handed over in
     place).  Same bits as the launch-per-step path all the way: factor, z, record, LAPACK info (also on a matrix that
     is not positive definite inside the persistent part's range)."""

@@ -107,7 +107,7 @@ for n, dup_at in ((200, 70), (700, 650), (1152, 64), (1152, 1100)):
 # hybrid (default mode above PP_AUTO_NB = 58 block columns): the first block columns a launch per step, the last 48 as one
 # persistent launch on the trailing matrix -- against the launch-per-step path
 if not quick:
-    for n, D, dup in ((3800, 8, None), (4095, 5, None), (4096, 8, None), (5000, 8, None), (4096, 3, 3000), (4096, 3, 500)):
+    for n, D, dup in ((3300, 8, None), (3800, 8, None), (4095, 5, None), (4096, 8, None), (5000, 8, None), (4096, 3, 3000), (4096, 3, 500)):
         rs = np.random.RandomState(n + D)
         X = rs.uniform(-5, 5, size=(n, D))
         if dup is not None:
