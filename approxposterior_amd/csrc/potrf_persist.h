@@ -920,6 +920,7 @@ __device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds
             for (;;) {
                 const bool have = i >= nb || pp_ld(q.ctl + PP_CTL_ROWDONE + i) >= (base | (pp_u64)(s + 1));
                 if (__all(have)) break;
+                __builtin_amdgcn_s_sleep(16);       // (a whole row step of slack: poll gently -- 0.5-1 % for the row workgroups)
                 if (pp_give_up(sp, q.ctl, q.call_id, q.timeout)) { ok = 0; break; }
             }
             PP_USTAMP(s, 0);
