@@ -586,6 +586,9 @@ __global__ __launch_bounds__(256) void trsv_persist_kernel(TrsvPArgs a) {
                 if (want_s) gs = __builtin_amdgcn_raw_buffer_load_b128(rsg, (unsigned)(64 * 16), (unsigned)(k * 65 * 16), 16);
                 const bool ok = g.y == a.tag && g.w == a.tag && gs.y == a.tag && gs.w == a.tag;
                 if (__all(ok)) break;
+                // (only the immediate successor of the awaited block polls flat out: a workgroup d blocks further on has d
+                // block times of slack, and its looks at the same kilobyte compete with the one that matters -- worth 1 %)
+                for (int dd = ord - 1 - p < 8 ? ord - 1 - p : 8; dd > 0; --dd) __builtin_amdgcn_s_sleep(24);
                 if ((++it & 63u) == 0) {
                     const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                     if (t0 == 0) t0 = now;

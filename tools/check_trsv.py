@@ -6,6 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from approxposterior_amd import _lib
+if "--lib" in sys.argv:          # an experimental build: python tools/check_trsv.py --lib path/to/libapgp.so
+    i = sys.argv.index("--lib")
+    _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 lib = _lib.load()
 dev = torch.device("cuda:0")
 bad = 0
