@@ -1,0 +1,34 @@
+"""Where the wall time of BASELINE configuration C5 exactly as written goes (ApproxPosterior.run at D = 8, m0 = 512, m = 64,
+nmax = 10, 1e6 candidates, 64 walkers x 2e4 on-device MCMC): cProfile of the whole run, cumulative times of the top callers.
+Round 4: 251 s under the profiler, of which optGP 208 s = 659,604 gpUtils._nll evaluations (0.28 ms each on average, N growing
+512 -> 1152), candidate sampling + sweeps 28 s, MCMC 12 s.   Usage (GPU box): python tools/c5_profile.py"""
+import cProfile, pstats, io, sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from scipy.optimize import rosen
+from approxposterior_amd import approx, gpUtils, utility as ut
+D, m0, m, nmax = 8, 512, 64, 10
+lo, hi = -5.0, 5.0
+bounds = [(lo, hi)] * D
+def lnprior(t):
+    t = np.asarray(t)
+    return 0.0 if np.all((t >= lo) & (t <= hi)) else -np.inf
+def sample(n=1):
+    return np.random.uniform(lo, hi, size=(n, D))
+lnlike = lambda t, *a, **k: -rosen(np.asarray(t).ravel()) / 100.0
+np.random.seed(11)
+theta = sample(m0)
+y = np.array([lnlike(t) + lnprior(t) for t in theta])
+gp = gpUtils.defaultGP(theta, y)
+ap = approx.ApproxPosterior(theta=theta, y=y, gp=gp, lnprior=lnprior, lnlike=lnlike, priorSample=sample, bounds=bounds, algorithm="agp")
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+with np.errstate(all="ignore"):
+    ap.run(m=m, nmax=nmax, nCandidates=1_000_000, nGPRestarts=1, cache=False, verbose=False, onDevice=True, estBurnin=True, thinChains=True,
+           mcmcKwargs={"iterations": 20000}, samplerKwargs={"nwalkers": 64})
+pr.disable()
+print("run: %.1f s" % (time.perf_counter() - t0))
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
+print(s.getvalue()[:6000])
