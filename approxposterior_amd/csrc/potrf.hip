@@ -144,7 +144,11 @@ extern "C" int apgp_debug_read_fstamps(unsigned long long* out) {
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 // every LDS spin between wavefronts is bounded (2^18 polls, tens of ms): a role that never publishes makes the result wrong,
 // never the GPU hang
+#ifdef PP_EXP_FASTPOLL   // (timing experiment: LDS spins without the sleep)
+#define PANEL_SPIN_WHILE(cond) do { unsigned guard_ = 0; while (cond) { if (++guard_ > (1u << 20)) break; } } while (0)
+#else
 #define PANEL_SPIN_WHILE(cond) do { unsigned guard_ = 0; while (cond) { __builtin_amdgcn_s_sleep(1); if (++guard_ > (1u << 18)) break; } } while (0)
+#endif
 // (a C++ volatile store through a generic pointer becomes a FLAT system-scope store plus
 // s_waitcnt vmcnt(0) -- hundreds of cycles per pivot on the critical path; this is the LDS store)
 __device__ __forceinline__ void lds_store_volatile(int* p, int v) {

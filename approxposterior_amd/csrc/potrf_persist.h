@@ -156,6 +156,8 @@ __device__ __forceinline__ bool pp_give_up(PpSpin& sp, pp_u64* ctl, const pp_u64
 __device__ __forceinline__ void pp_lds_wait_ge(const int* p, int need) {
 #ifdef PP_EXP_SLOWPOLL   // (timing experiment: the matrix wavefronts poll eight times less often)
     { unsigned guard_ = 0; while (lds_load_volatile(p) < need) { __builtin_amdgcn_s_sleep(8); if (++guard_ > (1u << 18)) break; } }
+#elif defined(PP_EXP_FASTWAIT)   // (timing experiment: no sleep between the looks of the persistent kernel's own LDS waits)
+    { unsigned guard_ = 0; while (lds_load_volatile(p) < need) { if (++guard_ > (1u << 20)) break; } }
 #else
     PANEL_SPIN_WHILE(lds_load_volatile(p) < need);
 #endif
