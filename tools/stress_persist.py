@@ -1,7 +1,9 @@
 """Randomised stress of the default Cholesky path (persistent / hybrid / paired) against the launch-per-step path without
 pairing: random training-set sizes, dimensions, hyper-parameters and right-hand sides, every factor, z and record compared bit
 for bit, twice per case (call-unique tags: nothing may leak from one call into the next).
-Usage (GPU box): python tools/stress_persist.py [cases] [max_n]"""
+With --noise a second stream runs fp64 matrix products all the while (foreign kernels hold CUs, shift every timing and make
+some persistent launches give up: those evaluations are redone on the launch-per-step path -- results must not change).
+Usage (GPU box): python tools/stress_persist.py [--noise] [cases] [max_n]"""
 import ctypes, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +11,11 @@ sys.path.insert(0, ROOT)
 import torch
 from approxposterior_amd import _lib, gp as agp
 lib = _lib.load(); dev = torch.device("cuda:0")
+noise = "--noise" in sys.argv
+if noise:
+    sys.argv.remove("--noise")
+    side = torch.cuda.Stream()
+    NA = torch.randn((3072, 3072), dtype=torch.float64, device=dev)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 max_n = int(sys.argv[2]) if len(sys.argv) > 2 else 3600
 rs = np.random.RandomState(20261003)
@@ -26,6 +33,10 @@ for c in range(cases):
     X_d = torch.from_numpy(X).to(dev); y_d = torch.from_numpy(y).to(dev)
     res = []
     for mode in (17, 0, 0):
+        if noise:
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    NB = NA @ NA
         lib.apgp_potrf_mode(mode)
         K = torch.zeros((n, n), dtype=torch.float64, device=dev); z = torch.empty(n, dtype=torch.float64, device=dev)
         info = torch.empty(1, dtype=torch.int32, device=dev); o5 = torch.empty(5, dtype=torch.float64, device=dev); o = np.empty(5)
