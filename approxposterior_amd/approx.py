@@ -33,7 +33,14 @@ Additions the reference does not have (all off by default):
 * ``_gpllBatch``: the surrogate log-probability of a whole walker ensemble in one
   launch (what the ensemble sampler calls with ``vectorize=True``);
 * ``runMCMC(onDevice=True)`` / ``run(onDevice=True)``: the whole chain as one
-  persistent kernel (box prior only).
+  persistent kernel (box prior only);
+* several GPUs: launched as ``python -m torch.distributed.run --nproc-per-node N script.py`` with a
+  process group initialised before the object is used (``tools/run_c5_dist.py``), every rank runs the
+  same outer loop on an identical training set -- the ``nCandidates`` sweep is sharded by rank with one
+  16-byte-per-rank all-gather (:func:`dist.sharded_acquire`), each rank samples its own replica
+  ensemble and the chains are gathered once (:func:`dist.replicated_ensembles`), optimiser restarts are
+  spread over the ranks (:func:`dist.spread_restarts`), the forward model runs on rank 0 only and its
+  value is broadcast, and only rank 0 prints and writes the caches (BASELINE config 5 "on 8 GPUs").
 
 The emcee HDF5 backend is replaced by a ``<runName>.npz`` chain dump (h5py and emcee
 are not installable here; :py:mod:`approxposterior_amd.mcmc` restates the sampler).
@@ -43,6 +50,7 @@ import time
 
 import numpy as np
 
+from . import dist as apdist
 from . import gp as george
 from . import gpUtils
 from . import mcmc as emcee   # drop-in for the ``emcee`` names used below
@@ -106,11 +114,14 @@ class ApproxPosterior(object):
     ``theta`` (N, D) / ``y`` (N,) is the initial training set, ``lnprior``,
     ``lnlike`` and ``priorSample`` the user's callables, ``bounds`` one (lo, hi)
     pair per dimension, ``gp`` an optional pre-built GP and ``algorithm`` one of
-    "bape", "agp", "alternate", "jones".
+    "bape", "agp", "alternate", "jones".  ``distributed`` (None: whenever a
+    ``torch.distributed`` process group is initialised; False: never) and ``group``
+    select the multi-GPU paths; the training set handed to every rank must be the same.
     """
 
     def __init__(self, theta, y, lnprior, lnlike, priorSample, bounds, gp=None,
-                 algorithm="bape"):
+                 algorithm="bape", distributed=None, group=None):
+        self.distributed, self.group = distributed, group
         if theta is None or y is None:
             raise ValueError("Must supply both theta and y for initial GP training set.")
         self.theta = np.array(theta).squeeze()
@@ -133,6 +144,23 @@ class ApproxPosterior(object):
             print("INFO: No GP specified. Initializing GP using ExpSquaredKernel.")
             gp = gpUtils.defaultGP(self.theta, self.y)
         self.gp = gp
+
+    # ---------------------------------------------------------------- several GPUs
+    def _ranks(self):
+        """``(rank, world)`` under an initialised process group (unless ``distributed=False``), else None."""
+        return apdist.context(self.group, self.distributed)
+
+    def _chief(self):
+        """True on the rank that prints, writes caches and calls the forward model."""
+        ranks = self._ranks()
+        return ranks is None or ranks[0] == 0
+
+    def _agree(self, *values):
+        """Rank 0's float64 arrays on every rank (a no-op without a process group)."""
+        if self._ranks() is None:
+            return values if len(values) > 1 else values[0]
+        out = tuple(apdist.broadcast_bytes(np.asarray(v, dtype=np.float64), 0, self.group) for v in values)
+        return out if len(out) > 1 else out[0]
 
     # ------------------------------------------------------- surrogate log-probability
     def _gpll(self, theta, *args, **kwargs):
@@ -175,28 +203,49 @@ class ApproxPosterior(object):
     # ------------------------------------------------------------------ GP re-fit
     def optGP(self, seed=None, method="powell", options=None, p0=None,
               nGPRestarts=1, gpHyperPrior=gpUtils.defaultHyperPrior):
-        """Re-fit the GP hyper-parameters in place (approx.py:192-226)."""
+        """Re-fit the GP hyper-parameters in place (approx.py:192-226).  Under a process group the
+        restarts are spread over the ranks and every rank ends with the same optimum."""
+        if self._ranks() is not None:
+            apdist.sync_random_state(0, self.group)      # the restart start points are one global draw
         self.gp = gpUtils.optimizeGP(self.gp, self.theta, self.y, seed=seed,
                                      method=method, options=options, p0=p0,
-                                     nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior)
+                                     nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior,
+                                     distributed=self.distributed, group=self.group)
 
     # ------------------------------------------------------- design-point selection
     def _selectPoint(self, utility, theta0, nRestarts, method, options, nCandidates, polish):
-        """One design point: the minimiser of ``utility`` over the prior."""
+        """One design point: the minimiser of ``utility`` over the prior.  Under a process group the
+        ``nCandidates`` draw is ONE global matrix (same random state on every rank), each rank sweeps its
+        contiguous rows and the winners meet in a 16-byte-per-rank all-gather; the Nelder-Mead search is
+        replicated and rank 0's answer kept."""
         scalarArgs = (self.y, self.gp, self._lnprior)
+        ranks = self._ranks()
         if nCandidates is None:
-            return ut.minimizeObjective(utility, self.y, self.gp, sampleFn=self.priorSample,
-                                        priorFn=self._lnprior, nRestarts=nRestarts, method=method,
-                                        options=options, bounds=self.bounds, theta0=theta0,
-                                        args=scalarArgs)
-        draws = np.asarray(self.priorSample(int(nCandidates)), dtype=float)
-        point, value = ut.sweepObjective(utility, self.y, self.gp,
-                                         draws.reshape(int(nCandidates), -1), bounds=self.bounds)
+            point, value = ut.minimizeObjective(utility, self.y, self.gp, sampleFn=self.priorSample,
+                                                priorFn=self._lnprior, nRestarts=nRestarts, method=method,
+                                                options=options, bounds=self.bounds, theta0=theta0,
+                                                args=scalarArgs)
+            return self._agree(point, value) if ranks is not None else (point, value)
+        draws = np.asarray(self.priorSample(int(nCandidates)), dtype=float).reshape(int(nCandidates), -1)
+        if ranks is None:
+            point, value = ut.sweepObjective(utility, self.y, self.gp, draws, bounds=self.bounds)
+        else:
+            lo, hi = apdist.shard_bounds(len(draws), ranks[1], ranks[0])
+            kind = ut.utilityKind(utility)
+            best, value = apdist.sharded_acquire(
+                lambda offset: self.gp.acquire(self.y, np.ascontiguousarray(draws[lo:hi]), kind,
+                                               bounds=self.bounds, idx_offset=offset, device_record=True),
+                lo, group=self.group)
+            if best < 0:
+                raise RuntimeError("ERROR: Cannot find a valid solution: no candidate is allowed by the prior")
+            point = np.array(draws[best])
         if polish:
             point, value = ut.minimizeObjective(utility, self.y, self.gp,
                                                 sampleFn=self.priorSample, priorFn=self._lnprior,
                                                 nRestarts=1, method=method, options=options,
                                                 bounds=self.bounds, theta0=point, args=scalarArgs)
+            if ranks is not None:
+                point, value = self._agree(point, value)
         return point, value
 
     def _absorbPoint(self, point, value):
@@ -241,7 +290,14 @@ class ApproxPosterior(object):
                   "re-optimized during this call.")
         fwdArgs = () if args is None else args
         points, values = [], []
+        ranks = self._ranks()
+        chief = self._chief()
+        verbose, cache = verbose and chief, cache and chief      # one rank talks and writes
         for count in range(numNewPoints):
+            if ranks is not None:
+                # one global random stream: the candidate matrix / restart draws below are the same on
+                # every rank whatever the forward model (rank 0 only) did to rank 0's stream
+                apdist.sync_random_state(0, self.group)
             if self.algorithm == "alternate":      # AGP, BAPE, AGP, ... (approx.py:656-661)
                 self.utility = (ut.AGPUtility, ut.BAPEUtility)[count % 2]
             point, _ = self._selectPoint(self.utility, theta0, nMinObjRestarts, minObjMethod,
@@ -249,9 +305,13 @@ class ApproxPosterior(object):
             points.append(point)
             if not computeLnLike:
                 continue
-            like = self._lnlike(point, *fwdArgs, **kwargs)
-            like = like[0] if hasattr(like, "__iter__") else like      # (lnlike, blobs...) allowed
-            value = np.array([like + self._lnprior(point)])
+            if chief:
+                like = self._lnlike(point, *fwdArgs, **kwargs)
+                like = like[0] if hasattr(like, "__iter__") else like      # (lnlike, blobs...) allowed
+                value = np.array([like + self._lnprior(point)], dtype=np.float64).reshape(1)
+            else:
+                value = np.zeros(1)
+            value = self._agree(value)             # the forward model ran once, on rank 0
             values.append(value)
             try:
                 hyper = self._absorbPoint(point, value)
@@ -329,21 +389,28 @@ class ApproxPosterior(object):
         With ``cache`` the chain goes to ``<runName>.npz`` (keys chain, log_prob, blobs)
         where the reference writes ``<runName>.h5``.
         """
+        ranks = self._ranks()
+        if ranks is not None:
+            apdist.sync_random_state(0, self.group)
+            verbose, cache = verbose and ranks[0] == 0, cache and ranks[0] == 0
         samplerKwargs, mcmcKwargs = mcmcUtils.validateMCMCKwargs(self, samplerKwargs,
                                                                  mcmcKwargs, verbose)
         if onDevice:
             self._requireBoxPrior()
-            result = self.gp.sample_ensemble(self.y, mcmcKwargs["initial_state"],
-                                             mcmcKwargs["iterations"], self.bounds,
-                                             seed=np.random.randint(0, 2 ** 31 - 1))
-            self.sampler = emcee.DeviceChain(result)
+        if onDevice or ranks is not None:
+            # one ensemble per rank, seeded base + rank, gathered once along the walker axis
+            # (a single rank without a process group: the local chain, unchanged)
+            base = np.random.randint(0, 2 ** 31 - 1)
+            merged = apdist.replicated_ensembles(
+                lambda seed: self._sampleReplica(seed, samplerKwargs, mcmcKwargs, args, kwargs,
+                                                 batched, onDevice),
+                seed=base, group=self.group if ranks is not None else None)
+            chain, logp, naccept = merged[0], merged[1], merged[2]
+            self.sampler = emcee.DeviceChain({"chain": chain, "log_prob": logp, "naccept": naccept,
+                                              "coords": chain[-1], "final_log_prob": logp[-1],
+                                              "blobs": merged[3] if len(merged) > 3 else None})
         else:
-            setup = dict(samplerKwargs)
-            if batched:
-                setup["log_prob_fn"] = lambda pts, *a, **k: self._gpllBatch(pts)
-                setup["vectorize"] = True
-            self.sampler = emcee.EnsembleSampler(**setup, backend=None, args=args, kwargs=kwargs,
-                                                 blobs_dtype=[("lnprior", float)])
+            self.sampler = self._hostSampler(samplerKwargs, args, kwargs, batched)
             for _ in self.sampler.sample(**mcmcKwargs):
                 pass
         if verbose:
@@ -353,6 +420,29 @@ class ApproxPosterior(object):
         iburn, ithin = mcmcUtils.estimateBurnin(self.sampler, estBurnin=estBurnin,
                                                 thinChains=thinChains, verbose=verbose)
         return self.sampler, iburn, ithin
+
+    def _hostSampler(self, samplerKwargs, args, kwargs, batched, seed=None):
+        setup = dict(samplerKwargs)
+        if batched:
+            setup["log_prob_fn"] = lambda pts, *a, **k: self._gpllBatch(pts)
+            setup["vectorize"] = True
+        if seed is not None:
+            setup["seed"] = seed
+        return emcee.EnsembleSampler(**setup, backend=None, args=args, kwargs=kwargs,
+                                     blobs_dtype=[("lnprior", float)])
+
+    def _sampleReplica(self, seed, samplerKwargs, mcmcKwargs, args, kwargs, batched, onDevice):
+        """This rank's ensemble: ``(chain, log_prob, naccept[, blobs])`` for :func:`dist.replicated_ensembles`."""
+        if onDevice:
+            res = self.gp.sample_ensemble(self.y, mcmcKwargs["initial_state"], mcmcKwargs["iterations"],
+                                          self.bounds, seed=seed)
+            return res["chain"], res["log_prob"], res["naccept"]
+        sampler = self._hostSampler(samplerKwargs, args, kwargs, batched, seed=seed)
+        for _ in sampler.sample(**mcmcKwargs):
+            pass
+        blobs = sampler.get_blobs()
+        out = (sampler.get_chain(), sampler.get_log_prob(), sampler._naccepted)
+        return out if blobs is None else out + (blobs,)
 
     # ---------------------------------------------------------------------- outer loop
     def run(self, m=10, nmax=2, seed=None, timing=False, verbose=True,
@@ -374,6 +464,7 @@ class ApproxPosterior(object):
         if convergenceCheck and onlyLastMCMC:
             raise RuntimeError("If convergenceCheck is True, must run an MCMC each iteration.\n"
                                "convergenceCheck = %d onlyLastMCMC = %d" % (convergenceCheck, onlyLastMCMC))
+        verbose, cache = verbose and self._chief(), cache and self._chief()
         if cache:
             np.savez(_cacheName(runName, "APFModelCache"), theta=self.theta, y=self.y)
             self.gpPar = []
@@ -445,10 +536,14 @@ class ApproxPosterior(object):
         def minusMean(x):
             return -(self._gpll(x)[0]) if np.isfinite(self._lnprior(x)) else np.inf
 
+        if self._ranks() is not None:
+            apdist.sync_random_state(0, self.group)
         best, value = ut.minimizeObjective(minusMean, self.y, self.gp, self.priorSample,
                                            self._lnprior, nRestarts=nRestarts, args=None,
                                            method=method, options=options, bounds=self.bounds,
                                            theta0=start)
+        if self._ranks() is not None:
+            best, value = self._agree(best, value)
         return best, -value
 
     # ---------------------------------------------------------- Bayesian optimisation
@@ -463,6 +558,7 @@ class ApproxPosterior(object):
         after each, stop after ``kmax`` consecutive iterations whose best value changed
         by less than ``tol``.  Returns the reference's solution dictionary (thetaBest,
         valBest, thetas, vals, nev [, thetasMAP, valsMAP, thetaMAPBest, valMAPBest])."""
+        verbose, cache = verbose and self._chief(), cache and self._chief()
         if cache:
             np.savez(_cacheName(runName, "APFModelCache"), theta=self.theta, y=self.y)
         if seed is not None:

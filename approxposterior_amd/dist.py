@@ -19,7 +19,8 @@ Nelder-Mead, utility.py:253-372); this is the multi-GPU form of
 
 import numpy as np
 
-__all__ = ["shard_bounds", "combine_best", "sharded_acquire", "replicated_ensembles"]
+__all__ = ["shard_bounds", "combine_best", "sharded_acquire", "replicated_ensembles", "context",
+           "broadcast_bytes", "sync_random_state", "all_gather_arrays", "spread_restarts"]
 
 
 def shard_bounds(m, world_size, rank):
@@ -105,30 +106,149 @@ def replicated_ensembles(local_sample, seed=0, group=None, device=None):
     bounds, seed=s))`` -- and the chains are concatenated along the walker axis with
     ONE all-gather at the end (no collective inside the sampling loop).
     Returns (chain (iterations, world*W, D), log_prob (iterations, world*W)) on every rank.
+    ``local_sample`` may return further arrays: (iterations, W) per-step values (e.g. the lnprior blobs)
+    or (W,) per-walker values (e.g. the accepted-move counts); each is concatenated along its walker
+    axis and returned after the first two.
     """
-    import torch
-    import torch.distributed as dist
-
-    distributed = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if distributed else 0
-    chain, logp = local_sample(int(seed) + rank)
-    chain = np.ascontiguousarray(chain, dtype=np.float64)
-    logp = np.ascontiguousarray(logp, dtype=np.float64)
+    ctx = context(group)
+    rank = ctx[0] if ctx is not None else 0
+    res = local_sample(int(seed) + rank)
+    chain = np.ascontiguousarray(res[0], dtype=np.float64)
+    logp = np.ascontiguousarray(res[1], dtype=np.float64)
     if chain.ndim != 3 or logp.shape != chain.shape[:2]:
         raise ValueError("local_sample must return chain (iterations, W, D) and log_prob (iterations, W)")
-    if not distributed:
-        return chain, logp
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) \
-            if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    extras = [np.ascontiguousarray(e, dtype=np.float64) for e in res[2:]]
+    for e in extras:
+        if e.shape != logp.shape and e.shape != logp.shape[1:]:
+            raise ValueError("extra arrays must be (iterations, W) or (W,)")
+    if ctx is None:
+        return (chain, logp) + tuple(extras)
+    per_rank = all_gather_arrays([chain, logp] + extras, group, device)
+    out = []
+    for k in range(2 + len(extras)):
+        axis = 0 if per_rank[0][k].ndim == 1 else 1
+        out.append(np.concatenate([r[k] for r in per_rank], axis=axis))
+    return tuple(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# The pieces ApproxPosterior / gpUtils.optimizeGP use when they run under torch.distributed.run
+# (one process per GPU): every rank executes the SAME outer loop on an identical training set; the
+# candidate sweep is sharded (above), MCMC ensembles and optimiser restarts are spread over the ranks,
+# and the few host values that must agree everywhere (NumPy's global random state, a selected point,
+# the forward-model value rank 0 computed) travel by broadcast.
+# ------------------------------------------------------------------------------------------------
+
+def context(group=None, enabled=None):
+    """``(rank, world)`` when the multi-GPU paths apply, else ``None``.
+
+    ``enabled`` None: whenever a torch.distributed process group is initialised (world size 1 included:
+    the collectives then run on a single rank); False: never; True: required (``RuntimeError`` without a
+    group)."""
+    if enabled is False:
+        return None
+    try:
+        import torch.distributed as dist
+    except ImportError:      # pragma: no cover
+        dist = None
+    if dist is None or not (dist.is_available() and dist.is_initialized()):
+        if enabled:
+            raise RuntimeError("distributed=True needs an initialised torch.distributed process group")
+        return None
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _carrier(group, device):
+    """Device the collectives' tensors live on: the current GPU for RCCL (``nccl``), the host for gloo."""
+    import torch
+    import torch.distributed as dist
+    if device is not None:
+        return device
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _global_rank(group, group_rank):
+    import torch.distributed as dist
+    if group is None:
+        return group_rank
+    return dist.get_global_rank(group, group_rank)
+
+
+def broadcast_bytes(buf, src=0, group=None, device=None):
+    """Every rank returns rank ``src``'s ``buf`` (a C-contiguous NumPy array; same shape and dtype
+    everywhere -- only the bytes travel)."""
+    import torch
+    import torch.distributed as dist
+    arr = np.ascontiguousarray(buf)
+    if context(group) is None:
+        return arr
+    raw = np.frombuffer(arr.tobytes(), dtype=np.uint8).copy()
+    t = torch.from_numpy(raw).to(_carrier(group, device))
+    dist.broadcast(t, src=_global_rank(group, src), group=group)
+    return np.frombuffer(t.cpu().numpy().tobytes(), dtype=arr.dtype).reshape(arr.shape).copy()
+
+
+def sync_random_state(src=0, group=None, device=None):
+    """Give every rank rank ``src``'s global NumPy random state (MT19937 key, position, cached Gaussian):
+    afterwards identical calls draw identical numbers on all ranks -- the candidate matrix, restart start
+    points and walker initial states are then ONE global draw, not one per rank."""
+    if context(group) is None:
+        return
+    name, key, pos, has_gauss, gauss = np.random.get_state()
+    if name != "MT19937":      # pragma: no cover
+        raise RuntimeError("unexpected NumPy bit generator %r" % name)
+    head = broadcast_bytes(np.array([pos, has_gauss], dtype=np.int64), src, group, device)
+    key = broadcast_bytes(np.asarray(key, dtype=np.uint32), src, group, device)
+    gauss = broadcast_bytes(np.array([gauss], dtype=np.float64), src, group, device)
+    np.random.set_state((name, key, int(head[0]), int(head[1]), float(gauss[0])))
+
+
+def all_gather_arrays(arrays, group=None, device=None):
+    """ONE all-gather of a list of equally-shaped (across ranks) float64 arrays: returns
+    ``per_rank[r][k]`` = rank r's k-th array.  Without a process group: ``[arrays]``."""
+    import torch
+    import torch.distributed as dist
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays]
+    if context(group) is None:
+        return [arrs]
+    flat = np.concatenate([a.ravel() for a in arrs]) if arrs else np.empty(0)
+    mine = torch.from_numpy(flat).to(_carrier(group, device))
     world = dist.get_world_size(group)
-    # one record per rank: [chain | log_prob] flattened (same shape on every rank)
-    mine = torch.from_numpy(np.concatenate([chain.ravel(), logp.ravel()])).to(device)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
-    chains, logps = [], []
+    out = []
     for g in gathered:
         h = g.cpu().numpy()
-        chains.append(h[:chain.size].reshape(chain.shape))
-        logps.append(h[chain.size:].reshape(logp.shape))
-    return np.concatenate(chains, axis=1), np.concatenate(logps, axis=1)
+        parts, at = [], 0
+        for a in arrs:
+            parts.append(h[at:at + a.size].reshape(a.shape).copy())
+            at += a.size
+        out.append(parts)
+    return out
+
+
+def spread_restarts(n_restarts, run_mine, n_params, group=None, device=None):
+    """Optimiser restarts over the ranks (SURVEY.md section 8e, row "GP fit": the fit does not shard,
+    its restarts do): restart r belongs to rank ``r % world``; ``run_mine(indices) -> [(mll, p), ...]``
+    runs this rank's restarts; ONE all-gather of (1 + P) doubles per restart slot returns
+    ``(mll (R,), p (R, P))`` in restart order on every rank."""
+    ctx = context(group)
+    rank, world = ctx if ctx is not None else (0, 1)
+    mine = list(range(rank, int(n_restarts), world))
+    res = run_mine(mine) if mine else []
+    if len(res) != len(mine):
+        raise ValueError("run_mine must return one (mll, p) per restart index")
+    slots = (int(n_restarts) + world - 1) // world
+    rec = np.full((slots, 1 + int(n_params)), np.nan)
+    for s, (mll, p) in enumerate(res):
+        rec[s, 0] = mll
+        rec[s, 1:] = np.asarray(p, dtype=np.float64)
+    per_rank = all_gather_arrays([rec], group, device)
+    mll = np.empty(int(n_restarts))
+    ps = np.empty((int(n_restarts), int(n_params)))
+    for r in range(int(n_restarts)):
+        row = per_rank[r % world][0][r // world]
+        mll[r], ps[r] = row[0], row[1:]
+    return mll, ps

@@ -314,6 +314,7 @@ class GP(object):
         self._computed = False
         self._x = None
         self._yerr2 = 0.0
+        self._nllMemo = None          # gpUtils._nll: values already evaluated on this training set
         self._reset_device_state()
 
     # -- device plumbing -------------------------------------------------------
@@ -449,6 +450,7 @@ class GP(object):
             raise ValueError("at most %d dimensions are supported" % _lib.MAX_DIM)
         same_x = self._x is not None and self._x.shape == x.shape and np.array_equal(self._x, x)
         self._x = x
+        self._nllMemo = None          # gpUtils._nll's table of evaluated points belongs to the old training set
         self._yerr2 = float(yerr) ** 2
         if previous is not None and self._try_extend(previous):
             return

@@ -27,6 +27,29 @@ def defaultHyperPrior(p):
     return 0.0
 
 
+_MEMO_SIZE = 64
+
+
+def _memoTable(gp, y):
+    """The GP's table of already-evaluated ``_nll`` values for THIS training set and y, or None when the
+    object cannot carry one.  SciPy's Powell asks for f at the current point again at the head of every
+    line search (one in ten of all evaluations in BASELINE config 5); an exact repeat -- same bytes of
+    ``p``, same fixed mean / white noise / yerr, same x and y -- is answered from here.  ``GP.compute``
+    drops the table; objects without the ``_nllMemo`` slot (a real ``george.GP``) are never memoised."""
+    if not hasattr(gp, "_nllMemo"):       # only a GP that drops the table in compute() carries one
+        return None
+    memo = gp._nllMemo
+    if memo is None or not np.array_equal(memo["y"], y):
+        from collections import OrderedDict
+        memo = gp._nllMemo = {"y": np.array(y, copy=True), "table": OrderedDict()}
+    return memo["table"]
+
+
+def _memoKey(p, gp):
+    fixed = (float(gp.mean.value), float(gp.white_noise.value), float(gp._yerr2))
+    return np.asarray(p, dtype=np.float64).tobytes(), fixed
+
+
 def _nll(p, gp, y, priorFn=None):
     """Negative marginal log-likelihood at hyper-parameters ``p``; +inf where the
     prior forbids ``p`` or the Gram matrix is not positive definite
@@ -37,8 +60,20 @@ def _nll(p, gp, y, priorFn=None):
         gp.set_parameter_vector(p)
     except np.linalg.LinAlgError:
         return np.inf
+    table = _memoTable(gp, y)
+    if table is not None:
+        key = _memoKey(p, gp)      # (after set_parameter_vector: a fitted mean / white noise is part of p)
+        hit = table.get(key)
+        if hit is not None:
+            table.move_to_end(key)
+            return hit
     ll = gp.log_likelihood(y, quiet=True)
-    return -ll if np.isfinite(ll) else np.inf
+    val = -ll if np.isfinite(ll) else np.inf
+    if table is not None:
+        table[key] = val
+        if len(table) > _MEMO_SIZE:
+            table.popitem(last=False)
+    return val
 
 
 def _grad_nll(p, gp, y, priorFn=None):
@@ -126,15 +161,24 @@ def _minimizeLockStep(gp, y, x0s, method, options, priorFn):
     ``_nll`` evaluations are served in lock-step by ``gp.nll_batch`` -- one batched
     Gram + Cholesky per round instead of one per restart."""
     import threading
+    from collections import OrderedDict
     step = _LockStep(len(x0s), lambda pts: gp.nll_batch(np.array(pts), y))
     sols, errs = [None] * len(x0s), [None] * len(x0s)
 
     def work(k):
+        seen = OrderedDict()      # this restart's exact repeats (Powell's line-search heads), as _nll's table
+
         def fn(p):
             # the prior gate of _nll (gpUtils.py:68-70) needs no device work
             if priorFn is not None and not np.isfinite(priorFn(p)):
                 return np.inf
-            return float(step.evaluate(k, p))
+            key = np.asarray(p, dtype=np.float64).tobytes()
+            val = seen.get(key)
+            if val is None:
+                val = seen[key] = float(step.evaluate(k, p))
+                if len(seen) > _MEMO_SIZE:
+                    seen.popitem(last=False)
+            return val
         try:
             sols[k] = minimize(fn, x0s[k], method=method, jac=None, bounds=None, options=options)["x"]
         except BaseException as err:
@@ -153,8 +197,38 @@ def _minimizeLockStep(gp, y, x0s, method, options, priorFn):
     return sols
 
 
+def _startPoint(gp, y, p0):
+    """Start point of one restart, drawn exactly as the reference does (gpUtils.py:224-230)."""
+    if p0 is None:
+        return [np.median(y)] + [np.random.randn() for _ in range(len(gp.get_parameter_vector()) - 1)]
+    return np.array(p0) + np.min(p0) * 1.0e-3 * np.random.randn(len(p0))
+
+
+def _runRestarts(gp, y, x0s, method, options, gpHyperPrior, batchRestarts):
+    """Minimise ``_nll`` from every start point of ``x0s``: ``(solutions, mll)``.  Derivative-free methods
+    with several starts run concurrently with batched device evaluations; everything else is the
+    reference's sequential loop body (gpUtils.py:232-247)."""
+    derivativeFree = method in ["nelder-mead", "powell", "cg"]
+    if batchRestarts and len(x0s) > 1 and derivativeFree and hasattr(gp, "nll_batch"):
+        res = _minimizeLockStep(gp, y, x0s, method, options, gpHyperPrior)
+        # marginal likelihood at each solution: one more batch (the sequential loop's
+        # set_parameter_vector + recompute + log_likelihood, gpUtils.py:243-247)
+        return res, -gp.nll_batch(np.array(res), y)
+    res, mll = [], []
+    for x0 in x0s:
+        jac = None if derivativeFree else _grad_nll
+        sol = minimize(_nll, x0, args=(gp, y, gpHyperPrior), method=method,
+                       jac=jac, bounds=None, options=options)["x"]
+        res.append(sol)
+        gp.set_parameter_vector(sol)
+        gp.recompute()
+        mll.append(gp.log_likelihood(y, quiet=True))
+    return res, np.array(mll, dtype=np.float64)
+
+
 def optimizeGP(gp, theta, y, seed=None, nGPRestarts=1, method="powell",
-               options=None, p0=None, gpHyperPrior=defaultHyperPrior, batchRestarts=True):
+               options=None, p0=None, gpHyperPrior=defaultHyperPrior, batchRestarts=True,
+               distributed=None, group=None):
     """Maximise the marginal log-likelihood over the GP hyper-parameters with
     ``nGPRestarts`` SciPy runs and keep the best (gpUtils.py:184-257).  ``seed``
     and ``theta`` are accepted and unused, as in the reference (quirk Q6).
@@ -163,36 +237,24 @@ def optimizeGP(gp, theta, y, seed=None, nGPRestarts=1, method="powell",
     concurrently and their ``_nll`` evaluations are batched on the device; start points,
     per-restart trajectories and the selected optimum are those of the sequential loop
     (the optimisers draw no random numbers, and a batched evaluation is bit-identical to a
-    single one).  ``batchRestarts=False`` runs the reference's sequential loop."""
-    derivativeFree = method in ["nelder-mead", "powell", "cg"]
-    if batchRestarts and nGPRestarts > 1 and derivativeFree and hasattr(gp, "nll_batch"):
-        x0s = []
-        for _ in range(nGPRestarts):
-            if p0 is None:
-                x0s.append([np.median(y)] + [np.random.randn() for _ in range(len(gp.get_parameter_vector()) - 1)])
-            else:
-                x0s.append(np.array(p0) + np.min(p0) * 1.0e-3 * np.random.randn(len(p0)))
-        res = _minimizeLockStep(gp, y, x0s, method, options, gpHyperPrior)
-        # marginal likelihood at each solution: one more batch (the sequential loop's
-        # set_parameter_vector + recompute + log_likelihood, gpUtils.py:243-247)
-        mll = -gp.nll_batch(np.array(res), y)
-        best = int(np.argmax(mll))
-        gp.set_parameter_vector(res[best])
-        gp.recompute()
-        return gp
-    res, mll = [], []
-    for _ in range(nGPRestarts):
-        if p0 is None:
-            x0 = [np.median(y)] + [np.random.randn() for _ in range(len(gp.get_parameter_vector()) - 1)]
-        else:
-            x0 = np.array(p0) + np.min(p0) * 1.0e-3 * np.random.randn(len(p0))
-        jac = None if derivativeFree else _grad_nll
-        sol = minimize(_nll, x0, args=(gp, y, gpHyperPrior), method=method,
-                       jac=jac, bounds=None, options=options)["x"]
-        res.append(sol)
-        gp.set_parameter_vector(sol)
-        gp.recompute()
-        mll.append(gp.log_likelihood(y, quiet=True))
+    single one).  ``batchRestarts=False`` runs the reference's sequential loop.
+
+    Under an initialised ``torch.distributed`` group (``distributed`` None / True; one process per
+    GPU, NumPy's global random state identical on every rank -- ``dist.sync_random_state``) every rank
+    draws ALL start points, runs restarts ``rank, rank + world, ...`` on its own GPU, and one all-gather
+    of ``(mll, p)`` per restart gives every rank the same optimum (``dist.spread_restarts``)."""
+    from . import dist as apdist
+    # all start points first, in the reference's draw order: its loop interleaves the draws with the
+    # minimisations, but SciPy's optimisers draw no random numbers
+    x0s = [_startPoint(gp, y, p0) for _ in range(nGPRestarts)]
+    if apdist.context(group, distributed) is None:
+        res, mll = _runRestarts(gp, y, x0s, method, options, gpHyperPrior, batchRestarts)
+    else:
+        def runMine(indices):
+            sols, vals = _runRestarts(gp, y, [x0s[i] for i in indices], method, options,
+                                      gpHyperPrior, batchRestarts)
+            return list(zip(vals, sols))
+        mll, res = apdist.spread_restarts(nGPRestarts, runMine, len(gp.get_parameter_vector()), group)
     best = int(np.argmax(mll))
     gp.set_parameter_vector(res[best])
     gp.recompute()

@@ -266,7 +266,8 @@ class DeviceChain(EnsembleSampler):
         self.iteration = chain.shape[0]
         self._chain = chain
         self._log_prob = result["log_prob"]
-        self._blobs = []
+        blobs = result.get("blobs")
+        self._blobs = [] if blobs is None else blobs      # (iterations, walkers) lnprior values of a gathered host chain
         self._naccepted = np.asarray(result["naccept"], dtype=float)
         self._coords = result["coords"]
         self._lp = result["final_log_prob"]
