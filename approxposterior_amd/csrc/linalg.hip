@@ -684,10 +684,12 @@ extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* 
             *calls = 0; ncall = 1; pa.ticket_base = 0;
         }
         pa.tag = (unsigned)ncall;
-        *calls = (ncall << 40) | ((pa.ticket_base + (unsigned long long)nb) & 0xffffffffffull);
         if (!trans) hipLaunchKernelGGL(trsv_persist_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, pa);
         else hipLaunchKernelGGL(trsv_persist_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, pa);
         APGP_CHECK_LAUNCH();
+        // (only a launch that was accepted draws its tickets on the device: the host-side base moves with it, not before --
+        // a failed launch would otherwise leave every later call on this stream with tickets nobody hands out)
+        *calls = (ncall << 40) | ((pa.ticket_base + (unsigned long long)nb) & 0xffffffffffull);
         return 0;
     }
     if (n >= 256) {

@@ -144,11 +144,14 @@ extern "C" int apgp_debug_read_fstamps(unsigned long long* out) {
 #define PANEL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 // every LDS spin between wavefronts is bounded (2^18 polls, tens of ms): a role that never publishes makes the result wrong,
 // never the GPU hang
+// PANEL_SPIN_WHILE_T: an expired guard also raises the LDS word `trip_` (if any): the persistent kernel turns that into its
+// global abort word, so that the host re-runs the evaluation instead of trusting values computed from stale operands
 #ifdef PP_EXP_FASTPOLL   // (timing experiment: LDS spins without the sleep)
-#define PANEL_SPIN_WHILE(cond) do { unsigned guard_ = 0; while (cond) { if (++guard_ > (1u << 20)) break; } } while (0)
+#define PANEL_SPIN_WHILE_T(cond, trip_) do { unsigned guard_ = 0; while (cond) { if (++guard_ > (1u << 20)) { if (trip_) lds_store_volatile((trip_), 1); break; } } } while (0)
 #else
-#define PANEL_SPIN_WHILE(cond) do { unsigned guard_ = 0; while (cond) { __builtin_amdgcn_s_sleep(1); if (++guard_ > (1u << 18)) break; } } while (0)
+#define PANEL_SPIN_WHILE_T(cond, trip_) do { unsigned guard_ = 0; while (cond) { __builtin_amdgcn_s_sleep(1); if (++guard_ > (1u << 18)) { if (trip_) lds_store_volatile((trip_), 1); break; } } } while (0)
 #endif
+#define PANEL_SPIN_WHILE(cond) PANEL_SPIN_WHILE_T(cond, (int*)nullptr)
 // (a C++ volatile store through a generic pointer becomes a FLAT system-scope store plus
 // s_waitcnt vmcnt(0) -- hundreds of cycles per pivot on the critical path; this is the LDS store)
 __device__ __forceinline__ void lds_store_volatile(int* p, int v) {
@@ -199,7 +202,8 @@ __device__ __forceinline__ void panel_trailing(double (&row)[LEN], const double 
 // (~20 cycles per ds_read_b128), and a second wavefront has its own.  The updated columns go back
 // through the staging positions Ls[lane][HELPER_COL0 ..] (not yet published at that point).
 #define HELPER_COL0 32
-__device__ __forceinline__ void panel_helper_wave(const int bs, const int lane, double (*Ls)[PB + 2], int* prog_p, int* hflag_p) {
+__device__ __forceinline__ void panel_helper_wave(const int bs, const int lane, double (*Ls)[PB + 2], int* prog_p, int* hflag_p,
+                                                  int* trip_p = nullptr) {
 #define prog (*prog_p)
     double hi[PB - HELPER_COL0];
 #pragma unroll
@@ -211,7 +215,7 @@ __device__ __forceinline__ void panel_helper_wave(const int bs, const int lane, 
     PANEL_FENCE();
     static_for<HELPER_COL0 / CB>([&](auto cc_) {
         constexpr int c0 = CB * decltype(cc_)::value;
-        PANEL_SPIN_WHILE(lds_load_volatile(&prog) < c0 + CB);
+        PANEL_SPIN_WHILE_T(lds_load_volatile(&prog) < c0 + CB, trip_p);
         PANEL_FENCE();
         double xs[CB];
 #pragma unroll
@@ -249,7 +253,7 @@ template <bool RHS = true>
 __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long j0, const int bs, const int lane,
                                                   double (&ar)[PB], double ri, double (*Ls)[PB + 2], double* invd,
                                                   double* zblk, int* prog_p, const int* hflag_p, const int wb_index,
-                                                  const int wb_count) {
+                                                  const int wb_count, int* trip_p = nullptr) {
 #define prog (*prog_p)
     PANEL_FENCE();
     PANEL_STAMP(1);
@@ -262,7 +266,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
             // the groups before this one (panel_helper_wave)
             // (the four columns of this group first; the others are awaited before this group's trailing update)
             PANEL_HOOK(1);
-            PANEL_SPIN_WHILE(lds_load_volatile(hflag_p) == 0);
+            PANEL_SPIN_WHILE_T(lds_load_volatile(hflag_p) == 0, trip_p);
             PANEL_FENCE();
             PANEL_HOOK(2);
 #pragma unroll
@@ -362,7 +366,7 @@ __device__ __forceinline__ void panel_factor_wave(PotrfArgs& a, const long long 
         if (c0 == 48) PANEL_HOOK(4);
         if (c0 == 60) PANEL_HOOK(5);
         if constexpr (c0 == HELPER_COL0) {
-            PANEL_SPIN_WHILE(lds_load_volatile(hflag_p) < 2);
+            PANEL_SPIN_WHILE_T(lds_load_volatile(hflag_p) < 2, trip_p);
             PANEL_FENCE();
 #pragma unroll
             for (int k = HELPER_COL0 + CB; k < PB; k += 2) {
@@ -932,10 +936,36 @@ static std::atomic<int> g_potrf_mode{0};
 #define POTRF_PAIR_MIN_TB 24
 static std::atomic<int> g_potrf_pairs{1};
 static std::atomic<long long> g_potrf_fallbacks{0};
+// Back-off after a persistent launch gave up (its workgroups were not all resident within the timeout: another stream
+// or process holds CUs): every such call costs the timeout AND the re-run, so the next PP_BACKOFF_BASE << (streak - 1)
+// evaluations on that device (at most PP_BACKOFF_MAX) take the launch-per-step path straight away; a persistent launch
+// that completes ends the streak.  (Per device: contention is a property of the device, not of the stream.)
+#define PP_BACKOFF_BASE 64
+#define PP_BACKOFF_MAX 4096
+static std::atomic<long long> g_pp_skip[64];
+static std::atomic<int> g_pp_streak[64];
+static std::atomic<long long> g_pp_skipped{0};
+extern "C" int64_t apgp_potrf_backoff_skips(void) { return g_pp_skipped.load(); }
+static bool pp_backoff_take(int dev) {          // true: this evaluation skips the persistent launch
+    if (dev < 0 || dev >= 64) return false;
+    long long left = g_pp_skip[dev].load();
+    while (left > 0)
+        if (g_pp_skip[dev].compare_exchange_weak(left, left - 1)) { g_pp_skipped.fetch_add(1); return true; }
+    return false;
+}
+static void pp_backoff_report(int dev, bool gave_up) {
+    if (dev < 0 || dev >= 64) return;
+    if (!gave_up) { g_pp_streak[dev].store(0); return; }
+    const int streak = g_pp_streak[dev].fetch_add(1) + 1;
+    long long skip = (long long)PP_BACKOFF_BASE << (streak > 7 ? 6 : streak - 1);
+    if (skip > PP_BACKOFF_MAX) skip = PP_BACKOFF_MAX;
+    g_pp_skip[dev].store(skip);
+}
 extern "C" int apgp_potrf_mode(int mode) {
     if (mode < 0) return g_potrf_mode.load() | (g_potrf_pairs.load() ? 0 : 16);
     if ((mode & ~16) > 3) { apgp_set_error("apgp_potrf_mode: bad argument: mode 0 .. 3 (+ 16: no paired trailing updates)"); return -1; }
     const int prev = g_potrf_mode.exchange(mode & 15) | (g_potrf_pairs.exchange((mode & 16) ? 0 : 1) ? 0 : 16);
+    for (int d = 0; d < 64; ++d) { g_pp_skip[d].store(0); g_pp_streak[d].store(0); }   // (an explicit mode ends any back-off)
     return prev;
 }
 extern "C" int64_t apgp_potrf_fallbacks(void) { return g_potrf_fallbacks.load(); }
@@ -1183,7 +1213,8 @@ int apgp_gram_with_rhs(const double* X, int64_t n, const apgp_kernel_t* kern, do
 extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern, const double* y, double mean,
                              double* K, double* z, int32_t* info_dev, double* out5_dev, double* out5_host,
                              void* stream) {
-    APGP_CHECK_ARG(X && kern && y && K && z && info_dev && out5_dev && out5_host, "null pointer");
+    APGP_CHECK_ARG(X && kern && K && info_dev && out5_dev && out5_host, "null pointer");
+    APGP_CHECK_ARG((y == NULL) == (z == NULL), "y and z must be given together");
     APGP_CHECK_ARG(n >= 1, "n >= 1 required");
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -1194,7 +1225,7 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
     const bool mail = mb && mb->host;
     std::lock_guard<std::mutex> lock(apgp_stream_lock(s));             // (one mailbox, one scratch per stream)
     const long long seq = mail ? ++mb->seq : 0;
-    if (n <= PB) {
+    if (n <= PB && y) {
         // one single-workgroup launch (nll_small_kernel): same values, two launch boundaries fewer
         rc = nll_small_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s, mail ? mb->dev : nullptr, seq);
         if (rc != 0) return rc;
@@ -1203,7 +1234,9 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
         // and the info word, the Cholesky's last launch writes the summary
         rc = apgp_gram_with_rhs(X, n, kern, K, n, y, mean, z, info_dev, stream);
         if (rc != 0) return rc;
-        const long long plan = potrf_plan(n, n, s);
+        long long plan = potrf_plan(n, n, s);
+        const int dev = apgp_stream_device(s);
+        if (plan >= 0 && g_potrf_mode.load() != 2 && pp_backoff_take(dev)) plan = -1;   // (mode 2 = the fallback test: always launches)
         const bool persist = plan >= 0;
         if (plan > 0) {
             rc = potrf_run_locked(K, n, n, 1, 0, y, &mean, z, info_dev, s, true, nullptr, nullptr, 0, plan);
@@ -1214,10 +1247,12 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
         if (rc != 0) return rc;
         if (persist) {
             rc = nll_fetch(mb, mail, seq, s, out5_dev, out5_host);
-            if (rc != 0 || out5_host[4] != PP_ABORTED) return rc;
+            if (rc != 0) return rc;
+            if (out5_host[4] != PP_ABORTED) { pp_backoff_report(dev, false); return rc; }
             // the persistent launch gave up (its workgroups were not all resident in time): the evaluation again,
             // from the Gram matrix, on the multi-launch path
             g_potrf_fallbacks.fetch_add(1);
+            if (g_potrf_mode.load() != 2) pp_backoff_report(dev, true);
             const long long seq2 = mail ? ++mb->seq : 0;
             rc = apgp_gram_with_rhs(X, n, kern, K, n, y, mean, z, info_dev, stream);
             if (rc != 0) return rc;

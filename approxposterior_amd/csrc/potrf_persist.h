@@ -153,13 +153,16 @@ __device__ __forceinline__ bool pp_give_up(PpSpin& sp, pp_u64* ctl, const pp_u64
     if (now - sp.t0 > timeout) { pp_st(ctl + PP_CTL_ABORT, call_id); return true; }
     return false;
 }
-__device__ __forceinline__ void pp_lds_wait_ge(const int* p, int need) {
+// (an expired guard raises `trip` -- this step's "give up" word: the workgroup leaves at the next step head / at the role's
+// exit and marks the CALL aborted, PP_ROLE_EXIT; before round 5 the wait just fell through and the wavefront went on with
+// stale operands while the launch could still finish "successfully")
+__device__ __forceinline__ void pp_lds_wait_ge(const int* p, int need, int* trip) {
 #ifdef PP_EXP_SLOWPOLL   // (timing experiment: the matrix wavefronts poll eight times less often)
-    { unsigned guard_ = 0; while (lds_load_volatile(p) < need) { __builtin_amdgcn_s_sleep(8); if (++guard_ > (1u << 18)) break; } }
+    { unsigned guard_ = 0; while (lds_load_volatile(p) < need) { __builtin_amdgcn_s_sleep(8); if (++guard_ > (1u << 18)) { lds_store_volatile(trip, 1); break; } } }
 #elif defined(PP_EXP_FASTWAIT)   // (timing experiment: no sleep between the looks of the persistent kernel's own LDS waits)
-    { unsigned guard_ = 0; while (lds_load_volatile(p) < need) { if (++guard_ > (1u << 20)) break; } }
+    { unsigned guard_ = 0; while (lds_load_volatile(p) < need) { if (++guard_ > (1u << 20)) { lds_store_volatile(trip, 1); break; } } }
 #else
-    PANEL_SPIN_WHILE(lds_load_volatile(p) < need);
+    PANEL_SPIN_WHILE_T(lds_load_volatile(p) < need, trip);
 #endif
     PANEL_FENCE();
 }
@@ -169,10 +172,10 @@ __device__ __forceinline__ void pp_lds_wait_ge(const int* p, int need) {
 // the groups from there to the granule stream (the stores would cost the solving wavefront ~1 us per step, and its
 // groups pace everybody).  The rows themselves go to memory from As once all sixteen groups are solved (pp_role_solve).
 __device__ __forceinline__ void pp_solve_wave(const int lane, double (&x)[PB], const double (*Ls)[PB + 2], const double* invd,
-                                              int* prog_p, double* As_par, int* xprog_p) {
+                                              int* prog_p, double* As_par, int* xprog_p, int* trip) {
     static_for<PB / CB>([&](auto cc_) {
         constexpr int cc = decltype(cc_)::value, c0 = CB * cc;
-        pp_lds_wait_ge(prog_p, c0 + CB);                 // columns c0 .. c0 + CB - 1 of L_jj published
+        pp_lds_wait_ge(prog_p, c0 + CB, trip);           // columns c0 .. c0 + CB - 1 of L_jj published
         f64x2 dq[CB][CB / 2], iq[CB / 2];
 #pragma unroll
         for (int r = 0; r < CB; ++r)
@@ -276,13 +279,24 @@ __device__ __forceinline__ double* pp_lds_base(unsigned off) {
 // every role runs the same loop over the steps s = 0 .. r, with the workgroup's ONE barrier per step at its end (the
 // roles are functions that are entered once: a function's callee-saved registers are stored and reloaded through
 // scratch memory at entry and exit -- once per launch, not once per step)
+// A wavefront that finds a "give up" word raised -- by a global spin that timed out (which has marked the call aborted
+// already) or by an LDS wait whose guard expired (which has not) -- marks the call aborted itself before it leaves:
+// whatever this workgroup has or has not stored, the host must not trust the launch (the last row workgroup
+// is awaited by nobody, its stale L(nb-1, .), z and logdet would have passed as a result).
+#define PP_ROLE_ABORT(q_) do { if ((threadIdx.x & 63) == 0) pp_st((q_)->ctl + PP_CTL_ABORT, (q_)->call_id); } while (0)
 #define PP_STEP_LOOP_BEGIN(lds_)                                                                     \
     for (int s_in = 0, r_ = (int)blockIdx.x; s_in <= r_; ++s_in) {                                   \
-        if (lds_load_volatile((int*)((lds_) + PP_INTS) + 17 + ((s_in + 1) & 1))) return;   /* somebody gave up during the previous step (uniform) */
+        if (lds_load_volatile((int*)((lds_) + PP_INTS) + 17 + ((s_in + 1) & 1))) { PP_ROLE_ABORT(q); return; }   /* somebody gave up during the previous step (uniform) */
 #define PP_STEP_LOOP_END()                                                                           \
         PP_WSTAMP(s_in);                                                                             \
         if (s_in < r_) __syncthreads();                                                              \
-    }
+    }                                                                                                \
+    PP_ROLE_EXIT(lds, q);
+// after a role's last step: a guard that expired during it (either parity) still aborts the call
+#define PP_ROLE_EXIT(lds_, q_) do {                                                                  \
+        const int* gi_ = (const int*)((lds_) + PP_INTS) + 17;                                        \
+        if (lds_load_volatile(gi_) | lds_load_volatile(gi_ + 1)) PP_ROLE_ABORT(q_);                  \
+    } while (0)
 
 struct PpStep {            // what every role derives from (r, s)
     int r, s, bs;
@@ -342,12 +356,12 @@ __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     pa.A = q->a.A; pa.rhs = nullptr;                           // (the forward solve is a separate pass below)
     pa.n = n; pa.lda = q->a.lda; pa.j0 = p.j0; pa.shift = 0.0; pa.info = q->a.info; pa.out5 = nullptr; pa.mail = nullptr; pa.seq = 0;
     pa.dscr = q->a.dscr; pa.batch_dscr = 0; pa.zoff = q->a.zoff; pa.batch_A = 0; pa.batch_rhs = 0; pa.abort_word = nullptr; pa.abort_id = 0; pa.no_panel = 0; pa.info_j0 = q->a.info_j0;
-    panel_factor_wave<false>(pa, p.j0, bs, lane, rowv, 0.0, Ls, invd, zblk, p.cnt + 0, p.cnt + 1, r == s ? 0 : PB, 1);
+    panel_factor_wave<false>(pa, p.j0, bs, lane, rowv, 0.0, Ls, invd, zblk, p.cnt + 0, p.cnt + 1, r == s ? 0 : PB, 1, p.abl);
     PP_STAMP(s, 1);
     if (r == s && q->a.rhs) {
         // z_s = L_ss^-1 (rhs block s): the operations of the pass that rides along in panel_factor_wave, in its
         // order, on the finished factor (Ls, invd) -- the 4 x 4 blocks of Ls ARE its d[][] bit for bit
-        pp_lds_wait_ge(p.cnt + 4, 1);
+        pp_lds_wait_ge(p.cnt + 4, 1, p.abl);
         double ri = lane < bs ? zrow[lane] : 0.0;
         static_for<PB / CB>([&](auto cc_) {
             constexpr int c0 = CB * decltype(cc_)::value;
@@ -419,7 +433,7 @@ __device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
         }
         PANEL_FENCE();
     }
-    pp_solve_wave(lane, rowv, Ls, lds + PP_INVD, p.cnt + 0, p.As_cur, p.cnt + 2);
+    pp_solve_wave(lane, rowv, Ls, lds + PP_INVD, p.cnt + 0, p.As_cur, p.cnt + 2, p.abl);
     PP_STAMP(p.s, 2);
     PP_STAMPP(p.s, 21);
     {
@@ -556,7 +570,7 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
         const __amdgpu_buffer_rsrc_t rs_strm = __builtin_amdgcn_make_buffer_rsrc((void*)q->strm, 0, (int)(PP_STRM_WORDS * 8), 0x00020000);
         static_for<PB / CB>([&](auto cc_) {
             constexpr int cc = decltype(cc_)::value;
-            pp_lds_wait_ge(p.cnt + 2, cc + 1);
+            pp_lds_wait_ge(p.cnt + 2, cc + 1, p.abl);
             const double* src = p.As_cur + (cc >> 2) * PP_CHUNK + lane * 18 + 4 * (cc & 3);
             const f64x2 a0 = *(const f64x2*)src, a1 = *(const f64x2*)(src + 2);
             const double xs[4] = {a0.x, a0.y, a1.x, a1.y};
@@ -617,7 +631,7 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     if (producer) {
 #pragma unroll 1
         for (int g = 0; g < PB / CB; ++g) {
-            pp_lds_wait_ge(xprog, g + 1);
+            pp_lds_wait_ge(xprog, g + 1, p.abl);
             const double* Ach = p.As_cur + (g >> 2) * PP_CHUNK;
             pp_kstep<false>(Ach, Ach, g & 3, lane, wr, wc, bcol, v, v2);
             PP_KSTAMPS();
@@ -625,8 +639,8 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     } else {
 #pragma unroll 1
         for (int g = 0; g < PB / CB; ++g) {
-            pp_lds_wait_ge(xprog, g + 1);
-            pp_lds_wait_ge(bprog, g + 1);
+            pp_lds_wait_ge(xprog, g + 1, p.abl);
+            pp_lds_wait_ge(bprog, g + 1, p.abl);
             pp_kstep<true>(p.As_cur + (g >> 2) * PP_CHUNK, Bs + (g >> 2) * PP_CHUNK, g & 3, lane, wr, wc, bcol, v, v2);
             PP_KSTAMPS();
         }
@@ -636,7 +650,7 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     // k-step, while the wavefront waits for the last group anyway, changed nothing: the hand-over is bound by its 32
     // scattered ds_write_b64 per wavefront -- 3-4-way bank conflicts of the accumulator layout at a row stride of 66
     // doubles, which is the conflict-free stride for the row-per-lane accesses of the panel code.)
-    pp_lds_wait_ge(p.cnt + 5, 1);
+    pp_lds_wait_ge(p.cnt + 5, 1, p.abl);
     if (lds_load_volatile(p.cnt + 5) != 1) dead = true;
     if (mw == 0) PP_STAMP(s, 5);
     double (*St)[PB + 2] = (double (*)[PB + 2])p.As_prev;
@@ -730,7 +744,7 @@ __device__ PP_NOINLINE void pp_stage_tiles(unsigned lds_off, PpKarg karg, int s_
                 const int gr = rw < nrow ? ri0 + rw : ni - 1;
                 tv[it] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_A, (unsigned)(gr * ldai + bn + col) * 8u, 0, 16));
             }
-            pp_lds_wait_ge(cnt + 6, 1);                        // (wavefront 3 is done with L(r, s-1) in this parity of As)
+            pp_lds_wait_ge(cnt + 6, 1, ints + 17 + (s & 1));                        // (wavefront 3 is done with L(r, s-1) in this parity of As)
 #pragma unroll
             for (int it = 0; it < 32; ++it) {
                 const int e = it * 64 + ln, rw = e >> 5, col = 2 * (e & 31);
@@ -769,8 +783,8 @@ __device__ PP_NOINLINE void pp_stage_tiles(unsigned lds_off, PpKarg karg, int s_
         for (int it = 0; it < 32; ++it) asm volatile("" : "+v"(tv[it]), "+v"(la[it]));
         // (prog = PB: the factorisation has published its last group and touches Ls no more in a workgroup that is not the
         // step's diagonal one -- not PB + 1: hipcc sinks the 64 pivot checks behind the last publish, 1.1 us before that)
-        pp_lds_wait_ge(cnt + 0, PB);
-        pp_lds_wait_ge(cnt + 2, PB / CB);                      // (... and the solving wavefront has read its last group of the factor)
+        pp_lds_wait_ge(cnt + 0, PB, ints + 17 + (s & 1));
+        pp_lds_wait_ge(cnt + 2, PB / CB, ints + 17 + (s & 1));                      // (... and the solving wavefront has read its last group of the factor)
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int it = 0; it < 32; ++it)
@@ -793,7 +807,7 @@ __device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
     const long long j0 = (long long)s_in * PB;
     int* cnt = (int*)(lds + PP_INTS) + 8 * (s_in & 1);
     __builtin_amdgcn_s_setprio(3);         // (the factorisation waits for these columns at group 8)
-    panel_helper_wave((int)((n - j0) < PB ? (n - j0) : PB), lane, Ls, cnt + 0, cnt + 1);
+    panel_helper_wave((int)((n - j0) < PB ? (n - j0) : PB), lane, Ls, cnt + 0, cnt + 1, (int*)(lds + PP_INTS) + 17 + (s_in & 1));
     __builtin_amdgcn_s_setprio(0);
     PP_STAMP(s_in, 16);
     // (the step's barrier is the last thing pp_stage_tiles does -- it is called exactly when the step has one -- so that the
@@ -801,6 +815,7 @@ __device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
     // was the last one to arrive)
     if (r_ > s_in) pp_stage_tiles(lds_off, karg, s_in);
     }
+    PP_ROLE_EXIT(lds, q);
 }
 
 __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, const unsigned lds_off) {

@@ -592,33 +592,28 @@ class GP(object):
             else:
                 K = (torch.empty if (yv is not None and n <= 64) else torch.zeros)((n, n), dtype=torch.float64, device=dev)
                 z = None
+            # the whole evaluation as ONE library call and one synchronisation: Gram + Cholesky on the persistent /
+            # hybrid plan (+ z = L^-1 (y - mean) riding along when y is given: a gpUtils._nll evaluation; without y:
+            # compute() / recompute(), the same plan -- round 4 still sent these through a launch per 64-column step)
+            y_d = None
             if yv is not None:
-                # the whole _nll evaluation as one library call and one synchronisation
                 y_d = keep_y if keep_y is not None else torch.from_numpy(yv).to(dev)
                 if z is None:
                     z = torch.empty(n, dtype=torch.float64, device=dev)
-                scr = self._nll_scratch
-                if scr is None:
-                    scr = self._nll_scratch = (torch.empty(1, dtype=torch.int32, device=dev),
-                                               torch.empty(5, dtype=torch.float64, device=dev))
-                o = np.empty(5, dtype=np.float64)
-                _lib.check(lib.apgp_nll_eval(self._x_d.data_ptr(), n, ctypes.byref(ks), y_d.data_ptr(),
-                                             float(self.mean.value), K.data_ptr(), z.data_ptr(),
-                                             scr[0].data_ptr(), scr[1].data_ptr(), o.ctypes.data, st),
-                           "apgp_nll_eval")
-                L = K
-            else:
-                _lib.check(lib.apgp_gram(self._x_d.data_ptr(), n, ctypes.byref(ks), K.data_ptr(), n, st),
-                           "apgp_gram")
-                out5 = torch.empty(5, dtype=torch.float64, device=dev)
-                # blocked Cholesky (csrc/potrf.hip), in place on the Gram matrix
-                info = torch.empty(1, dtype=torch.int32, device=dev)
-                _lib.check(lib.apgp_potrf(K.data_ptr(), n, n, None, 0.0, None, info.data_ptr(), st),
-                           "apgp_potrf")
-                L = K
-                _lib.check(lib.apgp_fit_summary(L.data_ptr(), n, n, None, info.data_ptr(), out5.data_ptr(), st),
-                           "apgp_fit_summary")
-                o = out5.cpu().numpy()          # the only synchronisation of the evaluation
+            scr = self._nll_scratch
+            if scr is None:
+                scr = self._nll_scratch = (torch.empty(1, dtype=torch.int32, device=dev),
+                                           torch.empty(5, dtype=torch.float64, device=dev))
+            o = np.empty(5, dtype=np.float64)
+            _lib.check(lib.apgp_nll_eval(self._x_d.data_ptr(), n, ctypes.byref(ks),
+                                         y_d.data_ptr() if y_d is not None else None,
+                                         float(self.mean.value), K.data_ptr(),
+                                         z.data_ptr() if yv is not None else None,
+                                         scr[0].data_ptr(), scr[1].data_ptr(), o.ctypes.data, st),
+                       "apgp_nll_eval")
+            if yv is None:
+                z = None
+            L = K
         if int(o[4]) != 0:
             # same failure mode as scipy.linalg.cholesky inside george
             raise LinAlgError("%d-th leading minor of the array is not positive definite" % int(o[4]))

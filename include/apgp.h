@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define APGP_ABI_VERSION 6
+#define APGP_ABI_VERSION 7
 #define APGP_MAX_DIM 16          /* feature dimension D supported by the kernels */
 #define APGP_ROW_BLOCK 512       /* rows per packed L^-1 row block (sweep tile)  */
 #define APGP_K_CHUNK 16          /* contraction depth per packed tile            */
@@ -153,11 +153,20 @@ int apgp_release_scratch(void* stream);
  * out5_dev are STREAM-ordered (read them from work enqueued on `stream`, or after
  * synchronising it), not host- or other-stream-visible on return.
  * Status as the parts'; a non-PD matrix is reported in out5_host[4] (> 0), not in the status.
- * 64 < n <= 3072: the Cholesky is ONE persistent launch (csrc/potrf_persist.h: row workgroups
- * chained by in-launch hand-offs instead of a launch per 64-column step; bit-identical to the
- * multi-launch path).  All of its workgroups must be resident at once; if they are not within
- * 50 ms (a foreign kernel holds compute units) the launch gives up and the call transparently
- * re-runs the evaluation on the multi-launch path (counted by apgp_potrf_fallbacks).      */
+ * 64 < n <= 3200 (50 block columns): the Cholesky is ONE persistent launch (csrc/potrf_persist.h:
+ * row workgroups chained by in-launch hand-offs instead of a launch per 64-column step); above
+ * that a hybrid -- a launch per step for the first block columns, ONE persistent launch for the
+ * trailing 44 x 44 blocks; all bit-identical to the multi-launch path.  The persistent launch
+ * needs one compute unit per workgroup (512 threads, 160 KB of LDS each: up to all 256 CUs), all
+ * resident at once; if they are not within 50 ms (a kernel of another stream or process holds
+ * compute units or LDS) the launch gives up -- every expired wait inside it marks the call
+ * aborted -- and the call transparently re-runs the evaluation on the multi-launch path
+ * (counted by apgp_potrf_fallbacks).  LATENCY CLIFF: such a call costs the 50 ms plus the
+ * re-run; after it the next 64 evaluations on that device (doubling per consecutive give-up,
+ * at most 4096) go straight to the multi-launch path (counted by apgp_potrf_backoff_skips), and
+ * the first persistent launch that completes ends the back-off.
+ * y == NULL and z == NULL (round 5; GP.compute / recompute): the factorisation alone on the same
+ * plan, out5[3] = 0.                                                                          */
 int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/,
                   const double* y, double mean, double* K, double* z,
                   int32_t* info_dev, double* out5_dev, double* out5_host /*host*/,
@@ -170,10 +179,12 @@ int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/
  * at once (exercises the fallback); 3 = persistent launch wherever it can run (64 < n <= 4096).
  * + 16: the launch-per-step path without its paired trailing updates (two block columns per
  * pass over a tile while the trailing matrix is large) -- all variants return the same bits.
- * mode < 0 only queries.  Returns the previous mode (-1: bad argument).
- * apgp_potrf_fallbacks: evaluations re-run on the multi-launch path so far (process-wide). */
+ * mode < 0 only queries; setting a mode also ends any back-off.  Returns the previous mode (-1: bad argument).
+ * apgp_potrf_fallbacks: evaluations re-run on the multi-launch path so far (process-wide);
+ * apgp_potrf_backoff_skips: evaluations that skipped the persistent launch while backing off. */
 int apgp_potrf_mode(int mode);
 int64_t apgp_potrf_fallbacks(void);
+int64_t apgp_potrf_backoff_skips(void);
 
 /* ---- `batch` _nll evaluations at different hyper-parameters, one call ----------
  * (the restarts of gpUtils.optimizeGP, gpUtils.py:223-247,
@@ -191,15 +202,17 @@ int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch,
  * Replaces BasicSolver.apply_inverse / dot_solve on a vector (scipy cho_solve;
  * george GP.log_likelihood and _compute_alpha; gpUtils.py:78, utility.py:131).
  * trans = 0: solve L x = (b - shift); trans = 1: solve L^T x = (b - shift).
- * If sumsq != NULL, *sumsq = x.x (device scalar).  x may alias b.  From n = 256 the solve runs
- * as one small launch per 64-row block with n doubles of stream-ordered scratch kept by the
- * library per (device, stream) (hipMallocAsync); below that one workgroup, right-hand side in LDS. */
+ * If sumsq != NULL, *sumsq = x.x (device scalar).  x may alias b.  Below n = 256: one workgroup,
+ * right-hand side in LDS.  256 <= n <= 16384: ONE persistent launch (a workgroup per 64-row block,
+ * solved blocks handed on as data-tagged granules; stream-ordered scratch per (device, stream):
+ * slot 3 of csrc/scratch.h).  Above, or with apgp_trsv_mode(1): one launch per 256 rows with n
+ * doubles of stream-ordered scratch.  All paths return the same bits.  If the persistent launch's
+ * workgroups are not all resident within its timeout, x and *sumsq are written as NaN (no
+ * automatic re-run: callers that may share the device re-issue with apgp_trsv_mode(1)).      */
 int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
               int trans, double* x, double* sumsq, void* stream);
-/* Round 4: for 256 <= n <= 16384 the blocked solve is ONE persistent launch (a workgroup per 64-row
- * block, solved blocks handed on as data-tagged granules; same bits as the launch-per-256-rows
- * path).  Test / profiling switch (not read from the environment): 1 = that multi-launch path,
- * 0 = default; < 0 queries.  Returns the previous value.                                        */
+/* Test / profiling switch (not read from the environment): 1 = the multi-launch path, 0 = default
+ * (persistent launch where it applies); < 0 queries.  Returns the previous value.             */
 int apgp_trsv_mode(int multi_launch);
 
 /* ---- pivot of an appended factor row -----------------------------------------
