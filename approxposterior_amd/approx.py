@@ -122,6 +122,7 @@ class ApproxPosterior(object):
     def __init__(self, theta, y, lnprior, lnlike, priorSample, bounds, gp=None,
                  algorithm="bape", distributed=None, group=None):
         self.distributed, self.group = distributed, group
+        self.deviceCandidates = False      # nCandidates drawn on the device, uniform in ``bounds`` (see findNextPoint)
         if theta is None or y is None:
             raise ValueError("Must supply both theta and y for initial GP training set.")
         self.theta = np.array(theta).squeeze()
@@ -226,19 +227,29 @@ class ApproxPosterior(object):
                                                 options=options, bounds=self.bounds, theta0=theta0,
                                                 args=scalarArgs)
             return self._agree(point, value) if ranks is not None else (point, value)
-        draws = np.asarray(self.priorSample(int(nCandidates)), dtype=float).reshape(int(nCandidates), -1)
-        if ranks is None:
-            point, value = ut.sweepObjective(utility, self.y, self.gp, draws, bounds=self.bounds)
+        total = int(nCandidates)
+        kind = ut.utilityKind(utility) if (ranks is not None or self.deviceCandidates) else None
+        lo, hi = apdist.shard_bounds(total, ranks[1], ranks[0]) if ranks is not None else (0, total)
+        if self.deviceCandidates:
+            # the global matrix is a function of (seed, row) alone: this rank generates its rows in HBM, no host draw,
+            # no H2D copy; the box ``bounds`` IS the prior here (priorSample is not consulted)
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+            mine = self.gp.box_candidates(hi - lo, self.bounds, seed, idx_offset=lo)
+            row = lambda g: self.gp.box_candidates(1, self.bounds, seed, idx_offset=g).cpu().numpy()[0]   # noqa: E731
         else:
-            lo, hi = apdist.shard_bounds(len(draws), ranks[1], ranks[0])
-            kind = ut.utilityKind(utility)
+            draws = np.asarray(self.priorSample(total), dtype=float).reshape(total, -1)
+            mine = draws if ranks is None else np.ascontiguousarray(draws[lo:hi])
+            row = lambda g: np.array(draws[g])                                                              # noqa: E731
+        if ranks is None and not self.deviceCandidates:
+            point, value = ut.sweepObjective(utility, self.y, self.gp, mine, bounds=self.bounds)
+        else:
             best, value = apdist.sharded_acquire(
-                lambda offset: self.gp.acquire(self.y, np.ascontiguousarray(draws[lo:hi]), kind,
-                                               bounds=self.bounds, idx_offset=offset, device_record=True),
-                lo, group=self.group)
+                lambda offset: self.gp.acquire(self.y, mine, kind, bounds=self.bounds, idx_offset=offset,
+                                               device_record=True),
+                lo, group=self.group if ranks is not None else None)
             if best < 0:
                 raise RuntimeError("ERROR: Cannot find a valid solution: no candidate is allowed by the prior")
-            point = np.array(draws[best])
+            point = row(best)
         if polish:
             point, value = ut.minimizeObjective(utility, self.y, self.gp,
                                                 sampleFn=self.priorSample, priorFn=self._lnprior,
@@ -272,7 +283,7 @@ class ApproxPosterior(object):
                       minObjMethod="nelder-mead", minObjOptions=None,
                       runName="apRun", numNewPoints=1, optGPEveryN=1,
                       gpHyperPrior=gpUtils.defaultHyperPrior, args=None,
-                      nCandidates=None, polish=False, **kwargs):
+                      nCandidates=None, polish=False, deviceCandidates=None, **kwargs):
         """Select ``numNewPoints`` design points by minimising the (negative) utility;
         with ``computeLnLike`` evaluate the forward model at each, absorb it into the
         training set / GP and re-fit the hyper-parameters every ``optGPEveryN`` points
@@ -281,8 +292,13 @@ class ApproxPosterior(object):
 
         ``nCandidates`` replaces the restarted Nelder-Mead search by the fused device
         sweep over that many ``priorSample`` draws (box ``bounds`` as the prior);
-        ``polish`` refines the sweep winner with one Nelder-Mead run.
+        ``polish`` refines the sweep winner with one Nelder-Mead run;
+        ``deviceCandidates=True`` draws the candidates on the device, uniformly in ``bounds``
+        (counter-based Philox keyed by one integer from NumPy's global stream) instead of calling
+        ``priorSample`` -- valid when the prior IS that box.
         """
+        if deviceCandidates is not None:
+            self.deviceCandidates = bool(deviceCandidates)
         assert isinstance(numNewPoints, int) and numNewPoints >= 1
         assert isinstance(optGPEveryN, int) and optGPEveryN >= 1
         if verbose and numNewPoints < optGPEveryN:
@@ -452,14 +468,15 @@ class ApproxPosterior(object):
             nMinObjRestarts=5, onlyLastMCMC=False, initGPOpt=True, kmax=3,
             gpHyperPrior=gpUtils.defaultHyperPrior, eps=1.0, convergenceCheck=False,
             minObjMethod="nelder-mead", minObjOptions=None, args=None,
-            nCandidates=None, onDevice=False, batched=True, **kwargs):
+            nCandidates=None, onDevice=False, batched=True, deviceCandidates=None, **kwargs):
         """BAPE / AGP outer loop (approx.py:229-524): ``nmax`` times, find ``m`` design
         points (re-fitting the GP every ``optGPEveryN``), sample the surrogate posterior,
         record burn-in / thinning, and -- with ``convergenceCheck`` -- stop once the
         marginal means have moved by less than ``eps`` previous standard deviations for
         ``kmax`` consecutive iterations.  (The reference honours that rule only when
         ``verbose`` is set, quirk Q4; here it does not depend on verbosity.)
-        ``nCandidates`` switches the point search to the fused device sweep;
+        ``nCandidates`` switches the point search to the fused device sweep
+        (``deviceCandidates``: drawn on the device, see :meth:`findNextPoint`);
         ``onDevice`` / ``batched`` are passed to :meth:`runMCMC`."""
         if convergenceCheck and onlyLastMCMC:
             raise RuntimeError("If convergenceCheck is True, must run an MCMC each iteration.\n"
@@ -488,7 +505,7 @@ class ApproxPosterior(object):
                                optGPEveryN=optGPEveryN, numNewPoints=m,
                                minObjMethod=minObjMethod, minObjOptions=minObjOptions,
                                runName=runName, theta0=None, args=args, verbose=verbose,
-                               nCandidates=nCandidates, **fit, **kwargs)
+                               nCandidates=nCandidates, deviceCandidates=deviceCandidates, **fit, **kwargs)
             if timing:
                 self.trainingTime.append(time.time() - clock)
             if cache:
@@ -552,7 +569,7 @@ class ApproxPosterior(object):
                  gpOptions=None, gpP0=None, optGPEveryN=1, nGPRestarts=1,
                  nMinObjRestarts=5, initGPOpt=True, minObjMethod="nelder-mead",
                  gpHyperPrior=gpUtils.defaultHyperPrior, minObjOptions=None,
-                 findMAP=True, args=None, nCandidates=None, **kwargs):
+                 findMAP=True, args=None, nCandidates=None, deviceCandidates=None, **kwargs):
         """Bayesian optimisation (approx.py:929-1151): one design point per iteration by
         the object's utility (use algorithm="jones"), optionally the MAP of the GP mean
         after each, stop after ``kmax`` consecutive iterations whose best value changed
@@ -579,7 +596,8 @@ class ApproxPosterior(object):
                                               optGPEveryN=period, numNewPoints=1,
                                               minObjMethod=minObjMethod, minObjOptions=minObjOptions,
                                               runName=runName, args=args, verbose=verbose,
-                                              nCandidates=nCandidates, **fit, **kwargs)
+                                              nCandidates=nCandidates, deviceCandidates=deviceCandidates,
+                                              **fit, **kwargs)
             evaluations = iteration + 1
             if verbose:
                 print("Forward model evaluation at: ", point, ", function value: ", value)

@@ -314,3 +314,51 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
     APGP_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Candidate matrix of the acquisition sweep drawn ON the device (round 5; opt-in, ApproxPosterior(deviceCandidates)):
+// the reference's point search starts from ``priorSample`` draws (utility.py:334-338); the batched counterpart
+// sweeps M of them, and drawing 1e6 x 8 uniforms with NumPy + the H2D copy cost more than the sweep itself at
+// C5's sizes (26 ms vs 18 ms).  Row i of the GLOBAL matrix is a pure function of (seed, i): counter-based
+// Philox4x32-10, counter = (i low, i high, d / 2, 0x43414e44 "CAND"), key = seed -- so rank r of a sharded sweep
+// generates exactly its rows [lo, hi) with idx_offset = lo, and anybody can regenerate the winning row alone.
+//   T[i][d] = lo[d] + (hi[d] - lo[d]) * u,  u = 53-bit uniform in (0, 1) (u01 above).
+// ---------------------------------------------------------------------------
+struct BoxArgs {
+    double* T;
+    long long m, idx_offset;
+    int ndim;
+    unsigned long long seed;
+    double lo[APGP_MAX_DIM], span[APGP_MAX_DIM];
+};
+
+__global__ __launch_bounds__(256) void box_candidates_kernel(BoxArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.m) return;
+    const unsigned long long g = (unsigned long long)(a.idx_offset + i);
+    double* row = a.T + i * a.ndim;
+    for (int d = 0; d < a.ndim; d += 2) {
+        unsigned int c[4] = {(unsigned int)g, (unsigned int)(g >> 32), (unsigned int)(d >> 1), 0x43414e44u};
+        philox4x32(c, (unsigned int)a.seed, (unsigned int)(a.seed >> 32));
+        row[d] = fma(a.span[d], u01(c[0], c[1]), a.lo[d]);
+        if (d + 1 < a.ndim) row[d + 1] = fma(a.span[d + 1], u01(c[2], c[3]), a.lo[d + 1]);
+    }
+}
+
+extern "C" int apgp_box_candidates(double* T, int64_t m, int32_t ndim, const double* lo, const double* hi,
+                                   uint64_t seed, int64_t idx_offset, void* stream) {
+    APGP_CHECK_ARG(T && lo && hi, "null pointer");
+    APGP_CHECK_ARG(m >= 0 && idx_offset >= 0, "m >= 0 and idx_offset >= 0 required");
+    APGP_CHECK_ARG(ndim >= 1 && ndim <= APGP_MAX_DIM, "1 <= ndim <= APGP_MAX_DIM required");
+    if (m == 0) return 0;
+    BoxArgs a;
+    a.T = T; a.m = m; a.idx_offset = idx_offset; a.ndim = ndim; a.seed = seed;
+    for (int d = 0; d < APGP_MAX_DIM; ++d) {
+        a.lo[d] = d < ndim ? lo[d] : 0.0;
+        a.span[d] = d < ndim ? hi[d] - lo[d] : 0.0;
+        APGP_CHECK_ARG(d >= ndim || (a.span[d] >= 0.0 && a.span[d] < INFINITY), "bounds must be finite with lo <= hi");
+    }
+    hipLaunchKernelGGL(box_candidates_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}

@@ -1068,6 +1068,25 @@ class GP(object):
                     out.append(u.cpu().numpy())
         return tuple(out)
 
+    # -- candidate matrix of the sweep drawn on the device -----------------------------
+    def box_candidates(self, m, bounds, seed, idx_offset=0):
+        """Rows ``idx_offset .. idx_offset + m - 1`` of the global candidate matrix ``U[bounds]`` keyed by ``seed``
+        (counter-based Philox: a row depends on (seed, row number) only), as a device tensor (m, D) ready for
+        :meth:`acquire` -- the batched counterpart of the ``sampleFn`` draws utility.minimizeObjective starts from
+        (utility.py:334-338) without the host draw and the H2D copy (26 ms per 1e6 x 8 against an 18 ms sweep)."""
+        torch, dev, lib = self._rt()
+        D = self.kernel.ndim
+        b = np.asarray(bounds, dtype=np.float64).reshape(-1, 2)
+        if len(b) != D:
+            raise ValueError("bounds must have one (lo, hi) pair per dimension")
+        lo = (ctypes.c_double * _lib.MAX_DIM)(*b[:, 0])
+        hi = (ctypes.c_double * _lib.MAX_DIM)(*b[:, 1])
+        with self._on(torch, dev):
+            T = torch.empty((int(m), D), dtype=torch.float64, device=dev)
+            _lib.check(lib.apgp_box_candidates(T.data_ptr(), int(m), D, lo, hi, int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                               int(idx_offset), self._stream(torch)), "apgp_box_candidates")
+        return T
+
     # -- on-device ensemble MCMC over the GP mean ------------------------------------
     def sample_ensemble(self, y, initial_state, iterations, bounds, a=2.0, seed=0, store=True):
         """Run the stretch-move ensemble sampler entirely on the device with

@@ -356,6 +356,16 @@ int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kernel_t* kern 
                          double* coords, double* logp, double* chain, double* logp_chain,
                          int64_t* naccept, void* stream);
 
+/* ---- candidate matrix of the sweep drawn on the device (round 5, opt-in) ------
+ * The batched counterpart of the ``sampleFn`` draws utility.minimizeObjective starts from
+ * (utility.py:334-338) when the prior is the box: T (m x ndim, device) row i =
+ * lo + (hi - lo) * u(seed, idx_offset + i), u = 53-bit uniforms in (0, 1) from counter-based
+ * Philox4x32-10 (counter = (row low, row high, d / 2, "CAND"), key = seed).  Row g of the global
+ * matrix depends on (seed, g) only: a rank of a sharded sweep generates its own rows with
+ * idx_offset = first row, and any rank regenerates the winning row alone.               */
+int apgp_box_candidates(double* T, int64_t m, int32_t ndim, const double* lo /*host*/,
+                        const double* hi /*host*/, uint64_t seed, int64_t idx_offset, void* stream);
+
 /* ---- K4: gradient of the log-likelihood wrt kernel hyper-parameters -------
  * Replaces george GP.grad_log_likelihood (gpUtils._grad_nll, gpUtils.py:110):
  *   g_k = 0.5 * sum_ij (alpha alpha^T - K^-1)_ij dK_ij/dtheta_k.
