@@ -53,6 +53,14 @@ typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef PP_AUTO_NB
 #define PP_AUTO_NB 50
 #endif
+#ifndef PP_SG16
+#define PP_SG16 1                                 // round 5: 16-column super-groups + catch-up on the matrix cores (potrf_persist_sg.h); 0: round 4's step
+#endif
+#if PP_SG16 && defined(PP_EXP_PAIR_LIGHT)
+#define PP_W_RECV 4                               // wavefront of the receiver role (see pp_row_role)
+#else
+#define PP_W_RECV 3
+#endif
 //                              // block columns up to which the persistent launch is the default
 #define PP_THREADS 512
 #define PP_CHUNK (64 * 18)                        // a 16-column chunk of a 64-row tile, rows padded to 18 (apgp_gemm64_tile's)
@@ -64,10 +72,11 @@ typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
 #define PP_ZBLK (PP_INVD + 64)
 #define PP_ZROW (PP_ZBLK + 64)
 #define PP_ZST (PP_ZROW + 64)
-#define PP_INTS (PP_ZST + 64)                     // 2 x 8 step-parity counters + 8 others
+#define PP_INTS (PP_ZST + 64)                     // 64 ints: 2 x 8 step-parity counters, 17 / 18 "give up", from 24: 2 x 16 super-group flags
+#define PP_XFER (PP_INTS + 32)                    // [64][18]  the tile's columns of the next super-group, matrix wavefronts -> solver (potrf_persist_sg.h)
 #define PP_LDS_DOUBLES (160 * 1024 / 8)
 #define PP_LDS_BYTES (PP_LDS_DOUBLES * 8)
-static_assert(PP_INTS + 12 <= PP_LDS_DOUBLES, "one row workgroup per CU");
+static_assert(PP_XFER + 64 * 18 <= PP_LDS_DOUBLES, "one row workgroup per CU");
 // update role: two buffers (current / next tile) of the two whole operand tiles of a product (chunk layout), counters
 #define PP_UPD_HALF (2 * 4 * PP_CHUNK)
 #define PP_UPD_INTS (2 * PP_UPD_HALF)
@@ -106,7 +115,23 @@ __device__ unsigned long long pp_ustamps[64 * 8];
 extern "C" int apgp_debug_read_ustamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_ustamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -2;
 }
+// (round 5, super-group step) the factorising / solving wavefront of the last row workgroup: 0 entry | 1 super-group 0 done |
+// 2 boundary 1 received | 3 super-group 1 done | 4 boundary 2 received | 5 super-group 2 done | 6 boundary 3 received | 7 done
+#define PP_FSTAMP(s_, i_) do { if ((int)blockIdx.x == q->nb - 1 && (threadIdx.x & 63) == 0) pp_fstamps[(s_) * 8 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PP_GSTAMP(s_, i_) do { if ((int)blockIdx.x == q->nb - 1 && (threadIdx.x & 63) == 0) pp_gstamps[(s_) * 8 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// event log of the four matrix wavefronts of the last row workgroup at step 5: [mw][event][0 start | 1 end | 2 kind]
+// (kind: 100 + H catch-up D | 200 + H catch-up T | g k-step)
+__device__ unsigned long long pp_estamps[4 * 32 * 3];
+#define PP_ESTAMP_BEGIN(kind_) do { if (s == 5 && (int)blockIdx.x == q->nb - 1 && lane == 0 && nev < 32) { pp_estamps[(mw * 32 + nev) * 3 + 0] = __builtin_amdgcn_s_memrealtime(); pp_estamps[(mw * 32 + nev) * 3 + 2] = (kind_); } } while (0)
+#define PP_ESTAMP_END() do { if (s == 5 && (int)blockIdx.x == q->nb - 1 && lane == 0 && nev < 32) { pp_estamps[(mw * 32 + nev) * 3 + 1] = __builtin_amdgcn_s_memrealtime(); } ++nev; } while (0)
+extern "C" int apgp_debug_read_estamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_estamps), sizeof(unsigned long long) * 4 * 32 * 3) == hipSuccess ? 0 : -2;
+}
 #else
+#define PP_ESTAMP_BEGIN(kind_) do { } while (0)
+#define PP_ESTAMP_END() do { } while (0)
+#define PP_FSTAMP(s_, i_) do { } while (0)
+#define PP_GSTAMP(s_, i_) do { } while (0)
 #define PP_STAMP(s_, i_) do { } while (0)
 #define PP_WSTAMP(s_) do { } while (0)
 #define PP_STAMPP(s_, i_) do { } while (0)
@@ -303,6 +328,7 @@ struct PpStep {            // what every role derives from (r, s)
     long long j0;
     bool producer;
     int* cnt;              // this step's counters: 0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 As_prev free
+    int* cnt2;             // super-group flags, one word per matrix wavefront: 0-3 diagonal block handed back | 4-7 tile | 8-11 staged values in registers
     int* abl;
     double* As_cur;
     double* As_prev;
@@ -318,6 +344,7 @@ __device__ __forceinline__ PpStep pp_step(double* lds, int s_in, long long n) {
     // step-parity counters: [par][0 prog | 1 hflag | 2 xprog | 3 bprog | 4 zflag | 5 cflag | 6 As_prev free]; others: 17, 18 "give up" by
     // step parity (set during step s, read at the head of step s + 1: never while it may still be written)
     p.cnt = ints + 8 * (p.s & 1);
+    p.cnt2 = ints + 24 + 16 * (p.s & 1);
     p.abl = ints + 17 + (p.s & 1);
     p.As_cur = lds + PP_AS + (p.s & 1) * 4 * PP_CHUNK;         // this step's solved tile; at the step's start: the handed-over tile [64][66]
     p.As_prev = lds + PP_AS + ((p.s & 1) ^ 1) * 4 * PP_CHUNK;  // L(r, s-1); at the step's end: the hand-over of the next tile
@@ -325,6 +352,7 @@ __device__ __forceinline__ PpStep pp_step(double* lds, int s_in, long long n) {
 }
 
 
+#if !PP_SG16
 // ---------------- wavefront 0: the diagonal block (s, s); at step r also z_r ----------------
 __device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
     pp_args_ptr q = pp_args(karg);
@@ -467,6 +495,8 @@ __device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
     PP_STEP_LOOP_END()
 }
 
+#endif   // !PP_SG16
+
 // ---------------- wavefront 3: receiver -- z of the previous block column, then the groups of L(s+1, s) ----------------
 // rhs_r: the running right-hand side of the forward solve for this lane's matrix row
 __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double rhs_r) {
@@ -591,6 +621,7 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
     PP_STEP_LOOP_END()
 }
 
+#if !PP_SG16
 // ---------------- wavefronts 4-7: the next tile and the next diagonal block ----------------
 __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     pp_args_ptr q = pp_args(karg);
@@ -688,6 +719,8 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     }
     PP_STEP_LOOP_END()
 }
+
+#endif   // !PP_SG16
 
 // ---------------- wavefront 2: the factorisation's helper for the first eight column groups; then -- idle otherwise -- it
 // watches the flags of the two tiles the matrix wavefronts subtract their products from (tile (r, s+1) and the next
@@ -797,6 +830,7 @@ __device__ PP_NOINLINE void pp_stage_tiles(unsigned lds_off, PpKarg karg, int s_
     __syncthreads();                                           // the step's barrier (see pp_role_helper)
 }
 
+#if !PP_SG16
 __device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
     pp_args_ptr q = pp_args(karg);
     double* lds = pp_lds_base(lds_off);
@@ -818,6 +852,10 @@ __device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
     PP_ROLE_EXIT(lds, q);
 }
 
+#else
+#include "potrf_persist_sg.h"
+#endif
+
 __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, const unsigned lds_off) {
     const PotrfArgs& a = q.a;
     const int t = threadIdx.x, lane = t & 63;
@@ -826,7 +864,7 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
     double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
     int* ints = (int*)(lds + PP_INTS);
     const long long n = a.n, lda = a.lda;
-    if (t < 24) ints[t] = 0;
+    if (t < 64) ints[t] = 0;
     double rhs_r = 0.0;     // receiving wavefront: running right-hand side of the forward solve for matrix row r * 64 + lane
     if (w == 0) {
         // block (0, 0), coalesced (lane = column), transposed to lane = row through Ls (n > 64: the block is full)
@@ -836,7 +874,7 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
         for (int k = 0; k < PB; ++k) tt[k] = src[(long long)k * lda];
 #pragma unroll
         for (int k = 0; k < PB; ++k) Ls[k][lane] = tt[k];
-    } else if (w == 3) {
+    } else if (w == PP_W_RECV) {
         const long long row = (long long)r * PB + lane;
         rhs_r = (a.rhs && row < n) ? a.rhs[row] : 0.0;
     }
@@ -861,11 +899,23 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
     // factorisation loses ~500 cycles whenever a k-step's 32 MFMAs meet one of its column groups.  Other pairings were
     // measured (factorisation + receiver, solver + helper, matrix wavefronts with each other; receiver and helper swapped;
     // ...): the factorisation gets faster, the helper or the last k-step slower, the step stays within 2 %.
+#if PP_SG16 && defined(PP_EXP_PAIR_LIGHT)
+    // (measured, round 5: the two row-per-lane wavefronts each paired with a wavefront that hardly touches the double-precision
+    // pipe -- receiver, stager -- and the four matrix wavefronts in pairs on the other two SIMDs: wavefronts 0 F | 1 S | 2 M0 |
+    // 3 M2 | 4 receiver | 5 stager | 6 M1 | 7 M3.  The factorisation finishes 1 us earlier, the k-steps 3 us later: 0.378
+    // against 0.337 ms at n = 1152 -- MFMA streams that share a SIMD halve each other)
+    if (w == 0) pp_role_factor(lo, karg);
+    else if (w == 1) pp_role_solve(lo, karg);
+    else if (w == PP_W_RECV) pp_role_recv(lo, karg, rhs_r);
+    else if (w == 5) pp_role_helper(lo, karg);
+    else pp_role_matrix(lo, karg);
+#else
     if (w == 0) pp_role_factor(lo, karg);
     else if (w == 1) pp_role_solve(lo, karg);
     else if (w == 3) pp_role_recv(lo, karg, rhs_r);
     else if (w >= 4) pp_role_matrix(lo, karg);
     else pp_role_helper(lo, karg);
+#endif
 }
 
 // ---------------------------------------------------------------------------

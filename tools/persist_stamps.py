@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "approxposterior_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "tmp", "libapgp_stamps.so")
+SG16 = True      # (round 5's step: potrf_persist_sg.h; build with -DPP_SG16=0 and set False for round 4's)
 
 
 def build(extra=(), out=OUT):
@@ -58,13 +59,38 @@ if __name__ == "__main__":
         nb = (n + 63) // 64
         print("n = %d (%d block columns), fallbacks %d; microseconds after the step's start (last row workgroup)" % (n, nb, lib.apgp_potrf_fallbacks()))
         fs = np.zeros(64 * 8, dtype=np.uint64)
-        if hasattr(lib, "apgp_debug_read_fstamps"):
+        if hasattr(lib, "apgp_debug_read_fstamps") and SG16:
+            lib.apgp_debug_read_fstamps.argtypes = [ctypes.c_void_p]
+            lib.apgp_debug_read_gstamps.argtypes = [ctypes.c_void_p]
+            gs = np.zeros(64 * 8, dtype=np.uint64)
+            assert lib.apgp_debug_read_fstamps(fs.ctypes.data) == 0 and lib.apgp_debug_read_gstamps(gs.ctypes.data) == 0
+            fs = fs.reshape(64, 8).astype(np.int64); gs = gs.reshape(64, 8).astype(np.int64)
+            print("super-group step, us after the step's start: entry | SG0 done | boundary 1 in | SG1 done | boundary 2 in | SG2 done | boundary 3 in | done")
+            for sidx in range(2, min(nb - 1, 9)):
+                print("  step %2d  factor: %s" % (sidx, " ".join("%6.2f" % ((fs[sidx, i] - st[sidx, 0]) / 100.0) for i in range(8))))
+                print("           solve : %s" % " ".join("%6.2f" % ((gs[sidx, i] - st[sidx, 0]) / 100.0) for i in range(8)))
+        elif hasattr(lib, "apgp_debug_read_fstamps"):
             lib.apgp_debug_read_fstamps.argtypes = [ctypes.c_void_p]
             assert lib.apgp_debug_read_fstamps(fs.ctypes.data) == 0
             fs = fs.reshape(64, 8).astype(np.int64)
             print("factorising wavefront, us after ITS entry: at the helper wait | columns back | group 4 / 12 / 15 published;  entry after step start")
             for sidx in range(4, min(nb - 1, 10)):
                 print("  step %2d: %s ; %6.2f" % (sidx, " ".join("%6.2f" % ((fs[sidx, i] - fs[sidx, 0]) / 100.0) for i in (1, 2, 3, 4, 5)), (fs[sidx, 0] - st[sidx, 0]) / 100.0))
+        if SG16 and hasattr(lib, "apgp_debug_read_estamps"):
+            es = np.zeros(4 * 32 * 3, dtype=np.uint64)
+            lib.apgp_debug_read_estamps.argtypes = [ctypes.c_void_p]
+            assert lib.apgp_debug_read_estamps(es.ctypes.data) == 0
+            es = es.reshape(4, 32, 3).astype(np.int64)
+            print("matrix wavefronts of the last row workgroup at step 5: event (D = diagonal catch-up, T = tile catch-up, k = k-step) start-end, us after the step's start")
+            for mwi in range(4):
+                row = []
+                for e in range(32):
+                    if es[mwi, e, 0] == 0:
+                        break
+                    kind = int(es[mwi, e, 2])
+                    name = "D%d" % (kind // 1000) if kind >= 1000 else ("T%d" % (kind // 100) if kind >= 100 else "k%d" % (kind - 1))
+                    row.append("%s %.2f-%.2f" % (name, (es[mwi, e, 0] - st[5, 0]) / 100.0, (es[mwi, e, 1] - st[5, 0]) / 100.0))
+                print("  w%d: %s" % (4 + mwi, " | ".join(row)))
         print("the step's producer workgroup (s + 1), us after the last workgroup's step start: its step start | its solve done | last group's granules stored")
         for sidx in range(4, min(nb - 2, 10)):
             print("  step %2d: %s" % (sidx, " ".join("%6.2f" % ((st[sidx, i] - st[sidx, 0]) / 100.0) for i in (20, 21, 22))))
@@ -76,7 +102,7 @@ if __name__ == "__main__":
         for sidx in range(4, min(nb - 2, 10)):
             print("  step %2d: %s | %6.2f" % (sidx, " ".join("%6.2f" % ((ws[sidx, i] - st[sidx, 0]) / 100.0) for i in range(8)), (st[sidx + 1, 0] - st[sidx, 0]) / 100.0))
         gs = np.zeros(64 * 8, dtype=np.uint64)
-        if hasattr(lib, "apgp_debug_read_gstamps"):
+        if hasattr(lib, "apgp_debug_read_gstamps") and not SG16:
             lib.apgp_debug_read_gstamps.argtypes = [ctypes.c_void_p]
             assert lib.apgp_debug_read_gstamps(gs.ctypes.data) == 0
             gs = gs.reshape(64, 8).astype(np.int64)
