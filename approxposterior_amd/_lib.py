@@ -79,6 +79,7 @@ SIGNATURES = {
     "apgp_predict_mean_host": (ctypes.c_int, [_P, _I64, _P, _I64, _KP, _F64, _P, _P, _P]),
     "apgp_ensemble_sample": (ctypes.c_int, [_P, _I64, _KP, _F64, ctypes.POINTER(_F64), ctypes.POINTER(_F64),
                                             _I32, _I32, _I64, _F64, ctypes.c_uint64, _P, _P, _P, _P, _P, _P]),
+    "apgp_ensemble_mode": (ctypes.c_int, [ctypes.c_int]),
     "apgp_box_candidates": (ctypes.c_int, [_P, _I64, _I32, ctypes.POINTER(_F64), ctypes.POINTER(_F64), ctypes.c_uint64,
                                            _I64, _P]),
     "apgp_release_scratch": (ctypes.c_int, [_P]),

@@ -14,6 +14,8 @@
 // Only a box prior can be evaluated on the device (arbitrary Python priors
 // cannot): the caller asserts lnprior == const inside [lo, hi], -inf outside.
 #include "apgp_common.h"
+#include "scratch.h"
+#include <atomic>
 #include <mutex>
 
 struct EnsArgs {
@@ -245,6 +247,232 @@ __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Round 5: ONE ensemble over SEVERAL workgroups.  The single-workgroup kernel above keeps 255 of 256 compute units idle for
+// a lone ensemble (BASELINE config 5: 64 walkers x 2e4 iterations at N = 1152 took 1.4 s, 35 us per half-step, all of it the
+// 32 GP means of the half-step on one CU).  Here G workgroups (256 threads = 4 wavefronts each, one per SIMD) share an
+// ensemble: every workgroup keeps the whole sampler state and draws the same proposals (the RNG is counter-based: pure
+// functions of (seed, iteration, walker)), evaluates the GP mean of ITS proposals (g, g + G, ...; rows split over its four
+// wavefronts, partial sums added in a fixed order), publishes them as data-tagged granules ({low word, tag, high word, tag},
+// tag = half-step number + 1, write-through stores, two buffers by half-step parity) and reads everybody else's; the accept
+// step then runs identically in every workgroup.  One exchange of H doubles per half-step, no flag, no fence.
+// All G x E workgroups must be resident at once (the host limits G x E to the device's CUs); every poll is bounded: on
+// timeout the workgroup writes NaN log-probabilities and leaves -- the host wrapper re-runs on the single-workgroup kernel.
+// ---------------------------------------------------------------------------
+struct EnsMwArgs {
+    EnsArgs e;
+    unsigned long long* xchg;      // [E][2][ENS_MAXW / 2] granules of 2 x 8 bytes
+    unsigned long long timeout;    // 100 MHz ticks
+    int G;
+};
+typedef unsigned int ens_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DPAD, bool XLDS>
+__global__ __launch_bounds__(256) void ensemble_mw_kernel(EnsMwArgs q) {
+    const EnsArgs& a = q.e;
+    constexpr int XS = DPAD + 2;
+    extern __shared__ __attribute__((aligned(16))) double xsl[];
+    __shared__ double etab[APGP_EXP_TAB_N];
+    __shared__ double cs[ENS_MAXW][DPAD];
+    __shared__ double lp[ENS_MAXW];
+    __shared__ double qs[ENS_MAXW / 2][DPAD];
+    __shared__ double lpq[ENS_MAXW / 2];
+    __shared__ double fac[ENS_MAXW / 2];
+    __shared__ double uacc[ENS_MAXW / 2];
+    __shared__ double part[4][2];              // partial sums of the (at most two) proposals in flight, per wavefront
+    __shared__ int qok[ENS_MAXW / 2];
+    __shared__ int nacc[ENS_MAXW];
+    __shared__ int gaveup;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int W = a.nwalkers, H = W / 2, D = a.ndim, G = q.G;
+    const long long ens = blockIdx.x / G;
+    const int g = (int)(blockIdx.x % G);
+    apgp_exp_tab_load(etab);
+    double* gc = a.coords + ens * W * D;
+    for (int e = t; e < W * DPAD; e += 256) {
+        const int w = e / DPAD, d = e % DPAD;
+        cs[w][d] = d < D ? gc[w * D + d] * a.sc[d] : 0.0;
+    }
+    if (t < W) nacc[t] = 0;
+    if (t == 0) gaveup = 0;
+    if (XLDS) {
+        for (long long e = t; e < a.n * XS; e += 256) xsl[e] = a.xs[e];
+    }
+    __syncthreads();
+    const int nn = (int)a.n;
+    // GP means of one or two points by the WHOLE workgroup: row k goes to thread k mod 256 (wavefront (k / 64) mod 4), each
+    // wavefront butterflies its lanes, the four partial sums are added 0 + 1 + 2 + 3
+    auto gp_mean_wg = [&](const double* p0, const double* p1, const bool two, double& m0, double& m1) {
+        double t0[DPAD], t1[DPAD];
+#pragma unroll
+        for (int d = 0; d < DPAD; ++d) { t0[d] = p0[d]; t1[d] = two ? p1[d] : p0[d]; }
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int k = t; k < nn; k += 256) {
+            const double* xr = (XLDS ? (const double*)xsl : a.xs) + k * XS;
+            double xv[DPAD];
+#pragma unroll
+            for (int d = 0; d < DPAD; ++d) xv[d] = xr[d];
+            const double al = xr[DPAD];
+            double s0 = 0.0, s03 = 0.0, s1 = 0.0, s13 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DPAD; d += 2) {
+                const double a0 = t0[d] - xv[d], a1 = t0[d + 1] - xv[d + 1];
+                const double b0 = t1[d] - xv[d], b1 = t1[d + 1] - xv[d + 1];
+                s0 = fma(a0, a0, s0); s03 = fma(a1, a1, s03);
+                s1 = fma(b0, b0, s1); s13 = fma(b1, b1, s13);
+            }
+            double kv0 = a.amp * apgp_exp(-(s0 + s03), etab);
+            double kv1 = a.amp * apgp_exp(-(s1 + s13), etab);
+            if (a.lin_coef != 0.0) {
+                double ls;
+                APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, t0[d_] * xv[d_] * a.lw[d_]);
+                kv0 = fma(a.lin_coef, ls, kv0);
+                APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, t1[d_] * xv[d_] * a.lw[d_]);
+                kv1 = fma(a.lin_coef, ls, kv1);
+            }
+            acc0 = fma(kv0, al, acc0);
+            acc1 = fma(kv1, al, acc1);
+        }
+        for (int o = 32; o > 0; o >>= 1) { acc0 += __shfl_xor(acc0, o); acc1 += __shfl_xor(acc1, o); }
+        if (lane == 0) { part[wv][0] = acc0; part[wv][1] = acc1; }
+        __syncthreads();
+        m0 = ((part[0][0] + part[1][0]) + part[2][0]) + part[3][0] + a.mean;
+        m1 = ((part[0][1] + part[1][1]) + part[2][1]) + part[3][1] + a.mean;
+        __syncthreads();
+    };
+    // start-up: every workgroup evaluates every walker (once per launch; keeps the state replicated without an exchange)
+    for (int w = 0; w < W; w += 2) {
+        double m0, m1;
+        gp_mean_wg(cs[w], cs[w + 1 < W ? w + 1 : w], w + 1 < W, m0, m1);
+        if (t == 0) {
+            for (int d = 0; d < D; ++d) {
+                if (!(cs[w][d] >= a.lo[d] && cs[w][d] <= a.hi[d])) m0 = -INFINITY;
+                if (w + 1 < W && !(cs[w + 1][d] >= a.lo[d] && cs[w + 1][d] <= a.hi[d])) m1 = -INFINITY;
+            }
+            lp[w] = m0;
+            if (w + 1 < W) lp[w + 1] = m1;
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(q.xchg + ens * 2 * (ENS_MAXW / 2) * 2), 0,
+                                                                          2 * (ENS_MAXW / 2) * 16, 0x00020000);
+    const unsigned int k0 = (unsigned int)a.seed, k1 = (unsigned int)(a.seed >> 32) ^ (unsigned int)(ens * 0x9E3779B9u);
+    bool dead = false;
+    for (long long it = 0; it < a.iterations && !dead; ++it) {
+        unsigned int cr[4] = {(unsigned int)it, (unsigned int)(it >> 32), 0xFFFFFFFFu, 0x5u};
+        philox4x32(cr, k0, k1);
+        const int rot = (int)(cr[0] % (unsigned int)W);
+        for (int split = 0; split < 2; ++split) {
+            auto s_idx = [&](int i) { int v = i + split * H + rot; return v >= W ? v - W : v; };
+            auto c_idx = [&](int i) { int v = i + (1 - split) * H + rot; return v >= W ? v - W : v; };
+            if (t < H) {
+                unsigned int c1[4] = {(unsigned int)it, (unsigned int)(it >> 32), (unsigned int)(split * ENS_MAXW + t), 0x1u};
+                philox4x32(c1, k0, k1);
+                const double u = u01(c1[0], c1[1]);
+                const double z = ((a.a_stretch - 1.0) * u + 1.0);
+                const double zz = z * z / a.a_stretch;
+                const int j = c_idx((int)(c1[2] % (unsigned int)H));
+                const int sw = s_idx(t);
+                bool ok = true;
+#pragma unroll
+                for (int d = 0; d < DPAD; ++d) {
+                    const double qv = cs[j][d] - (cs[j][d] - cs[sw][d]) * zz;
+                    qs[t][d] = qv;
+                    if (d < D && !(qv >= a.lo[d] && qv <= a.hi[d])) ok = false;
+                }
+                qok[t] = ok ? 1 : 0;
+                fac[t] = (D - 1.0) * log(zz);
+                unsigned int c2[4] = {(unsigned int)it, (unsigned int)(it >> 32), (unsigned int)(split * ENS_MAXW + t), 0x2u};
+                philox4x32(c2, k0, k1);
+                uacc[t] = u01(c2[0], c2[1]);
+            }
+            __syncthreads();
+            // this workgroup's proposals g, g + G, ... (two per pass over the training stream), published as they are done
+            const unsigned step = (unsigned)(2 * it + split);
+            const unsigned tag = step + 1u;
+            const unsigned par = step & 1u;
+            for (int i = g; i < H; i += 2 * G) {
+                const int i1 = i + G;
+                const bool ok0 = qok[i] != 0, ok1 = i1 < H && qok[i1] != 0;
+                double m0 = -INFINITY, m1 = -INFINITY;
+                if (ok0 || ok1) {
+                    double r0, r1;
+                    gp_mean_wg(qs[ok0 ? i : i1], qs[ok1 ? i1 : i], ok0 && ok1, r0, r1);
+                    if (ok0) m0 = r0;
+                    if (ok1) m1 = ok0 ? r1 : r0;
+                }
+                if (t < 2 && (t == 0 || i1 < H)) {
+                    const double mv = t == 0 ? m0 : m1;
+                    const int slot = t == 0 ? i : i1;
+                    const ens_u32x4 gr = {(unsigned)__double2loint(mv), tag, (unsigned)__double2hiint(mv), tag};
+                    __builtin_amdgcn_raw_buffer_store_b128(gr, rs_x, (unsigned)((par * (ENS_MAXW / 2) + slot) * 16), 0, 16);
+                    asm volatile("s_nop 1" : : "v"(gr));        // (16-byte store: its data registers stay live -- see PP_STORE16)
+                }
+            }
+            // everybody's values (one granule per thread, polled until its tag is this half-step's)
+            if (t < H) {
+                ens_u32x4 gr;
+                unsigned long long t0 = 0;
+                unsigned itn = 0;
+                for (;;) {
+                    gr = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)((par * (ENS_MAXW / 2) + t) * 16), 0, 16);
+                    if (gr.y == tag && gr.w == tag) break;
+                    if ((++itn & 63u) == 0) {
+                        if (*(volatile int*)&gaveup) break;
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > q.timeout) { gaveup = 1; break; }
+                    }
+                }
+                lpq[t] = __hiloint2double((int)gr.z, (int)gr.x);
+            }
+            __syncthreads();
+            if (gaveup) { dead = true; break; }
+            if (t < H) {
+                const int sw = s_idx(t);
+                const double diff = fac[t] + lpq[t] - lp[sw];
+                if (qok[t] && lpq[t] == lpq[t] && log(uacc[t]) < diff) {
+#pragma unroll
+                    for (int d = 0; d < DPAD; ++d) cs[sw][d] = qs[t][d];
+                    lp[sw] = lpq[t];
+                    nacc[sw] += 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (dead) break;
+        // the chain: every workgroup writes its share of the walkers
+        const long long E_ = gridDim.x / G;
+        if (a.chain) {
+            double* out = a.chain + ((it * E_ + ens) * W) * D;
+            for (int e = g * 256 + t; e < W * D; e += G * 256) {
+                const int w = e / D, d = e % D;
+                out[e] = cs[w][d] / a.sc[d];
+            }
+        }
+        if (a.logp_chain && g == 0 && t < W) a.logp_chain[(it * E_ + ens) * W + t] = lp[t];
+    }
+    if (g == 0 || dead) {
+        for (int e = t; e < W * D; e += 256) {
+            const int w = e / D, d = e % D;
+            gc[e] = cs[w][d] / a.sc[d];
+        }
+        if (t < W) {
+            a.logp[ens * W + t] = dead ? __longlong_as_double(0x7ff8000000000000ll) : lp[t];
+            a.naccept[ens * W + t] = nacc[t];
+        }
+    }
+}
+
+// 0 = several workgroups per ensemble where that helps and fits (default) | 1 = the single-workgroup kernel only.
+// A test / profiling switch, not read from the environment.  Returns the previous value.
+static std::atomic<int> g_ens_mode{0};
+extern "C" int apgp_ensemble_mode(int mode) {
+    if (mode < 0) return g_ens_mode.load();
+    return g_ens_mode.exchange(mode ? 1 : 0);
+}
+
 extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kernel_t* kern, double mean,
                                     const double* lo, const double* hi, int32_t nwalkers,
                                     int32_t nensembles, int64_t iterations, double a_stretch,
@@ -274,6 +502,59 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
     dim3 grid((unsigned)nensembles), block(1024);
     const size_t xbytes = (size_t)a.n * (kc.dpad + 2) * sizeof(double);
     const bool xlds = xbytes <= 96 * 1024;
+    {
+        // several workgroups per ensemble (ensemble_mw_kernel) when the ensembles alone leave compute units idle: G = the
+        // proposals of a half-step, at most (CUs / ensembles), at least 2; every workgroup must be resident (one per CU
+        // with the training stream in LDS)
+        int devn = 0, cus = 0;
+        if (g_ens_mode.load() == 0 && hipGetDevice(&devn) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devn) == hipSuccess && devn >= 0 && devn < 64) {
+            int G = nwalkers / 2;
+            if ((long long)G * nensembles > cus) G = cus / nensembles;
+            if (G >= 2 && iterations > 0) {
+                std::lock_guard<std::mutex> lock(apgp_stream_lock(s));
+                const size_t words = (size_t)nensembles * 2 * (ENS_MAXW / 2) * 2;
+                unsigned long long* xchg = (unsigned long long*)apgp_stream_scratch(4, s, words);
+                if (!xchg || hipMemsetAsync(xchg, 0, words * 8, s) != hipSuccess) {
+                    apgp_set_error("apgp_ensemble_sample: exchange buffer");
+                    return -2;
+                }
+                EnsMwArgs q;
+                q.e = a; q.xchg = xchg; q.timeout = 5000000ull; q.G = G;      // 50 ms of the 100 MHz clock
+                dim3 gridm((unsigned)(nensembles * G)), blockm(256);
+                static std::mutex attr_mu_m;
+                static bool attr_done_m[4][64] = {{false}};
+#define APGP_LAUNCH_ENS_MW(DP, SLOT)                                                                   \
+    do {                                                                                               \
+        if (xlds) {                                                                                    \
+            {                                                                                          \
+                std::lock_guard<std::mutex> lk(attr_mu_m);                                             \
+                if (!attr_done_m[SLOT][devn]) {                                                        \
+                    if (hipFuncSetAttribute((const void*)ensemble_mw_kernel<DP, true>,                 \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) { \
+                        apgp_set_error("apgp_ensemble_sample: hipFuncSetAttribute(96 KiB of LDS) failed"); \
+                        return -2;                                                                     \
+                    }                                                                                  \
+                    attr_done_m[SLOT][devn] = true;                                                    \
+                }                                                                                      \
+            }                                                                                          \
+            hipLaunchKernelGGL((ensemble_mw_kernel<DP, true>), gridm, blockm, xbytes, s, q);           \
+        } else {                                                                                       \
+            hipLaunchKernelGGL((ensemble_mw_kernel<DP, false>), gridm, blockm, 0, s, q);               \
+        }                                                                                              \
+    } while (0)
+                switch (kc.dpad) {
+                    case 2: APGP_LAUNCH_ENS_MW(2, 0); break;
+                    case 4: APGP_LAUNCH_ENS_MW(4, 1); break;
+                    case 8: APGP_LAUNCH_ENS_MW(8, 2); break;
+                    default: APGP_LAUNCH_ENS_MW(16, 3); break;
+                }
+#undef APGP_LAUNCH_ENS_MW
+                APGP_CHECK_LAUNCH();
+                return 0;
+            }
+        }
+    }
     // the LDS-resident form needs > 64 KiB of dynamic LDS: per-device attribute, set and CHECKED once per
     // device and instantiation
     int dev = 0;

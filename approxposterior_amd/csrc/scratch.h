@@ -2,7 +2,7 @@
 // hipFreeAsync): calls on one stream are serialised, so they can share a buffer; calls on different
 // streams cannot.  Slots: 0 = Cholesky (factored diagonal blocks), 1 = blocked triangular solve
 // (working right-hand side), 2 = persistent Cholesky (flags, granule streams), 3 = persistent triangular solve (ticket
-// counter, error word, granules).  One definition for the whole
+// counter, error word, granules), 4 = multi-workgroup ensemble sampler (log-probability granules).  One definition for the whole
 // library (inline functions, static locals).
 //   * The device is the STREAM's (hipStreamGetDevice), not the caller's current device.
 //   * Entries live until apgp_release_scratch(stream) (include/apgp.h) or process exit: call it before

@@ -1125,13 +1125,25 @@ class GP(object):
             nacc = torch.empty((E, W), dtype=torch.int64, device=dev)
             chain = torch.empty((iterations, E, W, D), dtype=torch.float64, device=dev) if store else None
             lchain = torch.empty((iterations, E, W), dtype=torch.float64, device=dev) if store else None
-            _lib.check(lib.apgp_ensemble_sample(
-                self._xs.data_ptr(), n, ctypes.byref(ks), float(self.mean.value), lo, hi, W, E,
-                iterations, float(a), int(seed) & 0xFFFFFFFFFFFFFFFF, coords.data_ptr(), logp.data_ptr(),
-                chain.data_ptr() if store else None, lchain.data_ptr() if store else None,
-                nacc.data_ptr(), st), "apgp_ensemble_sample")
+            def launch():
+                coords.copy_(torch.from_numpy(p0))
+                _lib.check(lib.apgp_ensemble_sample(
+                    self._xs.data_ptr(), n, ctypes.byref(ks), float(self.mean.value), lo, hi, W, E,
+                    iterations, float(a), int(seed) & 0xFFFFFFFFFFFFFFFF, coords.data_ptr(), logp.data_ptr(),
+                    chain.data_ptr() if store else None, lchain.data_ptr() if store else None,
+                    nacc.data_ptr(), st), "apgp_ensemble_sample")
+                return logp.cpu().numpy().reshape(E * W)
+            final = launch()
+            if np.any(np.isnan(final)):
+                # the multi-workgroup launch could not get its workgroups resident (another stream or process holds
+                # compute units): once more on the single-workgroup kernel -- slower, same posterior
+                prev = lib.apgp_ensemble_mode(1)
+                try:
+                    final = launch()
+                finally:
+                    lib.apgp_ensemble_mode(prev)
             out = {"coords": coords.cpu().numpy().reshape(E * W, D),
-                   "final_log_prob": logp.cpu().numpy().reshape(E * W),
+                   "final_log_prob": final,
                    "naccept": nacc.cpu().numpy().reshape(E * W),
                    "chain": chain.cpu().numpy().reshape(iterations, E * W, D) if store else None,
                    "log_prob": lchain.cpu().numpy().reshape(iterations, E * W) if store else None}

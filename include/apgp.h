@@ -349,6 +349,14 @@ int apgp_predict_mean_host(const double* T_host, int64_t m, const double* xs, in
  * initial state, out = final state; logp / naccept: nensembles x nwalkers;
  * chain (iterations x nensembles x nwalkers x ndim) and logp_chain may be NULL.
  * nwalkers even, >= 2 ndim, <= 256.  RNG: Philox4x32-10 keyed by seed.         */
+/* Round 5: when the ensembles alone leave compute units idle (nensembles x nwalkers / 2 <= CUs, or fewer workgroups per
+ * ensemble when not), ONE ensemble runs on several workgroups: each evaluates its share of a half-step's proposals
+ * and the log-probabilities are exchanged as data-tagged granules in memory (stream-ordered scratch, slot 4 of
+ * csrc/scratch.h); same RNG streams and proposals as the single-workgroup kernel, GP means summed in another order
+ * (chains agree to rounding, not bit for bit).  All workgroups must be resident at once; if they are not within
+ * 50 ms the launch writes NaN into logp[] -- the caller re-runs with apgp_ensemble_mode(1) (the Python wrapper does).
+ * apgp_ensemble_mode: 0 = default, 1 = single-workgroup kernel only; < 0 queries; returns the previous value.   */
+int apgp_ensemble_mode(int mode);
 int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kernel_t* kern /*host*/, double mean,
                          const double* lo /*host*/, const double* hi /*host*/,
                          int32_t nwalkers, int32_t nensembles, int64_t iterations,

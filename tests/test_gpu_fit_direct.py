@@ -268,3 +268,53 @@ def test_nll_memo_answers_exact_repeats_only():
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and res[0][2] == res[1][2]
     assert res[0][3] < res[1][3]
     print("Powell, 3 iterations at N = 512: %d objective calls, %d device evaluations with the memo" % (res[0][2], res[0][3]))
+
+
+@pytest.mark.parametrize("n,D,W,E", [(1152, 8, 64, 1), (300, 2, 8, 3), (700, 5, 40, 8), (2500, 8, 64, 2)])
+def test_multi_workgroup_sampler_against_oracle_and_single_workgroup(n, D, W, E):
+    """Round 5: one ensemble over several workgroups (csrc/ensemble.hip, ensemble_mw_kernel; BASELINE config 5's MCMC --
+    approx.py:839-856 -- was one workgroup on one of 256 compute units).  (1) every stored log-probability is the oracle's GP
+    mean at the stored coordinates (|d| <= 1e-9 sum|alpha|), (2) the chain equals the single-workgroup kernel's -- same
+    counter-based RNG streams and proposals; the GP means are summed in another order, so to rounding (1e-9), not bit for
+    bit -- including accepted-move counts, (3) the training stream outside LDS (n = 2500: 200 KB) takes the same path."""
+    import torch
+    from approxposterior_amd import _lib
+    go, agp = _mods()
+    lib = _lib.load()
+    X, y = _case(n, D, n + W)
+    g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(D, 8.0), ndim=D), fit_mean=True, mean=float(np.median(y)), white_noise=-12,
+               fit_white_noise=False)
+    g.compute(X)
+    gpo = go.GP(kernel=go.ExpSquaredKernel(np.full(D, 8.0), ndim=D), fit_mean=True, mean=float(np.median(y)), white_noise=-12,
+                fit_white_noise=False)
+    gpo.compute(X)
+    p0 = np.random.RandomState(2).uniform(-5, 5, size=(E, W, D))
+    p0[0, 0] = 7.0                                   # a walker that starts outside the prior: -inf until it moves
+    bounds = [(-5, 5)] * D
+    iters = 400
+    assert lib.apgp_ensemble_mode(-1) == 0
+    t0 = time.perf_counter()
+    multi = g.sample_ensemble(y, p0, iters, bounds, seed=99)
+    t_multi = time.perf_counter() - t0
+    prev = lib.apgp_ensemble_mode(1)
+    try:
+        t0 = time.perf_counter()
+        single = g.sample_ensemble(y, p0, iters, bounds, seed=99)
+        t_single = time.perf_counter() - t0
+    finally:
+        lib.apgp_ensemble_mode(prev)
+    print("n = %d, %d ensemble(s) x %d walkers x %d iterations: %.1f ms on several workgroups, %.1f ms on one"
+          % (n, E, W, iters, t_multi * 1e3, t_single * 1e3))
+    asum = np.abs(gpo._compute_alpha(y, False)).sum()
+    for it in (0, iters // 2, iters - 1):
+        want = gpo.predict(y, multi["chain"][it], return_cov=False)
+        lp = multi["log_prob"][it]
+        inside = np.all(np.abs(multi["chain"][it]) <= 5, axis=1)
+        assert np.all(np.isneginf(lp[~inside])) and np.abs(lp[inside] - want[inside]).max() <= 1e-9 * asum
+    assert np.allclose(multi["chain"], single["chain"], rtol=1e-9, atol=1e-9)
+    fin = np.isfinite(single["log_prob"])
+    assert np.array_equal(fin, np.isfinite(multi["log_prob"]))
+    assert np.allclose(multi["log_prob"][fin], single["log_prob"][fin], rtol=1e-9, atol=1e-9 * asum)
+    assert np.array_equal(multi["naccept"], single["naccept"])
+    assert np.allclose(multi["coords"], single["coords"], rtol=1e-9, atol=1e-9)
+    assert 0.05 < multi["naccept"].sum() / (iters * E * W) < 0.95
