@@ -412,21 +412,32 @@ __device__ __forceinline__ void pp_load_K(PpFragK& f, const double* Ach, const d
         for (int i = 0; i < 2; ++i) f.bfa[i] = Bch[(wr + 16 * i + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
     }
 }
-template <bool TWO>
+// DIAG: which 16 x 16 blocks of the quadrant's share of the NEXT DIAGONAL block are computed -- only its lower triangle is
+// ever read: 0 = none (the quadrant above the diagonal), 1 = blocks (0,0), (1,0), (1,1) (a quadrant on the diagonal),
+// 2 = all four (the quadrant below it)
+// (TILE: the same selection for the first product -- 2 for a tile; the step's producer workgroup multiplies its own rows with
+// themselves there, which IS its diagonal product)
+template <bool TWO, int DIAG, int TILE = 2>
 __device__ __forceinline__ void pp_mfma_K(const PpFragK& f, double (&acc)[2][2][4], double (&acc2)[2][2][4]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.af[i], f.bf[j][r], acc[i][j][r], 0, 0, 0);
-    if constexpr (TWO) {
+    if constexpr (TILE > 0) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                if (TILE == 1 && i == 0 && j == 1) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.af[i], f.bf[j][r], acc[i][j][r], 0, 0, 0);
+            }
+    }
+    if constexpr (TWO && DIAG > 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (DIAG == 1 && i == 0 && j == 1) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc2[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.bfa[i], f.bf[j][r], acc2[i][j][r], 0, 0, 0);
+            }
     }
 }
 
@@ -445,7 +456,9 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
 #ifdef PP_EXP_PAIR_LIGHT
     const int mw = ((wv & 1) << 1) | (wv >> 2);               // wavefronts 2, 6, 3, 7 -> 0, 1, 2, 3 (pp_row_role: pairs on two SIMDs)
 #else
-    const int mw = wv - 4;
+    // wavefront 4 shares its SIMD with the factorising wavefront: it takes the quadrant ABOVE the diagonal (wr = 0, wc = 32),
+    // whose share of the next diagonal block is never read and is skipped -- half the MFMAs of the others per k-step
+    const int mw = (wv - 4) ^ 1;
 #endif
     const int wr = (mw >> 1) * 32, wc = (mw & 1) * 32;         // this wavefront's 32 x 32 quadrant of both products
     bool dead = false;
@@ -535,18 +548,24 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
         const int nk = min(min(xprog, bprog), PB / CB);
         if (g < nk) {
             PP_ESTAMP_BEGIN(g + 1);
+            // (up to two k-steps per look, operand reads together.  A rolled, software-pipelined batch of up to four was
+            // measured: the fragment copy between iterations made the loop spill -- 0.49 ms at n = 1152 against 0.336)
             const bool two = g + 1 < nk;
             PpFragK f0, f1;
             if (producer) {
                 pp_load_K<false>(f0, p.As_cur + (g >> 2) * PP_CHUNK, p.As_cur + (g >> 2) * PP_CHUNK, g & 3, lane, wr, wc, bcol);
                 if (two) pp_load_K<false>(f1, p.As_cur + ((g + 1) >> 2) * PP_CHUNK, p.As_cur + ((g + 1) >> 2) * PP_CHUNK, (g + 1) & 3, lane, wr, wc, bcol);
-                pp_mfma_K<false>(f0, v, v2);
-                if (two) pp_mfma_K<false>(f1, v, v2);
+                // (its own rows with themselves: the quadrant above the diagonal owes nothing, the two on it three blocks of four)
+                if (wr < wc) { }
+                else if (wr == wc) { pp_mfma_K<false, 0, 1>(f0, v, v2); if (two) pp_mfma_K<false, 0, 1>(f1, v, v2); }
+                else { pp_mfma_K<false, 0, 2>(f0, v, v2); if (two) pp_mfma_K<false, 0, 2>(f1, v, v2); }
             } else {
                 pp_load_K<true>(f0, p.As_cur + (g >> 2) * PP_CHUNK, Bs + (g >> 2) * PP_CHUNK, g & 3, lane, wr, wc, bcol);
                 if (two) pp_load_K<true>(f1, p.As_cur + ((g + 1) >> 2) * PP_CHUNK, Bs + ((g + 1) >> 2) * PP_CHUNK, (g + 1) & 3, lane, wr, wc, bcol);
-                pp_mfma_K<true>(f0, v, v2);
-                if (two) pp_mfma_K<true>(f1, v, v2);
+                // (the quadrant above the diagonal owes the next diagonal block nothing, the two on it three blocks of four)
+                if (wr < wc) { pp_mfma_K<true, 0>(f0, v, v2); if (two) pp_mfma_K<true, 0>(f1, v, v2); }
+                else if (wr == wc) { pp_mfma_K<true, 1>(f0, v, v2); if (two) pp_mfma_K<true, 1>(f1, v, v2); }
+                else { pp_mfma_K<true, 2>(f0, v, v2); if (two) pp_mfma_K<true, 2>(f1, v, v2); }
             }
             g += two ? 2 : 1;
             PP_ESTAMP_END();
