@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libapgp.so")
 ABI_VERSION = 7
-MAX_DIM = 16
+MAX_DIM = 32
 
 UTIL_AGP, UTIL_BAPE, UTIL_JONES, UTIL_NONE = 0, 1, 2, 3
 

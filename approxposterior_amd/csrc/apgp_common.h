@@ -29,7 +29,7 @@ void apgp_set_error(const char* fmt, ...);
 
 // Feature dimension padded to a template-friendly width (zero scale => zero
 // contribution of the padded coordinates).
-static inline int apgp_dpad(int d) { return d <= 2 ? 2 : d <= 4 ? 4 : d <= 8 ? 8 : 16; }
+static inline int apgp_dpad(int d) { return d <= 2 ? 2 : d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : 32; }
 // doubles per row of the packed training stream: scaled x (Dpad) | alpha | 0
 static inline int apgp_xs_stride(int d) { return apgp_dpad(d) + 2; }
 

@@ -501,7 +501,8 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)nensembles), block(1024);
     const size_t xbytes = (size_t)a.n * (kc.dpad + 2) * sizeof(double);
-    const bool xlds = xbytes <= 96 * 1024;
+    // (D > 16: the sampler state alone takes 100 KB of LDS -- the training stream stays in L2)
+    const bool xlds = xbytes <= 96 * 1024 && kc.dpad <= 16;
     {
         // several workgroups per ensemble (ensemble_mw_kernel) when the ensembles alone leave compute units idle: G = the
         // proposals of a half-step, at most (CUs / ensembles), at least 2; every workgroup must be resident (one per CU
@@ -523,7 +524,7 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
                 q.e = a; q.xchg = xchg; q.timeout = 5000000ull; q.G = G;      // 50 ms of the 100 MHz clock
                 dim3 gridm((unsigned)(nensembles * G)), blockm(256);
                 static std::mutex attr_mu_m;
-                static bool attr_done_m[4][64] = {{false}};
+                static bool attr_done_m[5][64] = {{false}};
 #define APGP_LAUNCH_ENS_MW(DP, SLOT)                                                                   \
     do {                                                                                               \
         if (xlds) {                                                                                    \
@@ -547,7 +548,8 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
                     case 2: APGP_LAUNCH_ENS_MW(2, 0); break;
                     case 4: APGP_LAUNCH_ENS_MW(4, 1); break;
                     case 8: APGP_LAUNCH_ENS_MW(8, 2); break;
-                    default: APGP_LAUNCH_ENS_MW(16, 3); break;
+                    case 16: APGP_LAUNCH_ENS_MW(16, 3); break;
+                    default: APGP_LAUNCH_ENS_MW(32, 4); break;
                 }
 #undef APGP_LAUNCH_ENS_MW
                 APGP_CHECK_LAUNCH();
@@ -563,7 +565,7 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
         return -2;
     }
     static std::mutex attr_mu;
-    static bool attr_done[4][64] = {{false}};
+    static bool attr_done[5][64] = {{false}};
 #define APGP_LAUNCH_ENS(DP, SLOT)                                                                      \
     do {                                                                                               \
         if (xlds) {                                                                                    \
@@ -589,7 +591,8 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
         case 2: APGP_LAUNCH_ENS(2, 0); break;
         case 4: APGP_LAUNCH_ENS(4, 1); break;
         case 8: APGP_LAUNCH_ENS(8, 2); break;
-        default: APGP_LAUNCH_ENS(16, 3); break;
+        case 16: APGP_LAUNCH_ENS(16, 3); break;
+        default: APGP_LAUNCH_ENS(32, 4); break;
     }
 #undef APGP_LAUNCH_ENS
     APGP_CHECK_LAUNCH();

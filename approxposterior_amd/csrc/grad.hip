@@ -333,7 +333,8 @@ extern "C" int apgp_grad_loglik(const double* X, const double* alpha, const doub
         case 2: hipLaunchKernelGGL(grad_tile_kernel<2>, dim3(nlow), dim3(256), 0, s, g); break;
         case 4: hipLaunchKernelGGL(grad_tile_kernel<4>, dim3(nlow), dim3(256), 0, s, g); break;
         case 8: hipLaunchKernelGGL(grad_tile_kernel<8>, dim3(nlow), dim3(256), 0, s, g); break;
-        default: hipLaunchKernelGGL(grad_tile_kernel<16>, dim3(nlow), dim3(256), 0, s, g); break;
+        case 16: hipLaunchKernelGGL(grad_tile_kernel<16>, dim3(nlow), dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL(grad_tile_kernel<32>, dim3(nlow), dim3(256), 0, s, g); break;
     }
     hipLaunchKernelGGL(grad_final_kernel, dim3(1), dim3(1024), 0, s, (const double*)g.partial,
                        (long long)nlow, pw, alpha, (const double*)work, (long long)n, g.kc.ndim, out);

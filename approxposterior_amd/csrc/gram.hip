@@ -95,7 +95,8 @@ int apgp_gram_with_rhs(const double* X, int64_t n, const apgp_kernel_t* kern, do
         case 2: hipLaunchKernelGGL(gram_kernel<2>, grid, block, 0, s, a); break;
         case 4: hipLaunchKernelGGL(gram_kernel<4>, grid, block, 0, s, a); break;
         case 8: hipLaunchKernelGGL(gram_kernel<8>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(gram_kernel<16>, grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL(gram_kernel<16>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(gram_kernel<32>, grid, block, 0, s, a); break;
     }
     APGP_CHECK_LAUNCH();
     return 0;

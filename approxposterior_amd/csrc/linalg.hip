@@ -1001,7 +1001,8 @@ extern "C" int apgp_predict1_host(const double* t_host, const double* xs, int64_
         case 2: hipLaunchKernelGGL(pred1_kstar_kernel<2>, grid, block, 0, s, a); break;
         case 4: hipLaunchKernelGGL(pred1_kstar_kernel<4>, grid, block, 0, s, a); break;
         case 8: hipLaunchKernelGGL(pred1_kstar_kernel<8>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(pred1_kstar_kernel<16>, grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL(pred1_kstar_kernel<16>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(pred1_kstar_kernel<32>, grid, block, 0, s, a); break;
     }
     if (winv) {
         hipLaunchKernelGGL(winv_gemv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, winv, (long long)ldw,

@@ -649,7 +649,8 @@ static int nll_small_launch(const double* X, int64_t n, const apgp_kernel_t* ker
         case 2: hipLaunchKernelGGL(nll_small_kernel<2>, dim3(1), dim3(192), 0, s, q); break;
         case 4: hipLaunchKernelGGL(nll_small_kernel<4>, dim3(1), dim3(192), 0, s, q); break;
         case 8: hipLaunchKernelGGL(nll_small_kernel<8>, dim3(1), dim3(192), 0, s, q); break;
-        default: hipLaunchKernelGGL(nll_small_kernel<16>, dim3(1), dim3(192), 0, s, q); break;
+        case 16: hipLaunchKernelGGL(nll_small_kernel<16>, dim3(1), dim3(192), 0, s, q); break;
+        default: hipLaunchKernelGGL(nll_small_kernel<32>, dim3(1), dim3(192), 0, s, q); break;
     }
     APGP_CHECK_LAUNCH();
     return 0;

@@ -1194,7 +1194,8 @@ static int acquire_impl(bool solve, const double* T, int64_t m, int64_t idx_offs
         case 2: rc = launch_sweep<2>(a, s, solve); break;
         case 4: rc = launch_sweep<4>(a, s, solve); break;
         case 8: rc = launch_sweep<8>(a, s, solve); break;
-        default: rc = launch_sweep<16>(a, s, solve); break;
+        case 16: rc = launch_sweep<16>(a, s, solve); break;
+        default: rc = launch_sweep<32>(a, s, solve); break;
     }
     if (rc != 0) return rc;
     if (kind != APGP_UTIL_NONE)
@@ -1360,7 +1361,8 @@ extern "C" int apgp_predict_mean(const double* T, int64_t m, const double* xs, i
         case 2: hipLaunchKernelGGL(predict_mean_kernel<2>, grid, block, 0, s, a); break;
         case 4: hipLaunchKernelGGL(predict_mean_kernel<4>, grid, block, 0, s, a); break;
         case 8: hipLaunchKernelGGL(predict_mean_kernel<8>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(predict_mean_kernel<16>, grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL(predict_mean_kernel<16>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(predict_mean_kernel<32>, grid, block, 0, s, a); break;
     }
     APGP_CHECK_LAUNCH();
     return 0;

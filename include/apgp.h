@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define APGP_ABI_VERSION 7
-#define APGP_MAX_DIM 16          /* feature dimension D supported by the kernels */
+#define APGP_MAX_DIM 32          /* feature dimension D supported by the kernels (instantiated for D padded to 2 / 4 / 8 / 16 / 32) */
 #define APGP_ROW_BLOCK 512       /* rows per packed L^-1 row block (sweep tile)  */
 #define APGP_K_CHUNK 16          /* contraction depth per packed tile            */
 #define APGP_CAND_BLOCK 64       /* candidates per sweep workgroup                */

@@ -38,9 +38,9 @@ def test_abi_version_and_sizes():
     assert lib.apgp_packed_train_len(4096, 8) == 4096 * 10
     assert lib.apgp_packed_train_len(100, 3) == 512 * 6
     assert lib.apgp_trtri_work_len(100) == 2 * 128 * 128
-    assert lib.apgp_grad_work_len(64) == 64 * 64 + 18
+    assert lib.apgp_grad_work_len(64) == 64 * 64 + 2 + _lib.MAX_DIM
     assert lib.apgp_winv_apply_work_len(4096) == 32 * 4096 and lib.apgp_winv_apply_work_len(129) == 2 * 129
-    assert ctypes.sizeof(_lib.KernelStruct) == 8 + 16 + 16 * 8 + 8
+    assert ctypes.sizeof(_lib.KernelStruct) == 8 + 16 + _lib.MAX_DIM * 8 + 8 and _lib.MAX_DIM == 32
     assert ctypes.sizeof(_lib.BestStruct) == 16
 
 

@@ -77,6 +77,11 @@ def scan(co):
                 break
             mm = re.match(r"(v_[a-z0-9_]+|ds_read[a-z0-9_]*|buffer_load[a-z0-9_]*|global_load[a-z0-9_]*|scratch_load[a-z0-9_]*|flat_load[a-z0-9_]*)\s+([^,\s]+)", nt)
             if mm and not mm.group(1).startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and regs(mm.group(2)) & data:
+                # (a compiler-generated spill -- scratch_store -- whose registers are the destination of a MEMORY read: the
+                # read's data comes back tens of cycles after it issues (LDS >= 64), the store has read its own long before;
+                # the hazard seen on the chip was a VALU write in the next issue slot.  Round 5: the D > 16 sweep spills.)
+                if m.group(1) == "scratch" and not mm.group(1).startswith("v_"):
+                    break
                 found.append("%s: `%s` then (+%d) `%s`" % (fn, t, d, nt))
                 break
     return wide, found
