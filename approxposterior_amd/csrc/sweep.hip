@@ -189,7 +189,9 @@ __device__ __forceinline__ void s2_static_for(F&& f) {
 }
 
 // which form of the feeder loop an instantiation gets (see the feeder role)
-static constexpr bool s2_structured_feeder(int dpad, bool solve) { return solve ? dpad == 2 : dpad != 8; }
+// (Dpad = 32, round 5: the plain feeder -- an x chunk is 4352 bytes there, more than the four feeder wavefronts' four 1 KiB
+// LDS-DMA pieces of the structured form, whose hand-counted vmcnt waits assume exactly one piece per wavefront)
+static constexpr bool s2_structured_feeder(int dpad, bool solve) { return dpad == 32 ? false : (solve ? dpad == 2 : dpad != 8); }
 
 // MODE 0: inverse form (A = packed L^-1); 1: substitution form; 2: substitution form with the statically
 // unrolled diagonal tiles (N <= 256 S2_STATIC_DIAG_NRB) -- a separate instantiation: the 65 KiB of
@@ -656,14 +658,28 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, (int)a.xs_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.kcache + (long long)blockIdx.x * a.ncache * SW_BCH), 0, (int)a.kslot_bytes, 0x00020000);
+    // an x chunk is XCHUNK16 16-byte pieces, one per feeder thread -- two for the first threads when Dpad = 32 (272 pieces,
+    // 256 threads): XQ carries the second piece, dead code for the other instantiations
+    constexpr bool X2 = XCHUNK16 > 256;
+    struct XQ { f64x2 a, b; };
     const unsigned xoff = ht < XCHUNK16 ? hoff : 0u;
+    const unsigned xoff2 = (X2 && ht + 256 < XCHUNK16) ? hoff + 256u * 16u : 0u;
     auto x_fetch = [&](int kc) {
-        return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0));
+        XQ q;
+        q.a = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0));
+        if constexpr (X2) q.b = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff2, (unsigned)kc * (unsigned)(SW_KC * XS * 8), 0));
+        return q;
     };
-    auto x_put = [&](int xb, f64x2 v) {
+    auto x_put = [&](int xb, const XQ& v) {
         if (ht < XCHUNK16) {
-            if (xb == 0) *((f64x2*)Xbuf + ht) = v;
-            else *((f64x2*)(Xbuf + XSTRIDE) + ht) = v;
+            if (xb == 0) *((f64x2*)Xbuf + ht) = v.a;
+            else *((f64x2*)(Xbuf + XSTRIDE) + ht) = v.a;
+        }
+        if constexpr (X2) {
+            if (ht + 256 < XCHUNK16) {
+                if (xb == 0) *((f64x2*)Xbuf + ht + 256) = v.b;
+                else *((f64x2*)(Xbuf + XSTRIDE) + ht + 256) = v.b;
+            }
         }
     };
     const bool park = a.ncache > 0;
@@ -947,7 +963,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
         x_put(1, x_fetch(p1.kc));
         __syncthreads();                              // P0
         produce_b(p0.jb, p0.kc, 0, 0);
-        f64x2 xq = x_fetch(p2.kc);
+        XQ xq = x_fetch(p2.kc);
         __syncthreads();                              // P
         // total tiles of this workgroup
         long long ntile_blk = 0;
@@ -978,7 +994,7 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             // completes in issue order, so "at most n outstanding" still means the images and parked
             // operands of tile i+1 have landed -- without the ~1-2 k cycles of store acknowledgement.
             int n_pend = (!SOLVE && is_gen(p1) && park && p1.kc >= S2_CPB * p1.jb && p1.jb + 1 < nrb2) ? 2 : 0;
-            if (is_gen(p3)) { xq = x_fetch(p3.kc); ++n_pend; }
+            if (is_gen(p3)) { xq = x_fetch(p3.kc); n_pend += X2 ? 2 : 1; }
             last_m2 = last_m1;
             last_m1 = (p1.jb == jb_hi - 1 && p1.kc == nkc_of(p1.jb) - 1);
             p0 = p1; p1 = p2; p2 = p3; p3 = next_of(p3);
@@ -989,7 +1005,8 @@ __global__ __launch_bounds__(S2_THREADS, 1) void sweep2_kernel(SweepArgs a) {
             if (n_pend == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else if (n_pend == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else if (n_pend == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (n_pend == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
 }
