@@ -369,3 +369,79 @@ def test_more_than_sixteen_dimensions(n, D):
         with pytest.raises(ValueError):
             agp.GP(kernel=agp.ExpSquaredKernel(np.ones(33), ndim=33), fit_mean=True, mean=0.0, white_noise=-8,
                    fit_white_noise=False).compute(np.zeros((40, 33)))
+
+
+def _philox_box_numpy(m, D, lo, hi, seed, offset):
+    """NumPy restatement of csrc/ensemble.hip box_candidates_kernel: Philox4x32-10, counter = (row low, row high, d / 2,
+    0x43414e44), key = seed; u = 53-bit uniform in (0, 1); value = fma(span, u, lo) (the product span * u is exact enough to
+    compare to 1 ulp: the kernel fuses it)."""
+    rows = (np.arange(m, dtype=np.uint64) + np.uint64(offset))
+    out = np.empty((m, D))
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    for d in range(0, D, 2):
+        c = [rows & mask, rows >> np.uint64(32), np.full(m, d >> 1, dtype=np.uint64), np.full(m, 0x43414E44, dtype=np.uint64)]
+        k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+        for _ in range(10):
+            p0, p1 = M0 * c[0], M1 * c[2]
+            c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & mask, p1 & mask, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & mask, p0 & mask]
+            k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+            k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+        u0 = ((c[0] >> np.uint64(5)).astype(np.float64) * 67108864.0 + (c[1] >> np.uint64(6)).astype(np.float64) + 0.5) / 9007199254740992.0
+        u1 = ((c[2] >> np.uint64(5)).astype(np.float64) * 67108864.0 + (c[3] >> np.uint64(6)).astype(np.float64) + 0.5) / 9007199254740992.0
+        out[:, d] = lo[d] + (hi[d] - lo[d]) * u0
+        if d + 1 < D:
+            out[:, d + 1] = lo[d + 1] + (hi[d + 1] - lo[d + 1]) * u1
+    return out
+
+
+def test_device_candidates_are_a_function_of_seed_and_row():
+    """``deviceCandidates`` (round 5): the candidate matrix of the sweep drawn on the device by counter-based Philox -- the
+    batched counterpart of the ``sampleFn`` draws utility.minimizeObjective starts from (utility.py:334-338) when the prior is
+    the box.  (1) the matrix equals a NumPy restatement of the generator (to 1 ulp: the kernel fuses lo + span * u),
+    (2) rows generated with an offset are exactly the rows of the whole matrix -- what lets every rank of a sharded sweep
+    generate its own shard, (3) uniform in the box, (4) ``findNextPoint(nCandidates=..., deviceCandidates=True)`` picks the
+    arg-min of the oracle's utility over that matrix."""
+    from approxposterior_amd import approx, gpUtils, likelihood as lh, utility as ut
+    go, agp = _mods()
+    D = 5
+    X, y = _case(200, D, 4)
+    g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(D, 8.0), ndim=D), fit_mean=True, mean=float(np.median(y)), white_noise=-12,
+               fit_white_noise=False)
+    g.compute(X)
+    bounds = [(-5.0, 5.0), (-1.0, 3.0), (0.0, 0.5), (-5.0, 5.0), (2.0, 2.0 + 1e-3)]
+    lo, hi = np.array([b[0] for b in bounds]), np.array([b[1] for b in bounds])
+    seed = 123456789123
+    T = g.box_candidates(100003, bounds, seed).cpu().numpy()
+    want = _philox_box_numpy(100003, D, lo, hi, seed, 0)
+    assert np.abs(T - want).max() <= 4e-16 * np.abs(want).max()
+    part = g.box_candidates(777, bounds, seed, idx_offset=50000).cpu().numpy()
+    assert np.array_equal(part, T[50000:50777])
+    big = g.box_candidates(3, bounds, seed, idx_offset=2 ** 33 + 5).cpu().numpy()
+    assert np.abs(big - _philox_box_numpy(3, D, lo, hi, seed, 2 ** 33 + 5)).max() <= 4e-16 * 5
+    assert np.all(T >= lo) and np.all(T <= hi)
+    u = (T - lo) / (hi - lo)
+    assert np.abs(u.mean(axis=0) - 0.5).max() < 0.01 and np.abs(u.var(axis=0) - 1.0 / 12).max() < 0.005
+    assert g.box_candidates(0, bounds, seed).shape == (0, D)
+    # through ApproxPosterior: the winner is the oracle's arg-min over the generated matrix
+    D = 2
+    np.random.seed(57)
+    theta = np.array(lh.rosenbrockSample(60))
+    yy = np.array([lh.rosenbrockLnlike(t) + lh.rosenbrockLnprior(t) for t in theta])
+    gp = gpUtils.defaultGP(theta, yy)
+    ap = approx.ApproxPosterior(theta=theta, y=yy, gp=gp, lnprior=lh.rosenbrockLnprior, lnlike=lh.rosenbrockLnlike,
+                                priorSample=lh.rosenbrockSample, bounds=((-5, 5), (-5, 5)), algorithm="bape")
+    state = np.random.get_state()
+    pt = ap.findNextPoint(computeLnLike=False, nCandidates=50000, deviceCandidates=True)
+    np.random.set_state(state)
+    s2 = int(np.random.randint(0, 2 ** 31 - 1))
+    M = _philox_box_numpy(50000, 2, np.array([-5.0, -5.0]), np.array([5.0, 5.0]), s2, 0)
+    o = go.GP(kernel=go.ExpSquaredKernel(np.exp(gp.get_parameter_vector()[1:]), ndim=2), fit_mean=True,
+              mean=float(gp.get_parameter_vector()[0]), white_noise=-12, fit_white_noise=False)
+    o.compute(theta)
+    mo, vo = o.predict(yy, M, return_var=True)
+    with np.errstate(all="ignore"):
+        uo = -((2.0 * mo + vo) + vo + np.log(1.0 - np.exp(-vo)))
+    best = int(np.nanargmin(uo))
+    assert np.abs(pt - M[best]).max() <= 1e-12 or abs(uo[best] - np.sort(uo[np.isfinite(uo)])[0]) < 1e-9
+    assert ap.deviceCandidates is True
