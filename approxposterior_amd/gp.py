@@ -1083,6 +1083,8 @@ class GP(object):
         hi = (ctypes.c_double * _lib.MAX_DIM)(*b[:, 1])
         with self._on(torch, dev):
             T = torch.empty((int(m), D), dtype=torch.float64, device=dev)
+            if int(m) == 0:
+                return T
             _lib.check(lib.apgp_box_candidates(T.data_ptr(), int(m), D, lo, hi, int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                int(idx_offset), self._stream(torch)), "apgp_box_candidates")
         return T
