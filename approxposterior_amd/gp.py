@@ -684,6 +684,18 @@ class GP(object):
                                              float(self.mean.value), 0, self._z.data_ptr(),
                                              ztz.data_ptr(), st), "apgp_trsv(forward)")
                 self._ztz_host = float(ztz.item())
+                if not via_w and self._ztz_host != self._ztz_host:
+                    # NaN: the persistent solve could not get its workgroups resident (apgp.h: it writes NaN instead of
+                    # hanging) -- or the factor is not finite, in which case the re-run says so too.  Once more, a launch per
+                    # 256 rows.
+                    prev = lib.apgp_trsv_mode(1)
+                    try:
+                        _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, self._ld, self._y_d.data_ptr(),
+                                                 float(self.mean.value), 0, self._z.data_ptr(),
+                                                 ztz.data_ptr(), st), "apgp_trsv(forward, multi-launch)")
+                        self._ztz_host = float(ztz.item())
+                    finally:
+                        lib.apgp_trsv_mode(prev)
                 self._alpha = None
                 self._xs = None
                 self._alpha_y = np.array(y, copy=True)
@@ -696,8 +708,16 @@ class GP(object):
                                                    self._alpha.data_ptr(), None, wk.data_ptr(), st),
                                "apgp_winv_apply(backward)")
                 else:
+                    asq = torch.empty(1, dtype=torch.float64, device=dev)
                     _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, self._ld, self._z.data_ptr(), 0.0, 1,
-                                             self._alpha.data_ptr(), None, st), "apgp_trsv(backward)")
+                                             self._alpha.data_ptr(), asq.data_ptr(), st), "apgp_trsv(backward)")
+                    if float(asq.item()) != float(asq.item()):      # (NaN: see the forward solve)
+                        prev = lib.apgp_trsv_mode(1)
+                        try:
+                            _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, self._ld, self._z.data_ptr(), 0.0, 1,
+                                                     self._alpha.data_ptr(), None, st), "apgp_trsv(backward, multi-launch)")
+                        finally:
+                            lib.apgp_trsv_mode(prev)
                 self._xs = None
         return self._ztz_host
 

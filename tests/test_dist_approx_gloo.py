@@ -38,11 +38,11 @@ def _stub_module():
     from approxposterior_amd import gpUtils, mcmc
 
     class StubGP(go.GP):
-        calls = {"acquire_rows": [], "sample_seeds": []}
+        calls = {"acquire_rows": [], "sample_seeds": [], "box_rows": []}
 
         def acquire(self, y, t, kind, bounds=None, mask=None, zeta=0.01, return_all=False, idx_offset=0,
                     device_record=False):
-            t = self.parse_samples(t) if len(t) else np.empty((0, self.kernel.ndim))
+            t = self.parse_samples(np.asarray(t)) if len(t) else np.empty((0, self.kernel.ndim))
             StubGP.calls["acquire_rows"].append(len(t))
             bi, bu = -1, np.inf
             if len(t):
@@ -78,6 +78,13 @@ def _stub_module():
             s.run_mcmc(p0, iterations)
             return {"chain": s.get_chain(), "log_prob": s.get_log_prob(), "naccept": s._naccepted,
                     "coords": s.get_chain()[-1], "final_log_prob": s.get_log_prob()[-1]}
+
+        def box_candidates(self, m, bounds, seed, idx_offset=0):
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from philox_ref import philox_box_numpy
+            b = np.asarray(bounds, dtype=float)
+            StubGP.calls["box_rows"].append((int(m), int(idx_offset)))
+            return torch.from_numpy(philox_box_numpy(int(m), len(b), b[:, 0], b[:, 1], int(seed), int(idx_offset)))
 
         def nll_batch(self, P, y):
             saved = self.get_parameter_vector()
@@ -118,10 +125,12 @@ def _drive(out_path, rank):
         chain = ap.sampler.get_chain()
         extra = ap.findNextPoint(nCandidates=None, nMinObjRestarts=2, cache=False, verbose=False,
                                  gpOptions={"maxiter": 2}, minObjOptions={"maxiter": 20})
+        dev_pt = ap.findNextPoint(nCandidates=1003, deviceCandidates=True, computeLnLike=False, cache=False, verbose=False)
         best, val = ap.findMAP(nRestarts=2, options={"maxiter": 20, "adaptive": True})
     np.savez(out_path, theta=ap.theta, y=ap.y, p=ap.gp.get_parameter_vector(), chain=chain,
              iburns=ap.iburns, ithins=ap.ithins, nlnlike=len(evaluations), extra=np.asarray(extra[0]),
-             best=best, val=val, rows=np.array(stub.GP.calls["acquire_rows"]),
+             best=best, val=val, rows=np.array(stub.GP.calls["acquire_rows"]), dev_pt=np.asarray(dev_pt),
+             box_rows=np.array(stub.GP.calls["box_rows"]),
              seeds=np.array(stub.GP.calls["sample_seeds"]),
              wrote_cache=os.path.exists(runName + "APFModelCache.npz"),
              state=np.random.get_state()[1])
@@ -164,9 +173,15 @@ def test_approxposterior_run_is_rank_consistent(tmp_path, world):
         # the forward model ran on rank 0 only; only rank 0 wrote caches
         assert int(got["nlnlike"]) == (n_new if r == 0 else 0)
         assert bool(got["wrote_cache"]) == (r == 0)
-        # every sweep saw this rank's shard of the 601-row draw
+        # every sweep saw this rank's shard of the 601-row draw (the last one: of the 1003 rows drawn "on the device")
         base, rem = divmod(601, world)
-        assert set(got["rows"].tolist()) == {base + (1 if r < rem else 0)}
+        assert set(got["rows"][:-1].tolist()) == {base + (1 if r < rem else 0)}
+        b2, r2 = divmod(1003, world)
+        lo2 = r * b2 + min(r, r2)
+        assert got["rows"][-1] == b2 + (1 if r < r2 else 0)
+        # deviceCandidates: this rank generated exactly its rows [lo, hi) of the global matrix, then the winning row alone
+        assert got["box_rows"][0].tolist() == [b2 + (1 if r < r2 else 0), lo2] and got["box_rows"][1][0] == 1
+        assert np.array_equal(got["dev_pt"], one["dev_pt"])
         # replica ensembles: world x 6 walkers, the same gathered chain everywhere; rank r sampled with base + r
         assert got["chain"].shape == (30, 6 * world, 2)
         assert np.array_equal(got["chain"], ranks[0]["chain"])
@@ -174,7 +189,7 @@ def test_approxposterior_run_is_rank_consistent(tmp_path, world):
         assert np.array_equal(got["iburns"], ranks[0]["iburns"]) and np.array_equal(got["ithins"], ranks[0]["ithins"])
     # rank 0's replica is the single-process chain (same seed, same surrogate)
     assert np.array_equal(ranks[0]["chain"][:, :6], one["chain"])
-    assert one["rows"].tolist() == [601] * 6
+    assert one["rows"].tolist() == [601] * 6 + [1003]
     # the ranks' NumPy streams were pulled together before every draw that matters: after the last synchronised
     # call (findMAP) no rank has drawn anything rank 0 has not
     for got in ranks[1:]:
