@@ -370,7 +370,6 @@ __device__ __forceinline__ void pp_catch_T(const double (*Ls)[PB + 2], const dou
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-            constexpr int dummy = 0; (void)dummy;
             const int kc = K0 + 4 * ks;                            // first column of the group: chunk kc / 16, position kc % 16
             af[ti][ks] = -As_cur[(kc >> 4) * PP_CHUNK + (16 * ti + (lane & 15)) * 18 + (kc & 15) + (lane >> 4)];
         }
