@@ -88,10 +88,12 @@ def test_replicas_restarts_and_broadcast_through_rccl(rccl_world1):
     assert np.isnan(b[0]) and np.signbit(b[1]) and b[2] == 1e-310     # bytes, not values, travel
 
 
-def test_run_under_rccl_group_equals_run_without(rccl_world1, tmp_path, monkeypatch):
+@pytest.mark.parametrize("device_cands", [False, True])
+def test_run_under_rccl_group_equals_run_without(rccl_world1, tmp_path, monkeypatch, device_cands):
     """C5's shape in miniature (D = 4, m0 = 96, m = 4, nmax = 2, 20,000 candidates, 3 restarts, on-device MCMC),
     once with ``distributed=False`` and once through the process group: identical training sets, hyper-parameters
-    and chains."""
+    and chains -- with the candidates drawn by ``priorSample`` on the host and (``deviceCandidates``) by the counter-based
+    generator on the device."""
     monkeypatch.chdir(tmp_path)
     from scipy.optimize import rosen
     from approxposterior_amd import approx, gpUtils
@@ -110,7 +112,8 @@ def test_run_under_rccl_group_equals_run_without(rccl_world1, tmp_path, monkeypa
         assert (ap._ranks() is None) == (mode is False)
         with np.errstate(all="ignore"):
             ap.run(m=4, nmax=2, nCandidates=20000, nGPRestarts=3, cache=False, verbose=False, onDevice=True,
-                   gpOptions={"maxiter": 4}, mcmcKwargs={"iterations": 300}, samplerKwargs={"nwalkers": 16})
+                   gpOptions={"maxiter": 4}, mcmcKwargs={"iterations": 300}, samplerKwargs={"nwalkers": 16},
+                   deviceCandidates=device_cands)
         out[mode] = (ap.theta.copy(), ap.y.copy(), ap.gp.get_parameter_vector().copy(), ap.sampler.get_chain().copy(),
                      ap.sampler.get_log_prob().copy(), np.random.get_state()[1].copy())
     for a, b in zip(out[False], out[None]):
