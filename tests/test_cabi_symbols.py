@@ -65,3 +65,16 @@ def test_bad_arguments_are_refused_without_a_gpu():
     assert lib.apgp_pack_lsolve(None, 4, 4, None, None) == -1
     assert lib.apgp_predict1_host(None, None, 4, ctypes.byref(ks), 0.0, None, 0, None, 0, None, None, None) == -1
     assert lib.apgp_predict1_work_len(100) == 2 * 512 + 1 + 8
+    # round 5 entry points
+    lo = (ctypes.c_double * _lib.MAX_DIM)(); hi = (ctypes.c_double * _lib.MAX_DIM)(*([1.0] * _lib.MAX_DIM))
+    assert lib.apgp_box_candidates(None, 4, 2, lo, hi, 1, 0, None) == -1
+    assert b"null pointer" in lib.apgp_last_error()
+    buf = (ctypes.c_double * 8)()
+    assert lib.apgp_box_candidates(ctypes.addressof(buf), 4, _lib.MAX_DIM + 1, lo, hi, 1, 0, None) == -1
+    assert lib.apgp_box_candidates(ctypes.addressof(buf), 4, 2, lo, hi, 1, -5, None) == -1
+    assert lib.apgp_box_candidates(ctypes.addressof(buf), 0, 2, lo, hi, 1, 0, None) == 0        # nothing to draw: no launch
+    assert lib.apgp_nll_eval(None, 4, ctypes.byref(ks), None, 0.0, None, None, None, None, None, None) == -1
+    assert lib.apgp_ensemble_mode(-1) in (0, 1) and lib.apgp_potrf_backoff_skips() >= 0
+    ks.ndim = _lib.MAX_DIM + 1
+    assert lib.apgp_gram(ctypes.addressof(buf), 4, ctypes.byref(ks), ctypes.addressof(buf), 4, None) == -1
+    ks.ndim = 2
