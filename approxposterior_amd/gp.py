@@ -140,6 +140,9 @@ class ConstantKernel(Kernel):
         self.log_constant = float(v[0])
         self.dirty = True
 
+    def __len__(self):
+        return 1
+
 
 class ExpSquaredKernel(Kernel):
     """k(x,x') = exp(-0.5 sum_d (x_d-x'_d)^2 / M_d); parameters are log M_d."""
@@ -163,6 +166,9 @@ class ExpSquaredKernel(Kernel):
     def set_parameter_vector(self, v):
         self.log_M = np.array(v, dtype=np.float64)
         self.dirty = True
+
+    def __len__(self):
+        return len(self.log_M)
 
 
 class LinearKernel(Kernel):
@@ -194,6 +200,9 @@ class LinearKernel(Kernel):
         self.log_gamma2 = float(v[0])
         self.dirty = True
 
+    def __len__(self):
+        return 1
+
 
 class Product(Kernel):
     def __init__(self, k1, k2):
@@ -222,6 +231,9 @@ class Product(Kernel):
         n1 = len(self.k1)
         self.k1.set_parameter_vector(v[:n1])
         self.k2.set_parameter_vector(v[n1:])
+
+    def __len__(self):
+        return len(self.k1) + len(self.k2)
 
 
 class Sum(Product):
@@ -269,6 +281,14 @@ def _flatten_kernel(kernel, with_linear=False):
     """(amp, log_M) of an ExpSquared kernel, optionally times constants; with
     ``with_linear`` also (lin_coef, lin_order) of an added [constant *] LinearKernel
     (``kernel + c * LinearKernel``, gpUtils.py:170-173), (0.0, 0) if there is none."""
+    # the two shapes gpUtils.defaultGP builds without a linear term (gpUtils.py:160-165), without the generic walk:
+    # this runs once per objective evaluation of an optimiser loop
+    tk = type(kernel)
+    if tk is ExpSquaredKernel:
+        return (1.0, kernel.log_M, 0.0, 0) if with_linear else (1.0, kernel.log_M)
+    if tk is Product and type(kernel.k1) is ConstantKernel and type(kernel.k2) is ExpSquaredKernel:
+        amp = float(kernel.k1.ndim * np.exp(kernel.k1.log_constant))
+        return (amp, kernel.k2.log_M, 0.0, 0) if with_linear else (amp, kernel.k2.log_M)
     terms = [kernel.k1, kernel.k2] if isinstance(kernel, Sum) else [kernel]
     amp = log_M = None
     lin_coef, lin_order = 0.0, 0
@@ -289,6 +309,31 @@ def _flatten_kernel(kernel, with_linear=False):
     if with_linear:
         return amp, log_M, float(lin_coef), int(lin_order)
     return amp, log_M
+
+
+class _NllPlan(object):
+    """The arguments of one ``apgp_nll_eval`` call, kept between the evaluations of an optimiser loop
+    (``GP._factor_again``): device buffers (referenced, so their addresses stay valid), the kernel struct that is
+    refilled in place, the host record, and what has to be unchanged for the plan to apply."""
+    __slots__ = ("x", "ybytes", "n", "nlog2pi", "stream", "dev_index", "current_device", "raw_stream", "ks", "fn", "args",
+                 "o", "K", "z", "keep")
+
+    def __init__(self, gp, torch, dev, stream, ks, yv, x_d, y_d, K, z, scr, o, n):
+        self.x = gp._x
+        self.ybytes = yv.tobytes()
+        self.n = n
+        self.nlog2pi = n * np.log(2.0 * np.pi)
+        self.stream = stream
+        self.dev_index = dev.index
+        self.current_device = torch.cuda.current_device
+        self.raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self.ks = ks
+        self.fn = gp._rt()[2].apgp_nll_eval
+        self.o = o
+        self.K, self.z = K, z
+        self.keep = (x_d, y_d, scr)
+        self.args = [x_d.data_ptr(), n, ctypes.byref(ks), y_d.data_ptr(), 0.0, K.data_ptr(), z.data_ptr(),
+                     scr[0].data_ptr(), scr[1].data_ptr(), o.ctypes.data, ctypes.c_void_p(stream)]
 
 
 # ---------------------------------------------------------------------------
@@ -337,6 +382,7 @@ class GP(object):
         self._mean_work = getattr(self, "_mean_work", None)   # scratch survives refits
         self._p1_work = getattr(self, "_p1_work", None)
         self._nll_scratch = getattr(self, "_nll_scratch", None)
+        self._nll_plan = None     # the arguments of the last _nll evaluation, ready for the next (_factor_again)
         self.cond_estimate = None
         self.log_determinant = None
 
@@ -374,9 +420,13 @@ class GP(object):
             return ctypes.c_void_p(raw(torch.cuda.current_device()))
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def _kernel_struct(self):
+    def _kernel_struct(self, ks=None):
+        """The kernel's hyper-parameters as the C ABI's struct (``ks``: refilled in place)."""
         amp, log_M, lin_coef, lin_order = _flatten_kernel(self.kernel, with_linear=True)
-        ks = _lib.KernelStruct()
+        if ks is None:
+            ks = _lib.KernelStruct()
+        elif ks.ndim != len(log_M):
+            raise ValueError("dimension mismatch")
         ks.ndim = len(log_M)
         ks.amp = amp
         ks.lin_coef = lin_coef
@@ -468,8 +518,9 @@ class GP(object):
         return self.cond_estimate is not None and self.cond_estimate <= COND_SOLVE
 
     def _factor_key(self):
-        return (tuple(self.kernel.get_parameter_vector().tolist()), float(self.white_noise.value),
-                float(self._yerr2))
+        """What the factor depends on: the bytes of the C ABI's kernel struct (amplitude, inverse metric, linear term,
+        white noise + yerr^2) -- the mean is not part of it."""
+        return bytes(self._kernel_struct())
 
     def _try_extend(self, prev):
         """Extend ``prev``'s Cholesky factor by the rows of self._x it does not cover:
@@ -557,6 +608,8 @@ class GP(object):
         """Gram + Cholesky (+ z = L^-1 (y - mean) carried through the factorisation)
         + log-determinant / diagonal range / z.z / info, fetched with ONE 40-byte
         device-to-host copy.  This is one gpUtils._nll evaluation."""
+        if y is not None and not upload_x and self._nll_plan is not None and self._factor_again(y):
+            return
         torch, dev, lib = self._rt()
         x = self._x
         n = len(x)
@@ -626,7 +679,7 @@ class GP(object):
         self._const = -0.5 * (n * np.log(2.0 * np.pi) + self.log_determinant)
         self._computed = True
         self.kernel.dirty = False
-        self._factored_key = self._factor_key()
+        self._factored_key = bytes(ks)
         if z is not None:
             self._z = z
             self._ztz_host = float(o[3])
@@ -635,6 +688,49 @@ class GP(object):
             self._alpha_mean = self.mean.value
             self._nll_owned = True    # (K, z) came from an _nll evaluation: the next one may refactorise in place
             self._nll_stream = st.value
+            # everything the NEXT evaluation on this training set, y and stream needs, ready to go (_factor_again)
+            self._nll_plan = _NllPlan(self, torch, dev, st.value or 0, ks, yv, self._x_d, y_d, K, z, scr, o, n)
+
+    def _factor_again(self, y):
+        """One more gpUtils._nll evaluation (gpUtils.py:46-80) in the buffers of the last one: what ``_factor`` does when
+        it finds them reusable, minus everything that cannot have changed -- the optimiser loop's path (SciPy asks for
+        ~6e5 evaluations in BASELINE config 5; the generic path's 17 us of Python between two device evaluations were 7 %
+        of each).  False: something differs (training set, y, stream, device, buffers) -- the caller takes the generic path."""
+        plan = self._nll_plan
+        if (plan.x is not self._x or plan.K is not self._L or plan.z is not self._z or self._L_store is not None
+                or not self._nll_owned or type(y) is not np.ndarray or y.dtype != np.float64):
+            return False
+        cur = plan.current_device()
+        if cur != plan.dev_index or plan.raw_stream is None or plan.raw_stream(cur) != plan.stream:
+            return False
+        if y.size != plan.n or not y.flags.c_contiguous or y.tobytes() != plan.ybytes:
+            return False
+        ks = self._kernel_struct(plan.ks)
+        # (as _reset_device_state: whatever was derived from the previous factor is stale)
+        self._alpha = self._packed = self._packed_solve = self._work = self._xs = self._xs_key = None
+        self._computed = False
+        args = plan.args
+        args[4] = float(self.mean.value)
+        rc = plan.fn(*args)
+        if rc != 0:
+            self._reset_device_state()
+            _lib.check(rc, "apgp_nll_eval")
+        o = plan.o
+        if o[4] != 0.0 or not np.isfinite(o[0]):
+            self._reset_device_state()
+            if o[4] != 0.0:
+                raise LinAlgError("%d-th leading minor of the array is not positive definite" % int(o[4]))
+            raise LinAlgError("non-finite log-determinant")
+        logdet = float(o[0])
+        self.log_determinant = logdet
+        self.cond_estimate = float((o[2] / o[1]) ** 2)
+        self._const = -0.5 * (plan.nlog2pi + logdet)
+        self._ztz_host = float(o[3])
+        self._alpha_mean = self.mean.value
+        self._computed = True
+        self.kernel.dirty = False
+        self._factored_key = bytes(ks)
+        return True
 
     def recompute(self, quiet=False, **kwargs):
         if self.kernel.dirty or not self._computed:

@@ -11,6 +11,8 @@ public names and argument meaning (``defaultHyperPrior`` :22-43, ``_nll`` :46-80
 one Gram + Cholesky + solve on the GPU through the C ABI.
 """
 
+from collections import OrderedDict
+
 import numpy as np
 from scipy.optimize import minimize
 
@@ -22,7 +24,7 @@ __all__ = ["defaultHyperPrior", "defaultGP", "optimizeGP"]
 def defaultHyperPrior(p):
     """Flat prior keeping every log hyper-parameter (all but the mean) within
     [-20, 20]; returns 0.0 inside, -inf outside (gpUtils.py:22-43)."""
-    if np.any(np.fabs(p)[1:] > 20):
+    if (np.fabs(p)[1:] > 20).any():
         return -np.inf
     return 0.0
 
@@ -39,9 +41,9 @@ def _memoTable(gp, y):
     if not hasattr(gp, "_nllMemo"):       # only a GP that drops the table in compute() carries one
         return None
     memo = gp._nllMemo
-    if memo is None or not np.array_equal(memo["y"], y):
-        from collections import OrderedDict
-        memo = gp._nllMemo = {"y": np.array(y, copy=True), "table": OrderedDict()}
+    yb = y.tobytes() if type(y) is np.ndarray and y.dtype == np.float64 else np.asarray(y, dtype=np.float64).tobytes()
+    if memo is None or memo["y"] != yb:
+        memo = gp._nllMemo = {"y": yb, "table": OrderedDict()}
     return memo["table"]
 
 
@@ -161,7 +163,6 @@ def _minimizeLockStep(gp, y, x0s, method, options, priorFn):
     ``_nll`` evaluations are served in lock-step by ``gp.nll_batch`` -- one batched
     Gram + Cholesky per round instead of one per restart."""
     import threading
-    from collections import OrderedDict
     step = _LockStep(len(x0s), lambda pts: gp.nll_batch(np.array(pts), y))
     sols, errs = [None] * len(x0s), [None] * len(x0s)
 
