@@ -71,7 +71,29 @@ struct PotrfArgs {
     // both block columns to every other tile in ONE pass over the tile -- two products, each accumulated from zero and
     // subtracted in turn: the bits of two separate passes, half their traffic.  0 = every step applies its own column.
     int pair_mode;
+    // DEFERRED tiles (round 5): a narrow step is a latency chain (first tile + panel, ~25 us) on ~2 tb workgroups with the
+    // rest of the chip idle, the wide step before it is bound by its update.  A wide step therefore leaves `defer8` eighths
+    // of its tiles right of the next narrow step's two tile columns (block columns >= 3 of its trailing matrix; tile e of
+    // that triangle is deferred iff e % 8 < defer8) to the NEXT launch, whose `deferred8` says so: extra workgroups of the
+    // narrow step apply the two earlier block columns to them, exactly as the wide step would have (same products, same
+    // order: same bits), while the panel chain runs.  0 = nothing deferred.
+    int defer8, deferred8;
 };
+
+// tile e (row r, column c of the lower triangle, 0 <= c <= r) of a triangle, e = r (r + 1) / 2 + c
+__device__ __forceinline__ void potrf_tri(long long e, long long& r, long long& c) {
+    long long b = (long long)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((b + 1) * (b + 2) / 2 <= e) ++b;
+    while (b * (b + 1) / 2 > e) --b;
+    r = b;
+    c = e - b * (b + 1) / 2;
+}
+// the k-th deferred (e % 8 < d8) / kept (e % 8 >= d8) index
+__device__ __host__ __forceinline__ long long potrf_deferred_index(long long k, int d8) { return (k / d8) * 8 + (k % d8); }
+__device__ __host__ __forceinline__ long long potrf_kept_index(long long k, int d8) { return (k / (8 - d8)) * 8 + d8 + (k % (8 - d8)); }
+__device__ __host__ __forceinline__ long long potrf_deferred_count(long long E, int d8) {
+    return E <= 0 || d8 <= 0 ? 0 : (E / 8) * d8 + ((E % 8) < d8 ? (E % 8) : d8);
+}
 
 // matrix of this workgroup in a batched launch (gridDim.y = batch size; strides 0 otherwise)
 __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
@@ -587,7 +609,7 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
     a.A = q.K; a.rhs = q.z; a.n = q.n; a.lda = q.n; a.j0 = 0; a.shift = 0.0; a.info = q.info; a.out5 = nullptr;
     a.mail = nullptr; a.seq = 0;
     a.dscr = nullptr; a.batch_dscr = 0; a.zoff = 0; a.batch_A = 0; a.batch_rhs = 0;
-    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0;
+    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0; a.defer8 = 0; a.deferred8 = 0;
     double ar[PB];
     const double ri = lane < bs ? q.y[lane] - q.shift : 0.0;
 #pragma unroll
@@ -676,8 +698,32 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
     const long long tb = (a.n - base + PB - 1) / PB;      // its size in blocks
     const bool first = (long long)blockIdx.x < tb;
     long long bi, bk;
+    bool deferred = false;                                // a tile the previous (wide) step left to this launch
     if (first) { bi = blockIdx.x; bk = 0; }
-    else if (a.pair_mode == 1) { bi = (long long)blockIdx.x - tb + 1; bk = 1; }      // narrow step: the second tile column only
+    else if (a.pair_mode == 1) {
+        // narrow step: the second tile column only ...
+        const long long k = (long long)blockIdx.x - tb;
+        if (k < tb - 1) { bi = k + 1; bk = 1; }
+        else {
+            // ... and the previous wide step's deferred tiles: that step's trailing matrix starts at j0 (one block earlier
+            // than this one's), its eligible triangle at block (3, 3)
+            deferred = true;
+            long long r, c;
+            potrf_tri(potrf_deferred_index(k - (tb - 1), a.deferred8), r, c);
+            bi = r + 3 - 1; bk = c + 3 - 1;               // (in THIS step's block numbering: one less)
+        }
+    }
+    else if (a.defer8 > 0) {
+        // wide step that defers: tile columns 1 and 2 in full, then the kept tiles of the triangle from block (3, 3) on
+        const long long k = (long long)blockIdx.x - tb;
+        if (k < tb - 1) { bi = k + 1; bk = 1; }
+        else if (k < 2 * tb - 3) { bi = k - (tb - 1) + 2; bk = 2; }
+        else {
+            long long r, c;
+            potrf_tri(potrf_kept_index(k - (2 * tb - 3), a.defer8), r, c);
+            bi = r + 3; bk = c + 3;
+        }
+    }
     else {
         // the other tiles: lower triangle of the (tb - 1) x (tb - 1) blocks below / right of tile (0, 0)
         const long long tix = (long long)blockIdx.x - tb;
@@ -707,9 +753,11 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
                     cin[i][j][r] = (gr < a.n && gc < a.n && gc <= gr) ? a.A[gr * a.lda + gc] : 0.0;
                     v[i][j][r] = 0.0;
                 }
-        if (a.pair_mode == 2) {
+        // (a deferred tile: the wide step's two block columns are the two BEFORE this step's)
+        const long long jc = deferred ? a.j0 - PB : a.j0;
+        if (a.pair_mode == 2 || deferred) {
             // wide step: the previous block column first (its narrow step left these tiles alone), then this one
-            apgp_gemm64_tile<false, false>(a.A + ri * a.lda + a.j0 - PB, a.lda, a.n - ri, a.A + rk * a.lda + a.j0 - PB, a.lda, a.n - rk,
+            apgp_gemm64_tile<false, false>(a.A + ri * a.lda + jc - PB, a.lda, a.n - ri, a.A + rk * a.lda + jc - PB, a.lda, a.n - rk,
                                            0, PB, lds, v);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -721,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(PotrfArgs a) {
                         v[i][j][r] = 0.0;
                     }
         }
-        apgp_gemm64_tile<false, false>(a.A + ri * a.lda + a.j0, a.lda, a.n - ri, a.A + rk * a.lda + a.j0, a.lda, a.n - rk,
+        apgp_gemm64_tile<false, false>(a.A + ri * a.lda + jc, a.lda, a.n - ri, a.A + rk * a.lda + jc, a.lda, a.n - rk,
                                        0, PB, lds, v);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -936,6 +984,12 @@ static std::atomic<int> g_potrf_mode{0};
 // apgp_potrf_mode(mode | 16) switches them off (A/B and bit-identity tests), plain modes switch them on again
 #define POTRF_PAIR_MIN_TB 24
 static std::atomic<int> g_potrf_pairs{1};
+// eighths of a wide step's eligible tiles left to the narrow step after it (PotrfArgs::defer8); apgp_potrf_mode(mode | 32)
+// switches the deferral off
+#ifndef POTRF_DEFER8
+#define POTRF_DEFER8 4
+#endif
+static std::atomic<int> g_potrf_defer8{POTRF_DEFER8};
 static std::atomic<long long> g_potrf_fallbacks{0};
 // Back-off after a persistent launch gave up (its workgroups were not all resident within the timeout: another stream
 // or process holds CUs): every such call costs the timeout AND the re-run, so the next PP_BACKOFF_BASE << (streak - 1)
@@ -963,9 +1017,10 @@ static void pp_backoff_report(int dev, bool gave_up) {
     g_pp_skip[dev].store(skip);
 }
 extern "C" int apgp_potrf_mode(int mode) {
-    if (mode < 0) return g_potrf_mode.load() | (g_potrf_pairs.load() ? 0 : 16);
-    if ((mode & ~16) > 3) { apgp_set_error("apgp_potrf_mode: bad argument: mode 0 .. 3 (+ 16: no paired trailing updates)"); return -1; }
-    const int prev = g_potrf_mode.exchange(mode & 15) | (g_potrf_pairs.exchange((mode & 16) ? 0 : 1) ? 0 : 16);
+    if (mode < 0) return g_potrf_mode.load() | (g_potrf_pairs.load() ? 0 : 16) | (g_potrf_defer8.load() ? 0 : 32);
+    if ((mode & ~48) > 3) { apgp_set_error("apgp_potrf_mode: bad argument: mode 0 .. 3 (+ 16: no paired trailing updates, + 32: no deferred tiles)"); return -1; }
+    const int prev = g_potrf_mode.exchange(mode & 15) | (g_potrf_pairs.exchange((mode & 16) ? 0 : 1) ? 0 : 16) |
+                     (g_potrf_defer8.exchange((mode & 32) ? 0 : POTRF_DEFER8) ? 0 : 32);
     for (int d = 0; d < 64; ++d) { g_pp_skip[d].store(0); g_pp_streak[d].store(0); }   // (an explicit mode ends any back-off)
     return prev;
 }
@@ -1025,7 +1080,7 @@ static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, in
     PersistArgs q;
     PotrfArgs& a = q.a;
     a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.j0 = 0; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
-    a.mail = mail; a.seq = seq; a.batch_A = 0; a.batch_rhs = n; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0;
+    a.mail = mail; a.seq = seq; a.batch_A = 0; a.batch_rhs = n; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0; a.defer8 = 0; a.deferred8 = 0;
     a.zoff = nb_all * (long long)(PB * PB); a.batch_dscr = a.zoff + nb_all * PB;
     a.dscr = apgp_stream_scratch(0, s, (size_t)a.batch_dscr);
     bool fresh = false;
@@ -1108,7 +1163,7 @@ static int potrf_run_locked(double* A, int64_t n, int64_t lda, int64_t batch, in
     a.A = A; a.rhs = z; a.n = n; a.lda = lda; a.shift = 0.0; a.info = info_dev; a.out5 = out5;
     a.mail = mail; a.seq = seq;
     a.batch_A = batch_A; a.batch_rhs = n;
-    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0;
+    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0; a.defer8 = 0; a.deferred8 = 0;
     if (z && !pre_init)
         for (int64_t b = 0; b < batch; ++b)
             hipLaunchKernelGGL(potrf_rhs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, shifts[b],
@@ -1133,14 +1188,30 @@ static int potrf_run_locked(double* A, int64_t n, int64_t lda, int64_t batch, in
     // steps are paired (narrow, wide) while the trailing matrix is large; the step that hands over to the persistent
     // launch -- and the step before an unpaired one -- is never a narrow one (its deferred tiles would be missing)
     const long long last = (stop_at > 0 ? stop_at : nb - 1) - 1;         // last step launched here
-    int prev_mode = 0;
+    // a wide step defers part of its tiles to the narrow step that follows it, if one does (PotrfArgs::defer8)
+    const bool pairs = g_potrf_pairs.load() != 0;
+    const int defer_cfg = g_potrf_defer8.load();
+    auto narrow_at = [&](long long jb_) {                                  // would step jb_ be a narrow one (after a wide one)?
+        const long long tb_ = (n - (jb_ * PB + PB) + PB - 1) / PB;
+        return pairs && jb_ + 1 < nb && tb_ >= POTRF_PAIR_MIN_TB && jb_ + 1 <= last;
+    };
+    int prev_mode = 0, prev_defer = 0;
     for (long long jb = 0; jb + 1 < nb; ++jb) {
         a.j0 = jb * PB;
         a.no_panel = (stop_at > 0 && jb == stop_at - 1) ? 1 : 0;
         const long long tb = (n - (a.j0 + PB) + PB - 1) / PB;
-        a.pair_mode = prev_mode == 1 ? 2 : ((g_potrf_pairs.load() && tb >= POTRF_PAIR_MIN_TB && jb + 1 <= last) ? 1 : 0);
+        a.pair_mode = prev_mode == 1 ? 2 : ((pairs && tb >= POTRF_PAIR_MIN_TB && jb + 1 <= last) ? 1 : 0);
         prev_mode = a.pair_mode;
-        const long long tiles = a.pair_mode == 1 ? tb + (tb - 1) : tb + tb * (tb - 1) / 2;
+        a.deferred8 = a.pair_mode == 1 ? prev_defer : 0;
+        const long long E = (tb - 3) * (tb - 2) / 2;                       // this step's eligible triangle (from block (3, 3) on)
+        a.defer8 = 0;
+        if (a.pair_mode == 2 && !a.no_panel && tb >= 4 && narrow_at(jb + 1)) a.defer8 = defer_cfg;
+        prev_defer = a.defer8;
+        const long long Eprev = (tb - 2) * (tb - 1) / 2;                   // the previous wide step's, one block larger
+        long long tiles;
+        if (a.pair_mode == 1) tiles = tb + (tb - 1) + potrf_deferred_count(Eprev, a.deferred8);
+        else if (a.defer8 > 0) tiles = tb + (2 * tb - 3) + (E - potrf_deferred_count(E, a.defer8));
+        else tiles = tb + tb * (tb - 1) / 2;
         hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(256), 0, s, a);
         if (a.no_panel) {
             APGP_CHECK_LAUNCH();

@@ -178,7 +178,9 @@ int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* kern /*host*/
  * trailing 44 x 44 blocks); 1 = a launch per step only; 2 = persistent launch that gives up
  * at once (exercises the fallback); 3 = persistent launch wherever it can run (64 < n <= 4096).
  * + 16: the launch-per-step path without its paired trailing updates (two block columns per
- * pass over a tile while the trailing matrix is large) -- all variants return the same bits.
+ * pass over a tile while the trailing matrix is large); + 32: without the deferred tiles (a paired
+ * wide step leaves half of its far tiles to the narrow step after it, whose launch is a latency
+ * chain on a few workgroups) -- all variants return the same bits.
  * mode < 0 only queries; setting a mode also ends any back-off.  Returns the previous mode (-1: bad argument).
  * apgp_potrf_fallbacks: evaluations re-run on the multi-launch path so far (process-wide);
  * apgp_potrf_backoff_skips: evaluations that skipped the persistent launch while backing off. */

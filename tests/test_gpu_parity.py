@@ -1077,7 +1077,7 @@ def test_hybrid_cholesky_bit_identical_to_multi_launch(n, D, dup, lib_loaded):
         assert i0 > 0
 
 
-@pytest.mark.parametrize("n,D", [(1700, 3), (3000, 8), (5000, 5)])
+@pytest.mark.parametrize("n,D", [(1700, 3), (1857, 2), (3000, 8), (4096, 8), (5000, 5), (6100, 4)])
 def test_paired_trailing_updates_bit_identical(n, D, lib_loaded):
     """Launch-per-step Cholesky with its paired trailing updates (a narrow step applies its block column to the first two
     tile columns, the wide step after it applies both block columns to every other tile in one pass, each product
@@ -1089,6 +1089,12 @@ def test_paired_trailing_updates_bit_identical(n, D, lib_loaded):
     L1, z1, o1, i1 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.25, 1)
     L0, z0, o0, i0 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.25, 17)
     assert i0 == i1 == 0 and np.array_equal(o0, o1) and torch.equal(L0, L1) and torch.equal(z0, z1)
+    # ... and with the pairs but without the deferred tiles (round 5: a wide step leaves half of its far tiles to the
+    # narrow step after it, mode + 32 switches that off), launch-per-step and default plan
+    for mode in (1 + 32, 0 + 32):
+        L2, z2, o2, i2 = _nll_eval_raw(lib, torch, X_d, y_d, n, ks, 0.25, mode)
+        assert i2 == 0 and np.array_equal(o2, o1) and torch.equal(L2, L1) and torch.equal(z2, z1)
+    assert lib.apgp_potrf_mode(-1) == 0
 
 
 def test_persistent_cholesky_two_streams_at_once(lib_loaded):

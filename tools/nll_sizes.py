@@ -1,6 +1,7 @@
 """apgp_nll_eval (Gram + Cholesky + summary, default path) timed back to back over a range of training-set sizes; with a
 library path as the first argument an experimental build is timed instead of the shipped one (A/B of kernel variants).
-Usage (GPU box): python tools/nll_sizes.py [path/to/libapgp.so]"""
+NLL_MODE=<m> sets apgp_potrf_mode(m) first.
+Usage (GPU box): [NLL_MODE=m] python tools/nll_sizes.py [path/to/libapgp.so]"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,6 +9,7 @@ from approxposterior_amd import _lib
 if len(sys.argv) > 1: _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from approxposterior_amd import gp as agp
 lib = _lib.load(); dev = torch.device("cuda:0")
+if os.environ.get("NLL_MODE"): lib.apgp_potrf_mode(int(os.environ["NLL_MODE"]))     # e.g. 1 = launch per step, 32 = no deferred tiles
 out = []
 for n in (512, 800, 1152, 1600, 2048, 2560, 3072, 3712, 4096):
     D = 8; rs = np.random.RandomState(n)
@@ -23,4 +25,4 @@ for n in (512, 800, 1152, 1600, 2048, 2560, 3072, 3712, 4096):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(40): lib.apgp_nll_eval(*args)
     torch.cuda.synchronize(); out.append("%d: %.3f" % (n, (time.perf_counter() - t0) / 40 * 1e3))
-print(sys.argv[1:] or "shipped", " | ".join(out), "fallbacks", lib.apgp_potrf_fallbacks())
+print(sys.argv[1:] or "shipped", "mode", os.environ.get("NLL_MODE", "0"), " | ".join(out), "fallbacks", lib.apgp_potrf_fallbacks())
