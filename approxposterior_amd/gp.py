@@ -495,9 +495,12 @@ class GP(object):
         ApproxPosterior.findNextPoint has at hand when it appends a design point
         (approx.py:693-717).  The factor is then extended row by row in O(N^2) per
         new point instead of refactorised in O(N^3)."""
+        x_in = x
         x = self.parse_samples(x)
         if x.shape[1] > _lib.MAX_DIM:
             raise ValueError("at most %d dimensions are supported" % _lib.MAX_DIM)
+        if x is x_in or (isinstance(x_in, np.ndarray) and np.shares_memory(x, x_in)):
+            x = x.copy()              # the object owns its training set: a caller who edits x in place afterwards is not seen
         same_x = self._x is not None and self._x.shape == x.shape and np.array_equal(self._x, x)
         self._x = x
         self._nllMemo = None          # gpUtils._nll's table of evaluated points belongs to the old training set

@@ -491,3 +491,27 @@ def test_repeated_evaluation_plan_equals_the_generic_path():
     ga._nllMemo = gb._nllMemo = None
     gb._nll_plan = None
     assert gpUtils._nll(p0, ga, y, None) == gpUtils._nll(p0, gb, y, None)
+
+
+def test_compute_owns_its_training_set():
+    """``GP.compute(x)`` keeps a COPY of x (george: the object owns its training set): editing the caller's array in
+    place and computing again must be seen as a new training set (the device copy of x is re-uploaded), and edits
+    without a compute must not leak into later evaluations."""
+    go, agp = _mods()
+    n, D = 300, 3
+    X, y = _case(n, D, 21)
+
+    def fresh(Xc):
+        g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(D, 8.0), ndim=D), fit_mean=True, mean=float(np.median(y)),
+                   white_noise=-12, fit_white_noise=False)
+        g.compute(Xc)
+        return g
+    Xu = np.ascontiguousarray(X.copy())
+    g = fresh(Xu)
+    ll0 = g.log_likelihood(y)
+    Xu[5] += 0.25                                   # in place, no compute: the GP still describes the old set
+    p = g.get_parameter_vector()
+    g.set_parameter_vector(p)                        # (dirty: the next log_likelihood refactorises from the GP's own x)
+    assert abs(g.log_likelihood(y) - ll0) <= 1e-12 * abs(ll0)    # (z rides along the factorisation here: last bits may differ)
+    g.compute(Xu)                                    # the same object, new contents
+    assert g.log_likelihood(y) == fresh(Xu.copy()).log_likelihood(y) != ll0
