@@ -20,6 +20,7 @@
 #include "scratch.h"
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -654,6 +655,237 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
             q.mail[4] = (double)inf;
             __hip_atomic_store((long long*)(q.mail + 5), q.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same for 64 < n <= 128 (round 5; the README configuration grows from N = 50 to 90): TWO block columns in ONE
+// single-workgroup launch -- the Gram tiles (0,0) and (1,0) into LDS, block column 0 by the panel step's three
+// roles (panel_factor_wave + panel_helper_wave, panel_solve_wave for rows 64 ..: the code of potrf_panel_kernel), the
+// update of block (1,1) by the product of the launch-per-step path (apgp_gemm64_tile on the rows just written, the
+// block's own Gram values generated in the accumulators' layout), block column 1 by the panel step again, and
+// potrf_finish_kernel's summary in its order (two "virtual wavefronts" of 64 diagonal entries).  Every value is computed
+// by the code and in the order of gram + panel + step + finish: the same bits, without three launch boundaries
+// (51 -> ~35 us at N = 65 .. 128).  The factor goes straight into K (no sibling workgroups: no scratch blocks), z into q.z.
+// ---------------------------------------------------------------------------
+template <int DPAD>
+static constexpr size_t nll_two_lds_doubles() {
+    return (size_t)PB * (PB + 2) + GEMM64_LDS_DOUBLES + (size_t)2 * PB * (DPAD + 1) + 5 * PB + APGP_EXP_TAB_N + 2;
+}
+template <int DPAD>
+__global__ __launch_bounds__(256) void nll_two_kernel(NllSmallArgs q) {
+    extern __shared__ __attribute__((aligned(16))) double two_lds[];
+    double (*Ls)[PB + 2] = (double (*)[PB + 2])two_lds;                          // the block being factorised
+    double* gl = two_lds + PB * (PB + 2);                                         // Gram tile (1,0), later the product's buffers
+    double (*T10)[PB + 2] = (double (*)[PB + 2])gl;
+    double (*xs)[DPAD + 1] = (double (*)[DPAD + 1])(gl + GEMM64_LDS_DOUBLES);      // scaled coordinates of all n points
+    double* invd = (double*)(xs + 2 * PB);
+    double* zblk = invd + PB;
+    double* dsave = zblk + PB;                                                    // diagonal / z of block column 0 (for the summary)
+    double* zsave = dsave + PB;
+    double* rhs1 = zsave + PB;                                                    // running right-hand side of rows 64 ..
+    double* etab = rhs1 + PB;
+    int* prog_p = (int*)(etab + APGP_EXP_TAB_N);
+    int* hflag_p = prog_p + 1;
+    static_assert(GEMM64_LDS_DOUBLES >= PB * (PB + 2), "the Gram tile fits the product's buffers");
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int n = (int)q.n, bs1 = n - PB;                                         // rows of block column 1: 1 .. 64
+    apgp_exp_tab_load(etab);
+    if (t == 0) { *prog_p = 0; *hflag_p = 0; *(unsigned int*)q.info = 0xffffffffu; }
+    for (int e = t; e < 2 * PB * DPAD; e += 256) {
+        const int r = e / DPAD, d = e % DPAD;
+        xs[r][d] = (r < n && d < q.kc.ndim) ? q.X[(long long)r * q.kc.ndim + d] * q.kc.sc[d] : 0.0;
+    }
+    __syncthreads();
+    // Gram tiles (0,0) (lower triangle) and (1,0) (rows past n: zero): thread = (column c, rows g, g + 4, ...)
+    {
+        const int c = lane, g = wv;
+        double xc[DPAD];
+#pragma unroll
+        for (int d = 0; d < DPAD; ++d) xc[d] = xs[c][d];
+        for (int r = g; r < PB; r += 4) {
+            Ls[r][c] = c <= r ? apgp_gram_value<DPAD>(xs[r], xc, q.kc, r == c, etab) : 0.0;
+            T10[r][c] = r < bs1 ? apgp_gram_value<DPAD>(xs[PB + r], xc, q.kc, false, etab) : 0.0;
+        }
+    }
+    __syncthreads();
+    PotrfArgs a;
+    a.A = q.K; a.rhs = q.z; a.n = q.n; a.lda = q.n; a.j0 = 0; a.shift = 0.0; a.info = q.info; a.out5 = nullptr;
+    a.mail = nullptr; a.seq = 0;
+    a.dscr = nullptr; a.batch_dscr = 0; a.zoff = 0; a.batch_A = 0; a.batch_rhs = 0;
+    a.abort_word = nullptr; a.abort_id = 0; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0; a.defer8 = 0; a.deferred8 = 0;
+    // ---------------- block column 0: potrf_panel_kernel's roles ----------------
+    if (wv == 0) {
+        double ar[PB];
+        const double ri = q.y[lane] - q.shift;
+#pragma unroll
+        for (int k = 0; k < PB; k += 2) {
+            const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
+            ar[k] = k <= lane ? v.x : ((k == lane) ? 1.0 : 0.0);
+            ar[k + 1] = k + 1 <= lane ? v.y : ((k + 1 == lane) ? 1.0 : 0.0);
+        }
+        panel_factor_wave(a, 0, PB, lane, ar, ri, Ls, invd, zblk, prog_p, hflag_p, 0, 1);
+        dsave[lane] = Ls[lane][lane];
+        zsave[lane] = zblk[lane];
+    } else if (wv == 2) {
+        panel_helper_wave(PB, lane, Ls, prog_p, hflag_p);
+    } else if (wv == 1) {
+        const long long row = PB + lane;
+        const bool has_row = lane < bs1;
+        double x[PB];
+#pragma unroll
+        for (int k = 0; k < PB; k += 2) {
+            const f64x2 v = *(const f64x2*)(&T10[lane][k]);
+            x[k] = has_row ? v.x : 0.0;
+            x[k + 1] = has_row ? v.y : 0.0;
+        }
+        if (has_row) q.z[row] = q.y[row] - q.shift;                              // (the running right-hand side of this row)
+        PANEL_FENCE();
+        panel_solve_wave(a, 0, row, has_row, lane, x, Ls, invd, zblk, prog_p, 0);
+        rhs1[lane] = has_row ? q.z[row] : 0.0;                                   // (this lane's own store)
+    }
+    __threadfence();                          // (L(1,0) is read back from memory by all four wavefronts)
+    __syncthreads();
+    // ---------------- block (1,1) -= L(1,0) L(1,0)^T: potrf_step_kernel's first tile (bi = 0) ----------------
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+    double v[2][2][4];
+    {
+        double cin[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                double xc[DPAD];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, r);
+#pragma unroll
+                    for (int d = 0; d < DPAD; ++d) xc[d] = xs[PB + lc][d];
+                    cin[i][j][r] = (lr < bs1 && lc < bs1 && lc <= lr) ? apgp_gram_value<DPAD>(xs[PB + lr], xc, q.kc, lr == lc, etab) : 0.0;
+                    v[i][j][r] = 0.0;
+                }
+            }
+        apgp_gemm64_tile<false, false>(q.K + (long long)PB * q.n, q.n, bs1, q.K + (long long)PB * q.n, q.n, bs1, 0, PB, gl, v);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][j][r] = cin[i][j][r] - v[i][j][r];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ls[wr + 16 * i + apgp_mma16_row(lane)][wc + 16 * j + apgp_mma16_col(lane, r)] = v[i][j][r];
+    if (t == 0) { *prog_p = 0; *hflag_p = 0; }
+    __syncthreads();
+    // ---------------- block column 1: the panel step of potrf_step_kernel ----------------
+    if (wv == 2) {
+        panel_helper_wave(bs1, lane, Ls, prog_p, hflag_p);
+        return;
+    }
+    if (wv != 0) return;
+    {
+        double rowv[PB];
+        const double rhs_i = lane < bs1 ? rhs1[lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < PB; k += 2) {
+            const f64x2 qv = *(const f64x2*)(&Ls[lane][k]);
+            rowv[k] = (lane < bs1 && k <= lane) ? qv.x : ((k == lane) ? 1.0 : 0.0);
+            rowv[k + 1] = (lane < bs1 && k + 1 <= lane) ? qv.y : ((k + 1 == lane) ? 1.0 : 0.0);
+        }
+        panel_factor_wave(a, PB, bs1, lane, rowv, rhs_i, Ls, invd, zblk, prog_p, hflag_p, 0, 1);
+    }
+    // fit summary: potrf_finish_kernel's operations in its order -- virtual wavefront 0 = entries 0 .. 63, 1 = 64 .. n - 1,
+    // each through the butterfly, the sixteen partials summed in order (fourteen of them zeros / infinities)
+    double p_sl[2], p_zz[2], p_mn[2], p_mx[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double sl = 0.0, mn = INFINITY, mx = -INFINITY, zz = 0.0;
+        if (h == 0 || lane < bs1) {
+            const double d = h == 0 ? dsave[lane] : Ls[lane][lane];
+            const double zv = h == 0 ? zsave[lane] : zblk[lane];
+            sl += log(d);
+            mn = fmin(mn, d);
+            mx = fmax(mx, d);
+            zz = fma(zv, zv, zz);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            sl += __shfl_xor(sl, o);
+            zz += __shfl_xor(zz, o);
+            mn = fmin(mn, __shfl_xor(mn, o));
+            mx = fmax(mx, __shfl_xor(mx, o));
+        }
+        p_sl[h] = sl; p_zz[h] = zz; p_mn[h] = mn; p_mx[h] = mx;
+    }
+    if (lane == 0) {
+        double sl = 0.0, zz = 0.0, mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { sl += p_sl[h]; zz += p_zz[h]; mn = fmin(mn, p_mn[h]); mx = fmax(mx, p_mx[h]); }
+        int inf = *q.info;                      // (this wavefront's own atomicMin, if any, precedes the read)
+        if ((unsigned int)inf == 0xffffffffu) inf = 0;
+        *q.info = inf;
+        q.out5[0] = 2.0 * sl;
+        q.out5[1] = mn;
+        q.out5[2] = mx;
+        q.out5[3] = zz;
+        q.out5[4] = (double)inf;
+        if (q.mail) {
+            q.mail[0] = 2.0 * sl;
+            q.mail[1] = mn;
+            q.mail[2] = mx;
+            q.mail[3] = zz;
+            q.mail[4] = (double)inf;
+            __hip_atomic_store((long long*)(q.mail + 5), q.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// the kernel's dynamic LDS exceeds 64 KiB: the attribute is set once per device and instantiation
+template <int DPAD>
+static int nll_two_launch_t(const NllSmallArgs& q, hipStream_t s) {
+    static bool done[64] = {false};
+    static std::mutex mu;
+    const int lds = (int)(nll_two_lds_doubles<DPAD>() * sizeof(double));
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        apgp_set_error("apgp_nll_eval: hipGetDevice failed");
+        return -2;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done[dev]) {
+            const hipError_t e = hipFuncSetAttribute((const void*)nll_two_kernel<DPAD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) {
+                apgp_set_error("apgp_nll_eval: hipFuncSetAttribute(%d B of LDS) failed on device %d: %s", lds, dev, hipGetErrorString(e));
+                return -2;
+            }
+            done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(nll_two_kernel<DPAD>, dim3(1), dim3(256), lds, s, q);
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+static int nll_two_launch(const double* X, int64_t n, const apgp_kernel_t* kern, const double* y, double mean,
+                          double* K, double* z, int32_t* info_dev, double* out5_dev, hipStream_t s,
+                          double* mail = nullptr, long long seq = 0) {
+    NllSmallArgs q;
+    q.mail = mail; q.seq = seq;
+    if (apgp_make_kernconst(kern, &q.kc) != 0) {
+        apgp_set_error("apgp_nll_eval: bad argument: kernel parameters");
+        return -1;
+    }
+    q.X = X; q.y = y; q.K = K; q.z = z; q.info = info_dev; q.out5 = out5_dev; q.n = n; q.shift = mean;
+    switch (q.kc.dpad) {
+        case 2: return nll_two_launch_t<2>(q, s);
+        case 4: return nll_two_launch_t<4>(q, s);
+        case 8: return nll_two_launch_t<8>(q, s);
+        case 16: return nll_two_launch_t<16>(q, s);
+        default: return nll_two_launch_t<32>(q, s);
     }
 }
 
@@ -1300,6 +1532,10 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
     if (n <= PB && y) {
         // one single-workgroup launch (nll_small_kernel): same values, two launch boundaries fewer
         rc = nll_small_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s, mail ? mb->dev : nullptr, seq);
+        if (rc != 0) return rc;
+    } else if (n <= 2 * PB && y && (g_potrf_mode.load() == 0 || g_potrf_mode.load() == 3)) {
+        // two block columns, still one single-workgroup launch (nll_two_kernel; modes 1 / 2 keep the separate launches)
+        rc = nll_two_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s, mail ? mb->dev : nullptr, seq);
         if (rc != 0) return rc;
     } else {
         // three launches fewer than the separate calls: the Gram launch initialises the right-hand side

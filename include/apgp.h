@@ -141,7 +141,8 @@ int apgp_release_scratch(void* stream);
  * apgp_gram -> apgp_potrf (z = L^-1 (y - mean) riding along) -> apgp_fit_summary, and the
  * 5-value record of apgp_fit_summary in out5_host when the call returns (the call
  * synchronises with its own work only).  n <= 64: ONE single-workgroup launch (Gram block
- * in LDS, register-resident factorisation, summary; same bits as the separate calls).
+ * in LDS, register-resident factorisation, summary; same bits as the separate calls); 64 < n <= 128
+ * (with y): both block columns in one single-workgroup launch, same bits again.
  * The record travels through 64 bytes of pinned, device-mapped host memory kept per
  * (device, stream): the last kernel's last lane writes it and a sequence word, the host
  * polls the word (400 us, then an ordinary stream synchronisation) -- no D2H copy; if

@@ -515,3 +515,60 @@ def test_compute_owns_its_training_set():
     assert abs(g.log_likelihood(y) - ll0) <= 1e-12 * abs(ll0)    # (z rides along the factorisation here: last bits may differ)
     g.compute(Xu)                                    # the same object, new contents
     assert g.log_likelihood(y) == fresh(Xu.copy()).log_likelihood(y) != ll0
+
+
+@pytest.mark.parametrize("n,D", [(65, 2), (66, 3), (90, 2), (100, 8), (127, 5), (128, 16), (97, 24), (128, 1)])
+def test_two_block_column_fused_evaluation(n, D):
+    """64 < n <= 128 (the README example's sizes, N = 50 -> 90): ``apgp_nll_eval`` is ONE single-workgroup launch (Gram tiles in
+    LDS, both block columns by the panel step's code, the update by the launch-per-step product, the summary in the finish
+    kernel's order).  Bit-identical to the separate launches (mode 1): factor, z, record, LAPACK info -- also for a matrix that
+    is not positive definite in either block column -- and equal to LAPACK / the oracle within fp64 tolerances."""
+    import torch
+    from scipy.linalg import cholesky, solve_triangular
+    from approxposterior_amd import _lib
+    go, agp = _mods()
+    lib = _lib.load()
+    X, y = _case(n, D, 7 * n + D)
+    mean = float(np.median(y))
+
+    def run(mode, Xc, wn=-12.0):
+        g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(D, 8.0), ndim=D), fit_mean=True, mean=mean, white_noise=wn,
+                   fit_white_noise=False)
+        g._x = Xc; g._yerr2 = 0.0
+        ks = g._kernel_struct()
+        X_d, y_d = torch.from_numpy(Xc).cuda(), torch.from_numpy(y).cuda()
+        K = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+        z = torch.full((n,), np.nan, dtype=torch.float64, device="cuda")
+        info = torch.empty(1, dtype=torch.int32, device="cuda")
+        o5 = torch.empty(5, dtype=torch.float64, device="cuda")
+        o = np.full(5, np.nan)
+        lib.apgp_potrf_mode(mode)
+        try:
+            for _ in range(2):                   # (twice in the same buffers: nothing may leak from one call into the next)
+                rc = lib.apgp_nll_eval(X_d.data_ptr(), n, ctypes.byref(ks), y_d.data_ptr(), mean, K.data_ptr(), z.data_ptr(),
+                                       info.data_ptr(), o5.data_ptr(), o.ctypes.data, None)
+                assert rc == 0, lib.apgp_last_error()
+            torch.cuda.synchronize()
+        finally:
+            lib.apgp_potrf_mode(0)
+        assert o.tobytes() == o5.cpu().numpy().tobytes()
+        return K.clone(), z.clone(), o, int(info.item())
+    K0, z0, o0, i0 = run(0, X)
+    K1, z1, o1, i1 = run(1, X)
+    assert i0 == i1 == 0 and o0.tobytes() == o1.tobytes()
+    assert torch.equal(torch.tril(K0), torch.tril(K1)) and torch.equal(z0, z1)
+    assert float(torch.triu(K0, 1).abs().max()) == 0.0
+    ko = go.ExpSquaredKernel(np.full(D, 8.0), ndim=D)
+    Ko = ko.get_value(X)
+    Ko[np.diag_indices(n)] += np.exp(-12.0)
+    Lo = cholesky(Ko, lower=True)
+    zo = solve_triangular(Lo, y - mean, lower=True)
+    assert np.abs(torch.tril(K0).cpu().numpy() - Lo).max() <= 1e-11 * np.abs(Lo).max()
+    assert np.abs(z0.cpu().numpy() - zo).max() <= 1e-9 * np.abs(zo).max()
+    assert abs(o0[0] - 2.0 * np.sum(np.log(np.diag(Lo)))) <= 1e-11 * abs(o0[0]) and abs(o0[3] - zo @ zo) <= 1e-11 * (zo @ zo)
+    # (nearly) singular: a tripled point in block column 0, then in block column 1 (no white noise to speak of)
+    for dup in (10, n - 2):
+        Xd = X.copy(); Xd[dup] = Xd[dup - 1]; Xd[dup + 1] = Xd[dup - 1]
+        a0, a1 = run(0, Xd, wn=-60.0), run(1, Xd, wn=-60.0)
+        assert a0[3] == a1[3] and a0[2][4] == a1[2][4] == a0[3]        # (the same LAPACK info, whatever rounding makes of it)
+        assert a0[2].tobytes() == a1[2].tobytes()
