@@ -189,15 +189,25 @@ class ApproxPosterior(object):
             pts = pts.reshape(-1, self.ndim)
         logp = np.full(len(pts), -np.inf)
         blob = np.full(len(pts), np.nan)
-        prior = np.array([self._lnprior(p) if np.any(np.isfinite(p)) else -np.inf for p in pts],
-                         dtype=float)
+        fin = np.isfinite(pts)
+        some = fin.any(axis=1)                      # (a walker without a finite coordinate is rejected before the prior)
+        batch = getattr(self._lnprior, "batch", None)
+        if batch is not None and some.all():
+            # the prior's vectorised twin (likelihood.py): one call per ensemble instead of one per walker
+            prior = np.asarray(batch(pts), dtype=float).reshape(len(pts))
+        else:
+            prior = np.array([self._lnprior(p) if ok else -np.inf for p, ok in zip(pts, some)], dtype=float)
         rows = np.flatnonzero(np.isfinite(prior))
         if rows.size:
-            finite = np.all(np.isfinite(pts[rows]), axis=1)
-            mean = self.gp.predict(self.y, np.where(np.isfinite(pts[rows]), pts[rows], 0.0),
-                                   return_cov=False, return_var=False)
-            keep = rows[finite & np.isfinite(mean)]
-            logp[keep] = mean[finite & np.isfinite(mean)]
+            if rows.size == len(pts) and fin.all():
+                finite, sel = np.ones(len(pts), dtype=bool), pts                      # (the usual half-step: nothing to mask)
+            else:
+                finite = np.all(fin[rows], axis=1)
+                sel = np.where(fin[rows], pts[rows], 0.0)
+            mean = self.gp.predict(self.y, sel, return_cov=False, return_var=False)
+            ok = finite & np.isfinite(mean)
+            keep = rows[ok]
+            logp[keep] = mean[ok]
             blob[keep] = prior[keep]
         return logp, blob
 

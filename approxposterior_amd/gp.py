@@ -336,6 +336,26 @@ class _NllPlan(object):
                      scr[0].data_ptr(), scr[1].data_ptr(), o.ctypes.data, ctypes.c_void_p(stream)]
 
 
+class _MeanPlan(object):
+    """The arguments of one small ``apgp_predict_mean_host`` call, kept for the next (``GP._predict_mean_again``)."""
+    __slots__ = ("xs", "work", "ybytes", "n", "ndim", "mean", "max_m", "stream", "dev_index", "current_device", "raw_stream",
+                 "ks", "ks_ref", "fn", "xs_ptr", "work_ptr", "stream_arg")
+
+    def __init__(self, gp, torch, dev, stream, ks, yv, n):
+        self.xs, self.work = gp._xs, gp._mean_work
+        self.ybytes = yv.tobytes()
+        self.n, self.ndim = n, int(ks.ndim)
+        self.mean = float(gp.mean.value)
+        self.max_m = min(4096, gp._mean_work.numel() // (self.ndim + 1))
+        self.stream, self.dev_index = stream, dev.index
+        self.current_device = torch.cuda.current_device
+        self.raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self.ks, self.ks_ref = ks, ctypes.byref(ks)
+        self.fn = gp._rt()[2].apgp_predict_mean_host
+        self.xs_ptr, self.work_ptr = gp._xs.data_ptr(), gp._mean_work.data_ptr()
+        self.stream_arg = ctypes.c_void_p(stream)
+
+
 # ---------------------------------------------------------------------------
 # GP
 # ---------------------------------------------------------------------------
@@ -383,6 +403,7 @@ class GP(object):
         self._p1_work = getattr(self, "_p1_work", None)
         self._nll_scratch = getattr(self, "_nll_scratch", None)
         self._nll_plan = None     # the arguments of the last _nll evaluation, ready for the next (_factor_again)
+        self._mean_plan = None    # ... of the last small mean-only prediction (_predict_mean_again)
         self.cond_estimate = None
         self.log_determinant = None
 
@@ -942,6 +963,10 @@ class GP(object):
 
     # -- predict (george GP.predict) ----------------------------
     def predict(self, y, t, return_cov=True, return_var=False, cache=True, **kwargs):
+        if not return_var and not return_cov and self._mean_plan is not None:
+            mu = self._predict_mean_again(y, t)
+            if mu is not None:
+                return mu
         self.recompute()
         xs = self.parse_samples(t)
         if return_cov and not return_var:
@@ -951,6 +976,28 @@ class GP(object):
             return mu
         mu, var = self._sweep(y, xs, kind=None, want=("mu", "var"))
         return mu, var
+
+    def _predict_mean_again(self, y, t):
+        """The mean at a few more points for the model, y and stream of the previous such call (the walker ensembles of
+        ``ApproxPosterior._gpllBatch``, approx.py:148-189 batched: 4e4 calls per chain in the README example) -- the previous
+        call's arguments with new points, none of the generic path's checks that cannot have changed.  None: something
+        differs, the caller takes the generic path."""
+        plan = self._mean_plan
+        if (not self._computed or self.kernel.dirty or plan.xs is not self._xs or plan.work is not self._mean_work
+                or plan.mean != self.mean.value or type(y) is not np.ndarray or y.dtype != np.float64
+                or type(t) is not np.ndarray or t.dtype != np.float64 or t.ndim != 2 or t.shape[1] != plan.ndim
+                or not t.flags.c_contiguous):
+            return None
+        m = t.shape[0]
+        if not 0 < m <= plan.max_m or y.size != plan.n or not y.flags.c_contiguous or y.tobytes() != plan.ybytes:
+            return None
+        cur = plan.current_device()
+        if cur != plan.dev_index or plan.raw_stream is None or plan.raw_stream(cur) != plan.stream:
+            return None
+        mu_h = np.empty(m, dtype=np.float64)
+        _lib.check(plan.fn(t.ctypes.data, m, plan.xs_ptr, plan.n, plan.ks_ref, plan.mean, mu_h.ctypes.data, plan.work_ptr,
+                           plan.stream_arg), "apgp_predict_mean_host")
+        return mu_h
 
     # -- the rest of george.GP's public surface (not called by approxposterior) ---------------
     def apply_inverse(self, y):
@@ -1095,6 +1142,8 @@ class GP(object):
                                                       ctypes.byref(ks), float(self.mean.value),
                                                       mu_h.ctypes.data, self._mean_work.data_ptr(), st),
                            "apgp_predict_mean_host")
+                # the sampler asks again, for another few points of the same model and y, 4e4 times per chain
+                self._mean_plan = _MeanPlan(self, torch, dev, st.value or 0, ks, y, n)
                 return (mu_h,)
             if need_var and kind is None and cand_device is None and len(cand) == 1:
                 # ONE candidate with variance: the reference's scalar utilities (utility.py:131,178,224), once per

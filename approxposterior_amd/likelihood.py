@@ -36,6 +36,12 @@ def rosenbrockLnprior(theta):
     return -np.inf if np.any(np.fabs(theta) > 5) else 0.0
 
 
+# A prior may carry a vectorised twin as its ``batch`` attribute -- f.batch(T) == [f(t) for t in T] for T of shape (W, D),
+# same values -- which the walker-ensemble log-probability (ApproxPosterior._gpllBatch) calls once per half-step instead
+# of f once per walker (the README example: 4e5 scalar calls, 1 s of its 6.6).  User priors without one work as before.
+rosenbrockLnprior.batch = lambda T: np.where(np.any(np.fabs(T) > 5, axis=1), -np.inf, 0.0)
+
+
 def rosenbrockSample(n=1, dim=2):
     """n draws from U[-5, 5]^dim, squeezed (likelihood.py:67-85)."""
     return np.random.uniform(low=-5, high=5, size=(n, dim)).squeeze()
@@ -66,6 +72,9 @@ def testBOFnLnPrior(theta):
     return -np.inf if (np.any(theta < -1) or np.any(theta > 2)) else 0.0
 
 
+testBOFnLnPrior.batch = lambda T: np.where(np.any(T < -1, axis=1) | np.any(T > 2, axis=1), -np.inf, 0.0)
+
+
 def sphereLnlike(theta):
     """-sum theta^2 (likelihood.py:180-199)."""
     theta = np.asarray(theta)
@@ -80,3 +89,6 @@ def sphereSample(n=1):
 def sphereLnprior(theta):
     """Uniform prior on [-2, 2]^D (likelihood.py:222-240)."""
     return -np.inf if np.any(np.fabs(theta) > 2) else 0.0
+
+
+sphereLnprior.batch = lambda T: np.where(np.any(np.fabs(T) > 2, axis=1), -np.inf, 0.0)

@@ -572,3 +572,56 @@ def test_two_block_column_fused_evaluation(n, D):
         a0, a1 = run(0, Xd, wn=-60.0), run(1, Xd, wn=-60.0)
         assert a0[3] == a1[3] and a0[2][4] == a1[2][4] == a0[3]        # (the same LAPACK info, whatever rounding makes of it)
         assert a0[2].tobytes() == a1[2].tobytes()
+
+
+def test_repeated_mean_prediction_plan_equals_the_generic_path():
+    """``GP.predict(y, t, return_cov=False, return_var=False)`` for a few points at a time (the walker ensembles of the host-loop
+    sampler) re-uses the previous call's arguments (``_predict_mean_again``): same values as the generic path, and anything
+    that changes the model, y, the mean or the stream goes back to it."""
+    import torch
+    go, agp = _mods()
+    n, D = 90, 2
+    X, y = _case(n, D, 13)
+    rs = np.random.RandomState(2)
+
+    def make():
+        g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(D, 3.0), ndim=D), fit_mean=True, mean=float(np.median(y)),
+                   white_noise=-12, fit_white_noise=False)
+        g.compute(X)
+        return g
+    ga, gb = make(), make()
+    used = 0
+    for it in range(8):
+        T = rs.uniform(-5, 5, size=(10 if it % 2 else 7, D))
+        used += ga._mean_plan is not None
+        gb._mean_plan = None
+        assert np.array_equal(ga.predict(y, T, return_cov=False, return_var=False),
+                              gb.predict(y, T, return_cov=False, return_var=False))
+    assert used >= 7
+    gpo = go.GP(kernel=go.ExpSquaredKernel(np.full(D, 3.0), ndim=D), fit_mean=True, mean=float(np.median(y)), white_noise=-12,
+                fit_white_noise=False)
+    gpo.compute(X)
+    T = rs.uniform(-5, 5, size=(10, D))
+    mo = gpo.predict(y, T, return_cov=False, return_var=False)
+    asum = np.abs(gpo._compute_alpha(y, False)).sum()
+    assert ga._mean_plan is not None and np.abs(ga.predict(y, T, return_cov=False, return_var=False) - mo).max() <= 1e-10 * asum
+    # another y: not the plan's
+    y2 = y + 0.5
+    gb._mean_plan = None
+    assert np.array_equal(ga.predict(y2, T, return_cov=False, return_var=False), gb.predict(y2, T, return_cov=False, return_var=False))
+    # new hyper-parameters: the model is dirty, the generic path refactorises
+    p = ga.get_parameter_vector() + 0.1
+    ga.set_parameter_vector(p); gb.set_parameter_vector(p)
+    gb._mean_plan = None
+    m1, m2 = ga.predict(y, T, return_cov=False, return_var=False), gb.predict(y, T, return_cov=False, return_var=False)
+    assert np.array_equal(m1, m2) and ga.computed
+    # a changed mean alone (george: a ConstantModel value), lists and float32 points: generic path, same values
+    ga.mean.value += 1.0; gb.mean.value += 1.0
+    gb._mean_plan = None
+    assert np.array_equal(ga.predict(y, T, return_cov=False, return_var=False), gb.predict(y, T, return_cov=False, return_var=False))
+    assert np.array_equal(ga.predict(y, T.tolist(), return_cov=False, return_var=False), ga.predict(y, T, return_cov=False, return_var=False))
+    # another current stream
+    with torch.cuda.stream(torch.cuda.Stream()):
+        m3 = ga.predict(y, T, return_cov=False, return_var=False)
+        torch.cuda.current_stream().synchronize()
+    assert np.array_equal(m3, ga.predict(y, T, return_cov=False, return_var=False))

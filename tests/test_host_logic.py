@@ -157,6 +157,34 @@ def test_gpll_guards_with_oracle_gp(golden_dir):
         assert lp[i] == want[0] or np.isclose(lp[i], want[0], rtol=1e-10)
 
 
+def test_vectorised_prior_twins_equal_the_scalar_priors():
+    """``prior.batch(T)`` (likelihood.py; what ``_gpllBatch`` calls once per walker ensemble) == ``[prior(t) for t in T]``
+    on random, boundary, NaN and infinite rows -- and ``_gpllBatch`` returns the same with a prior that has no twin."""
+    rs = np.random.RandomState(4)
+    for f, D, edge in ((lh.rosenbrockLnprior, 2, 5.0), (lh.sphereLnprior, 2, 2.0), (lh.rosenbrockLnprior, 8, 5.0),
+                       (lh.testBOFnLnPrior, 1, 2.0)):
+        T = rs.uniform(-1.3 * edge, 1.3 * edge, size=(400, D))
+        T[0, 0] = edge; T[1, 0] = -edge; T[2, -1] = np.nextafter(edge, np.inf); T[3, 0] = np.nan
+        T[4, -1] = np.inf; T[5, 0] = -np.inf; T[6] = 0.0; T[7, 0] = -1.0; T[8, 0] = np.nextafter(-1.0, -np.inf)
+        with np.errstate(all="ignore"):
+            want = np.array([f(t) for t in T], dtype=float)
+            got = np.asarray(f.batch(T), dtype=float)
+        assert got.shape == want.shape and np.array_equal(got, want)
+    np.random.seed(57)
+    theta, y = rosen_set(50, corners=True)
+    gp = oracle_default_gp(theta, y, False)
+    mk = lambda prior: approx.ApproxPosterior(theta=theta, y=y, gp=gp, lnprior=prior, lnlike=lh.rosenbrockLnlike,   # noqa: E731
+                                              priorSample=lh.rosenbrockSample, bounds=((-5, 5), (-5, 5)), algorithm="bape")
+    a1, a2 = mk(lh.rosenbrockLnprior), mk(lambda t: lh.rosenbrockLnprior(t))
+    assert getattr(a2._lnprior, "batch", None) is None
+    W = rs.uniform(-6, 6, size=(64, 2))
+    for pts in (W, W[:10], np.vstack([W[:5], [[np.nan, np.nan]], [[np.nan, 1.0]], [[np.inf, 0.0]]])):
+        with np.errstate(all="ignore"):
+            l1, b1 = a1._gpllBatch(pts)
+            l2, b2 = a2._gpllBatch(pts)
+        assert np.array_equal(l1, l2) and np.array_equal(b1, b2, equal_nan=True)
+
+
 def test_approxposterior_input_validation():
     th = np.zeros((3, 2)); y = np.zeros(3)
     kw = dict(lnprior=lh.rosenbrockLnprior, lnlike=lh.rosenbrockLnlike,
