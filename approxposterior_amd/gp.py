@@ -336,6 +336,28 @@ class _NllPlan(object):
                      scr[0].data_ptr(), scr[1].data_ptr(), o.ctypes.data, ctypes.c_void_p(stream)]
 
 
+class _OnePlan(object):
+    """The arguments of one ``apgp_predict1_host`` call (one candidate, mean + variance), kept for the next."""
+    __slots__ = ("xs", "p1", "factor", "solve", "ybytes", "n", "ndim", "mean", "ld", "stream", "dev_index", "current_device",
+                 "raw_stream", "ks", "ks_ref", "fn", "xs_ptr", "p1_ptr", "factor_ptr", "stream_arg")
+
+    def __init__(self, gp, torch, dev, stream, ks, yv, n, solve):
+        self.xs, self.p1 = gp._xs, gp._p1_work
+        self.solve = bool(solve)
+        self.factor = gp._L if solve else gp._work          # substitution against L, or the resident dense L^-1
+        self.ld = int(gp._ld) if solve else (n + 63) // 64 * 64
+        self.ybytes = yv.tobytes()
+        self.n, self.ndim = n, int(ks.ndim)
+        self.mean = float(gp.mean.value)
+        self.stream, self.dev_index = stream, dev.index
+        self.current_device = torch.cuda.current_device
+        self.raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self.ks, self.ks_ref = ks, ctypes.byref(ks)
+        self.fn = gp._rt()[2].apgp_predict1_host
+        self.xs_ptr, self.p1_ptr, self.factor_ptr = gp._xs.data_ptr(), gp._p1_work.data_ptr(), self.factor.data_ptr()
+        self.stream_arg = ctypes.c_void_p(stream)
+
+
 class _MeanPlan(object):
     """The arguments of one small ``apgp_predict_mean_host`` call, kept for the next (``GP._predict_mean_again``)."""
     __slots__ = ("xs", "work", "ybytes", "n", "ndim", "mean", "max_m", "stream", "dev_index", "current_device", "raw_stream",
@@ -404,6 +426,7 @@ class GP(object):
         self._nll_scratch = getattr(self, "_nll_scratch", None)
         self._nll_plan = None     # the arguments of the last _nll evaluation, ready for the next (_factor_again)
         self._mean_plan = None    # ... of the last small mean-only prediction (_predict_mean_again)
+        self._one_plan = None     # ... of the last single-candidate prediction with variance (_predict_one_again)
         self.cond_estimate = None
         self.log_determinant = None
 
@@ -967,6 +990,10 @@ class GP(object):
             mu = self._predict_mean_again(y, t)
             if mu is not None:
                 return mu
+        if return_var and self._one_plan is not None:
+            res = self._predict_one_again(y, t)
+            if res is not None:
+                return res
         self.recompute()
         xs = self.parse_samples(t)
         if return_cov and not return_var:
@@ -976,6 +1003,31 @@ class GP(object):
             return mu
         mu, var = self._sweep(y, xs, kind=None, want=("mu", "var"))
         return mu, var
+
+    def _predict_one_again(self, y, t):
+        """Mean and variance at ONE more point for the model, y and stream of the previous such call (the reference's scalar
+        utilities under Nelder-Mead, utility.py:131,178,224) -- the previous ``apgp_predict1_host`` call's arguments with a new
+        point.  None: something differs, the caller takes the generic path."""
+        plan = self._one_plan
+        if (not self._computed or self.kernel.dirty or plan.xs is not self._xs or plan.p1 is not self._p1_work
+                or plan.factor is not (self._L if plan.solve else self._work) or plan.mean != self.mean.value
+                or plan.solve == self._trust_inverse()          # (variance_mode / the conditioning gate picked the other form)
+                or type(y) is not np.ndarray or y.dtype != np.float64 or type(t) is not np.ndarray or t.dtype != np.float64
+                or t.shape != (1, plan.ndim) or not t.flags.c_contiguous
+                or y.size != plan.n or not y.flags.c_contiguous or y.tobytes() != plan.ybytes):
+            return None
+        cur = plan.current_device()
+        if cur != plan.dev_index or plan.raw_stream is None or plan.raw_stream(cur) != plan.stream:
+            return None
+        o2 = np.empty(2, dtype=np.float64)
+        if plan.solve:
+            rc = plan.fn(t.ctypes.data, plan.xs_ptr, plan.n, plan.ks_ref, plan.mean, None, 0, plan.factor_ptr, plan.ld,
+                         plan.p1_ptr, o2.ctypes.data, plan.stream_arg)
+        else:
+            rc = plan.fn(t.ctypes.data, plan.xs_ptr, plan.n, plan.ks_ref, plan.mean, plan.factor_ptr, plan.ld, None, 0,
+                         plan.p1_ptr, o2.ctypes.data, plan.stream_arg)
+        _lib.check(rc, "apgp_predict1_host")
+        return np.array([o2[0]]), np.array([o2[1]])
 
     def _predict_mean_again(self, y, t):
         """The mean at a few more points for the model, y and stream of the previous such call (the walker ensembles of
@@ -1160,6 +1212,9 @@ class GP(object):
                                                       float(self.mean.value), self._work.data_ptr(), (n + 63) // 64 * 64,
                                                       None, 0, self._p1_work.data_ptr(), o2.ctypes.data, st),
                                "apgp_predict1_host")
+                if want == ("mu", "var"):
+                    # the reference's scalar utilities ask again at the next simplex point, ~460 times per search
+                    self._one_plan = _OnePlan(self, torch, dev, st.value or 0, ks, y, n, use_solve)
                 res = {"mu": np.array([o2[0]]), "var": np.array([o2[1]])}
                 return tuple(res[w_] for w_ in want)
             T = cand_device if cand_device is not None else torch.from_numpy(cand).to(dev)

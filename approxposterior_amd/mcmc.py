@@ -155,9 +155,9 @@ class EnsembleSampler(object):
     def compute_log_prob(self, coords):
         """log-probability (and first blob, if any) for every row of ``coords``."""
         coords = np.atleast_2d(coords)
-        if np.any(np.isinf(coords)):
-            raise ValueError("At least one parameter value was infinite")
-        if np.any(np.isnan(coords)):
+        if not np.isfinite(coords).all():                 # (one pass in the usual case; the two messages as before)
+            if np.isinf(coords).any():
+                raise ValueError("At least one parameter value was infinite")
             raise ValueError("At least one parameter value was NaN")
         if self.vectorize:
             res = self.log_prob_fn(coords, *self.args, **self.kwargs)
@@ -180,7 +180,7 @@ class EnsembleSampler(object):
                         blob[i] = float(np.ravel(r[1])[0])
                 else:
                     lp[i] = float(np.ravel(r)[0])
-        if np.any(np.isnan(lp)):
+        if np.isnan(lp).any():
             raise ValueError("Probability function returned NaN")
         return lp, blob
 

@@ -625,3 +625,59 @@ def test_repeated_mean_prediction_plan_equals_the_generic_path():
         m3 = ga.predict(y, T, return_cov=False, return_var=False)
         torch.cuda.current_stream().synchronize()
     assert np.array_equal(m3, ga.predict(y, T, return_cov=False, return_var=False))
+
+
+def test_repeated_single_candidate_prediction_plan_equals_the_generic_path():
+    """``GP.predict(y, t, return_var=True)`` for ONE point at a time (the reference's scalar utilities under Nelder-Mead) re-uses
+    the previous call's arguments (``_predict_one_again``), through the dense inverse or -- ``variance_mode = "solve"`` -- the
+    substitution against L: same (mu, var) as the generic path; a switch of the form, new hyper-parameters or another y go
+    back to it."""
+    go, agp = _mods()
+    n, D = 90, 2
+    X, y = _case(n, D, 17)
+    rs = np.random.RandomState(3)
+
+    def make(mode):
+        g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(D, 3.0), ndim=D), fit_mean=True, mean=float(np.median(y)),
+                   white_noise=-12, fit_white_noise=False)
+        g.variance_mode = mode
+        g.compute(X)
+        return g
+    for mode in (None, "solve"):
+        ga, gb = make(mode), make(mode)
+        used = 0
+        for it in range(6):
+            t = rs.uniform(-5, 5, size=(1, D))
+            used += ga._one_plan is not None
+            gb._one_plan = None
+            ma, va = ga.predict(y, t, return_var=True)
+            mb, vb = gb.predict(y, t, return_var=True)
+            assert np.array_equal(ma, mb) and np.array_equal(va, vb) and ma.shape == va.shape == (1,)
+        assert used >= 5
+        # the other variance form: not the plan's
+        ga.variance_mode = gb.variance_mode = "inverse" if mode == "solve" else "solve"
+        gb._one_plan = None
+        t = rs.uniform(-5, 5, size=(1, D))
+        ra, rb = ga.predict(y, t, return_var=True), gb.predict(y, t, return_var=True)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+        # new hyper-parameters, another y, two points at once
+        p = ga.get_parameter_vector() + 0.05
+        ga.set_parameter_vector(p); gb.set_parameter_vector(p)
+        gb._one_plan = None
+        ra, rb = ga.predict(y, t, return_var=True), gb.predict(y, t, return_var=True)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+        y2 = y - 0.25
+        gb._one_plan = None
+        ra, rb = ga.predict(y2, t, return_var=True), gb.predict(y2, t, return_var=True)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+        T2 = rs.uniform(-5, 5, size=(2, D))
+        ra = ga.predict(y2, T2, return_var=True)
+        assert ra[0].shape == (2,)
+    gpo = go.GP(kernel=go.ExpSquaredKernel(np.exp(p[1:]), ndim=D), fit_mean=True, mean=float(p[0]), white_noise=-12,
+                fit_white_noise=False)
+    gpo.compute(X)
+    mo, vo = gpo.predict(y, t, return_var=True)
+    ma, va = ga.predict(y, t, return_var=True)
+    ma, va = ga.predict(y, t, return_var=True)          # (the second call is the short path)
+    asum = np.abs(gpo._compute_alpha(y, False)).sum()
+    assert abs(ma[0] - mo[0]) <= 1e-10 * asum and abs(va[0] - vo[0]) <= 1e-9
