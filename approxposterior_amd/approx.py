@@ -187,11 +187,32 @@ class ApproxPosterior(object):
         pts = np.asarray(thetas, dtype=float)
         if pts.ndim == 1:
             pts = pts.reshape(-1, self.ndim)
+        fin = np.isfinite(pts)
+        batch = getattr(self._lnprior, "batch", None)
+        if batch is not None and fin.all():
+            # the usual half-step of the sampler, without the row-by-row bookkeeping below: every coordinate finite, the
+            # prior's vectorised twin (likelihood.py) in one call, one mean-only launch for the walkers inside the prior
+            prior = np.asarray(batch(pts), dtype=float).reshape(len(pts))
+            inside = np.isfinite(prior)
+            if inside.all():
+                mean = self.gp.predict(self.y, pts, return_cov=False, return_var=False)
+                ok = np.isfinite(mean)
+                if ok.all():
+                    return mean, prior
+                return np.where(ok, mean, -np.inf), np.where(ok, prior, np.nan)
+            logp = np.full(len(pts), -np.inf)
+            blob = np.full(len(pts), np.nan)
+            rows = np.flatnonzero(inside)
+            if rows.size:
+                mean = self.gp.predict(self.y, pts[rows], return_cov=False, return_var=False)
+                ok = np.isfinite(mean)
+                keep = rows[ok]
+                logp[keep] = mean[ok]
+                blob[keep] = prior[keep]
+            return logp, blob
         logp = np.full(len(pts), -np.inf)
         blob = np.full(len(pts), np.nan)
-        fin = np.isfinite(pts)
         some = fin.any(axis=1)                      # (a walker without a finite coordinate is rejected before the prior)
-        batch = getattr(self._lnprior, "batch", None)
         if batch is not None and some.all():
             # the prior's vectorised twin (likelihood.py): one call per ensemble instead of one per walker
             prior = np.asarray(batch(pts), dtype=float).reshape(len(pts))

@@ -202,9 +202,9 @@ class EnsembleSampler(object):
         for _ in range(int(iterations)):
             inds = np.arange(nw) % 2
             self._random.shuffle(inds)
+            halves = (np.flatnonzero(inds == 0), np.flatnonzero(inds == 1))
             for split in range(2):
-                S = np.flatnonzero(inds == split)
-                C = np.flatnonzero(inds != split)
+                S, C = halves[split], halves[1 - split]
                 s, c = self._coords[S], self._coords[C]
                 zz = ((a - 1.0) * self._random.rand(len(S)) + 1.0) ** 2.0 / a
                 factors = (nd - 1.0) * np.log(zz)
