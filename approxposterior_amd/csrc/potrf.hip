@@ -564,10 +564,36 @@ struct NllSmallArgs {
     KernConst kc;
     double* mail;        // optional: pinned, device-mapped host record (5 doubles + sequence word)
     long long seq;
+    // batched launch (apgp_nll_eval_batch at n <= 128: gridDim.x matrices of the SAME training set, one workgroup each):
+    // matrix b takes its kernel constants from bkc[b] and its shift from bshift[b] (device-mapped host memory, read once
+    // into LDS), works in K + b n^2, z + b n, info + b, out5 + 5 b and posts its record + sequence word at brec + 8 b
+    const KernConst* bkc;
+    const double* bshift;
+    double* brec;
 };
+// this workgroup's matrix of a batched launch: the constants into LDS, the pointers moved on
+template <bool BATCH>
+__device__ __forceinline__ void nll_batch_select(NllSmallArgs& q, KernConst* kcb) {
+    if constexpr (BATCH) {
+        const int b = blockIdx.x;
+        for (int e = threadIdx.x; e < (int)(sizeof(KernConst) / sizeof(double)); e += blockDim.x)
+            ((double*)kcb)[e] = ((const double*)(q.bkc + b))[e];
+        q.shift = q.bshift[b];
+        q.K += (long long)b * q.n * q.n;
+        q.z += (long long)b * q.n;
+        q.info += b;
+        q.out5 += 5 * b;
+        q.mail = q.brec + 8 * b;
+        __syncthreads();
+    }
+}
+static_assert(sizeof(KernConst) % sizeof(double) == 0, "KernConst is copied as doubles");
 
-template <int DPAD>
+template <int DPAD, bool BATCH>
 __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
+    __shared__ KernConst kcb;
+    nll_batch_select<BATCH>(q, &kcb);
+    const KernConst& kc = BATCH ? kcb : q.kc;
     __shared__ __attribute__((aligned(16))) double Ls[PB][PB + 2];
     __shared__ __attribute__((aligned(16))) double invd[PB];
     __shared__ double zblk[PB];
@@ -580,7 +606,7 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
     if (t == 0) { prog = 0; hflag = 0; *(unsigned int*)q.info = 0xffffffffu; }
     for (int e = t; e < PB * DPAD; e += 192) {
         const int r = e / DPAD, d = e % DPAD;
-        xs[r][d] = (r < bs && d < q.kc.ndim) ? q.X[(long long)r * q.kc.ndim + d] * q.kc.sc[d] : 0.0;
+        xs[r][d] = (r < bs && d < kc.ndim) ? q.X[(long long)r * kc.ndim + d] * kc.sc[d] : 0.0;
     }
     __syncthreads();
     // Gram block, lower triangle (zero above it and past n): thread = (column c, rows r = g, g + 3, ...)
@@ -591,7 +617,7 @@ __global__ __launch_bounds__(192) void nll_small_kernel(NllSmallArgs q) {
         for (int d = 0; d < DPAD; ++d) xc[d] = xs[c][d];
         for (int r = g; r < PB; r += 3) {
             double k = 0.0;
-            if (r < bs && c <= r) k = apgp_gram_value<DPAD>(xs[r], xc, q.kc, r == c, etab);
+            if (r < bs && c <= r) k = apgp_gram_value<DPAD>(xs[r], xc, kc, r == c, etab);
             Ls[r][c] = k;
         }
     }
@@ -672,8 +698,11 @@ template <int DPAD>
 static constexpr size_t nll_two_lds_doubles() {
     return (size_t)PB * (PB + 2) + GEMM64_LDS_DOUBLES + (size_t)2 * PB * (DPAD + 1) + 5 * PB + APGP_EXP_TAB_N + 2;
 }
-template <int DPAD>
+template <int DPAD, bool BATCH>
 __global__ __launch_bounds__(256) void nll_two_kernel(NllSmallArgs q) {
+    __shared__ KernConst kcb;
+    nll_batch_select<BATCH>(q, &kcb);
+    const KernConst& kc = BATCH ? kcb : q.kc;
     extern __shared__ __attribute__((aligned(16))) double two_lds[];
     double (*Ls)[PB + 2] = (double (*)[PB + 2])two_lds;                          // the block being factorised
     double* gl = two_lds + PB * (PB + 2);                                         // Gram tile (1,0), later the product's buffers
@@ -694,7 +723,7 @@ __global__ __launch_bounds__(256) void nll_two_kernel(NllSmallArgs q) {
     if (t == 0) { *prog_p = 0; *hflag_p = 0; *(unsigned int*)q.info = 0xffffffffu; }
     for (int e = t; e < 2 * PB * DPAD; e += 256) {
         const int r = e / DPAD, d = e % DPAD;
-        xs[r][d] = (r < n && d < q.kc.ndim) ? q.X[(long long)r * q.kc.ndim + d] * q.kc.sc[d] : 0.0;
+        xs[r][d] = (r < n && d < kc.ndim) ? q.X[(long long)r * kc.ndim + d] * kc.sc[d] : 0.0;
     }
     __syncthreads();
     // Gram tiles (0,0) (lower triangle) and (1,0) (rows past n: zero): thread = (column c, rows g, g + 4, ...)
@@ -704,8 +733,8 @@ __global__ __launch_bounds__(256) void nll_two_kernel(NllSmallArgs q) {
 #pragma unroll
         for (int d = 0; d < DPAD; ++d) xc[d] = xs[c][d];
         for (int r = g; r < PB; r += 4) {
-            Ls[r][c] = c <= r ? apgp_gram_value<DPAD>(xs[r], xc, q.kc, r == c, etab) : 0.0;
-            T10[r][c] = r < bs1 ? apgp_gram_value<DPAD>(xs[PB + r], xc, q.kc, false, etab) : 0.0;
+            Ls[r][c] = c <= r ? apgp_gram_value<DPAD>(xs[r], xc, kc, r == c, etab) : 0.0;
+            T10[r][c] = r < bs1 ? apgp_gram_value<DPAD>(xs[PB + r], xc, kc, false, etab) : 0.0;
         }
     }
     __syncthreads();
@@ -761,7 +790,7 @@ __global__ __launch_bounds__(256) void nll_two_kernel(NllSmallArgs q) {
                     const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, r);
 #pragma unroll
                     for (int d = 0; d < DPAD; ++d) xc[d] = xs[PB + lc][d];
-                    cin[i][j][r] = (lr < bs1 && lc < bs1 && lc <= lr) ? apgp_gram_value<DPAD>(xs[PB + lr], xc, q.kc, lr == lc, etab) : 0.0;
+                    cin[i][j][r] = (lr < bs1 && lc < bs1 && lc <= lr) ? apgp_gram_value<DPAD>(xs[PB + lr], xc, kc, lr == lc, etab) : 0.0;
                     v[i][j][r] = 0.0;
                 }
             }
@@ -845,8 +874,8 @@ __global__ __launch_bounds__(256) void nll_two_kernel(NllSmallArgs q) {
 }
 
 // the kernel's dynamic LDS exceeds 64 KiB: the attribute is set once per device and instantiation
-template <int DPAD>
-static int nll_two_launch_t(const NllSmallArgs& q, hipStream_t s) {
+template <int DPAD, bool BATCH>
+static int nll_two_launch_t(const NllSmallArgs& q, int batch, hipStream_t s) {
     static bool done[64] = {false};
     static std::mutex mu;
     const int lds = (int)(nll_two_lds_doubles<DPAD>() * sizeof(double));
@@ -858,7 +887,7 @@ static int nll_two_launch_t(const NllSmallArgs& q, hipStream_t s) {
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!done[dev]) {
-            const hipError_t e = hipFuncSetAttribute((const void*)nll_two_kernel<DPAD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            const hipError_t e = hipFuncSetAttribute((const void*)nll_two_kernel<DPAD, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) {
                 apgp_set_error("apgp_nll_eval: hipFuncSetAttribute(%d B of LDS) failed on device %d: %s", lds, dev, hipGetErrorString(e));
                 return -2;
@@ -866,48 +895,45 @@ static int nll_two_launch_t(const NllSmallArgs& q, hipStream_t s) {
             done[dev] = true;
         }
     }
-    hipLaunchKernelGGL(nll_two_kernel<DPAD>, dim3(1), dim3(256), lds, s, q);
+    hipLaunchKernelGGL((nll_two_kernel<DPAD, BATCH>), dim3((unsigned)batch), dim3(256), lds, s, q);
     APGP_CHECK_LAUNCH();
     return 0;
 }
-static int nll_two_launch(const double* X, int64_t n, const apgp_kernel_t* kern, const double* y, double mean,
-                          double* K, double* z, int32_t* info_dev, double* out5_dev, hipStream_t s,
-                          double* mail = nullptr, long long seq = 0) {
-    NllSmallArgs q;
-    q.mail = mail; q.seq = seq;
-    if (apgp_make_kernconst(kern, &q.kc) != 0) {
-        apgp_set_error("apgp_nll_eval: bad argument: kernel parameters");
-        return -1;
+// one launch of the fused evaluation: n <= 64 (nll_small_kernel) or 64 < n <= 128 (nll_two_kernel); q.bkc != NULL:
+// `batch` matrices, one workgroup each
+template <bool BATCH>
+static int nll_fused_launch_q(const NllSmallArgs& q, int dpad, int batch, hipStream_t s) {
+    if (q.n > PB) {
+        switch (dpad) {
+            case 2: return nll_two_launch_t<2, BATCH>(q, batch, s);
+            case 4: return nll_two_launch_t<4, BATCH>(q, batch, s);
+            case 8: return nll_two_launch_t<8, BATCH>(q, batch, s);
+            case 16: return nll_two_launch_t<16, BATCH>(q, batch, s);
+            default: return nll_two_launch_t<32, BATCH>(q, batch, s);
+        }
     }
-    q.X = X; q.y = y; q.K = K; q.z = z; q.info = info_dev; q.out5 = out5_dev; q.n = n; q.shift = mean;
-    switch (q.kc.dpad) {
-        case 2: return nll_two_launch_t<2>(q, s);
-        case 4: return nll_two_launch_t<4>(q, s);
-        case 8: return nll_two_launch_t<8>(q, s);
-        case 16: return nll_two_launch_t<16>(q, s);
-        default: return nll_two_launch_t<32>(q, s);
+    const dim3 grid((unsigned)batch), block(192);
+    switch (dpad) {
+        case 2: hipLaunchKernelGGL((nll_small_kernel<2, BATCH>), grid, block, 0, s, q); break;
+        case 4: hipLaunchKernelGGL((nll_small_kernel<4, BATCH>), grid, block, 0, s, q); break;
+        case 8: hipLaunchKernelGGL((nll_small_kernel<8, BATCH>), grid, block, 0, s, q); break;
+        case 16: hipLaunchKernelGGL((nll_small_kernel<16, BATCH>), grid, block, 0, s, q); break;
+        default: hipLaunchKernelGGL((nll_small_kernel<32, BATCH>), grid, block, 0, s, q); break;
     }
+    APGP_CHECK_LAUNCH();
+    return 0;
 }
-
-static int nll_small_launch(const double* X, int64_t n, const apgp_kernel_t* kern, const double* y, double mean,
+static int nll_fused_launch(const double* X, int64_t n, const apgp_kernel_t* kern, const double* y, double mean,
                             double* K, double* z, int32_t* info_dev, double* out5_dev, hipStream_t s,
                             double* mail = nullptr, long long seq = 0) {
     NllSmallArgs q;
-    q.mail = mail; q.seq = seq;
+    q.mail = mail; q.seq = seq; q.bkc = nullptr; q.bshift = nullptr; q.brec = nullptr;
     if (apgp_make_kernconst(kern, &q.kc) != 0) {
         apgp_set_error("apgp_nll_eval: bad argument: kernel parameters");
         return -1;
     }
     q.X = X; q.y = y; q.K = K; q.z = z; q.info = info_dev; q.out5 = out5_dev; q.n = n; q.shift = mean;
-    switch (q.kc.dpad) {
-        case 2: hipLaunchKernelGGL(nll_small_kernel<2>, dim3(1), dim3(192), 0, s, q); break;
-        case 4: hipLaunchKernelGGL(nll_small_kernel<4>, dim3(1), dim3(192), 0, s, q); break;
-        case 8: hipLaunchKernelGGL(nll_small_kernel<8>, dim3(1), dim3(192), 0, s, q); break;
-        case 16: hipLaunchKernelGGL(nll_small_kernel<16>, dim3(1), dim3(192), 0, s, q); break;
-        default: hipLaunchKernelGGL(nll_small_kernel<32>, dim3(1), dim3(192), 0, s, q); break;
-    }
-    APGP_CHECK_LAUNCH();
-    return 0;
+    return nll_fused_launch_q<false>(q, q.kc.dpad, 1, s);
 }
 
 // One launch per block step after the first: the trailing update of block column j AND the panel
@@ -1531,11 +1557,11 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
     const long long seq = mail ? ++mb->seq : 0;
     if (n <= PB && y) {
         // one single-workgroup launch (nll_small_kernel): same values, two launch boundaries fewer
-        rc = nll_small_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s, mail ? mb->dev : nullptr, seq);
+        rc = nll_fused_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s, mail ? mb->dev : nullptr, seq);
         if (rc != 0) return rc;
     } else if (n <= 2 * PB && y && (g_potrf_mode.load() == 0 || g_potrf_mode.load() == 3)) {
         // two block columns, still one single-workgroup launch (nll_two_kernel; modes 1 / 2 keep the separate launches)
-        rc = nll_two_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s, mail ? mb->dev : nullptr, seq);
+        rc = nll_fused_launch(X, n, kern, y, mean, K, z, info_dev, out5_dev, s, mail ? mb->dev : nullptr, seq);
         if (rc != 0) return rc;
     } else {
         // three launches fewer than the separate calls: the Gram launch initialises the right-hand side
@@ -1584,6 +1610,51 @@ extern "C" int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch, co
     APGP_CHECK_ARG(batch >= 1 && batch <= 65535, "1 <= batch <= 65535 required");
     APGP_CHECK_ARG(n >= 1, "n >= 1 required");
     int rc;
+    if (n <= 2 * PB && batch <= 64 && (g_potrf_mode.load() == 0 || g_potrf_mode.load() == 3)) {
+        // README sizes (round 5): ONE launch of the fused evaluation, a workgroup per matrix (nll_small_kernel /
+        // nll_two_kernel); constants and shifts go in -- and the records come back -- through the stream's pinned,
+        // device-mapped staging area, each workgroup posting its own sequence word: no copy, no synchronisation.
+        // Every matrix runs the code of the single call: the same bits.
+        hipStream_t s = (hipStream_t)stream;
+        std::lock_guard<std::mutex> lock(apgp_stream_lock(s));
+        constexpr size_t KCD = sizeof(KernConst) / sizeof(double);
+        double* io_dev = nullptr;
+        double* io = apgp_stream_pinned_io(s, (size_t)batch * (KCD + 1 + 8), &io_dev);
+        ApgpMailbox* mb = io ? apgp_stream_mailbox(s) : nullptr;
+        if (io && mb && mb->host) {
+            KernConst* kcs = (KernConst*)io;
+            for (int64_t b = 0; b < batch; ++b) {
+                APGP_CHECK_ARG(apgp_make_kernconst(kerns + b, kcs + b) == 0, "kernel parameters");
+                APGP_CHECK_ARG(kcs[b].dpad == kcs[0].dpad && kcs[b].ndim == kcs[0].ndim, "kernels of one batch share their dimension");
+            }
+            double* sh = io + (size_t)batch * KCD;
+            for (int64_t b = 0; b < batch; ++b) sh[b] = means[b];
+            double* rec = sh + batch;
+            const long long seq = ++mb->seq;
+            NllSmallArgs q;
+            q.X = X; q.y = y; q.K = K; q.z = z; q.info = info_dev; q.out5 = out5_dev; q.n = n; q.shift = 0.0;
+            q.kc = kcs[0]; q.mail = nullptr; q.seq = seq;
+            q.bkc = (const KernConst*)io_dev; q.bshift = io_dev + (size_t)batch * KCD; q.brec = io_dev + (size_t)batch * (KCD + 1);
+            if ((rc = nll_fused_launch_q<true>(q, kcs[0].dpad, (int)batch, s)) != 0) return rc;
+            const auto t0 = std::chrono::steady_clock::now();
+            bool synced = false;
+            for (int64_t b = 0; b < batch; ++b) {
+                volatile long long* flag = (volatile long long*)(rec + 8 * b + 5);
+                unsigned spins = 0;
+                while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                    if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(600)) {
+                        if (synced || hipStreamSynchronize(s) != hipSuccess || __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                            apgp_set_error("apgp_nll_eval_batch: result record not written");
+                            return -2;
+                        }
+                        synced = true;
+                    }
+                }
+                for (int i = 0; i < 5; ++i) out5_host[5 * b + i] = rec[8 * b + i];
+            }
+            return 0;
+        }
+    }
     for (int64_t b = 0; b < batch; ++b)
         if ((rc = apgp_gram_with_rhs(X, n, kerns + b, K + b * n * n, n, y, means[b], z + b * n, info_dev + b, stream)) != 0) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -402,6 +402,7 @@ class GP(object):
         self._x = None
         self._yerr2 = 0.0
         self._nllMemo = None          # gpUtils._nll: values already evaluated on this training set
+        self._batch_cache = None      # nll_batch: work buffers and the device copy of y, kept between the rounds of a fit
         self._reset_device_state()
 
     # -- device plumbing -------------------------------------------------------
@@ -916,20 +917,34 @@ class GP(object):
             return out
         # chunks bounded by 2 GiB of Gram-matrix work space
         per = max(1, int((2 << 30) // (8 * n * n)))
-        with torch.cuda.device(dev):
+        with self._on(torch, dev):
             st = self._stream(torch)
             if getattr(self, "_x_d", None) is None:
                 self._x_d = torch.from_numpy(self._x).to(dev)
-            y_d = torch.from_numpy(yv).to(dev)
+            # the rounds of a lock-step fit (gpUtils._minimizeLockStep) come back with the same y, batch size and stream a few
+            # hundred times: the device copy of y and the work buffers are kept (the call is synchronous: nothing of the
+            # previous round is in flight)
+            cache = self._batch_cache
+            ybytes = yv.tobytes()
+            if (cache is None or cache["x_d"] is not self._x_d or cache["stream"] != (st.value or 0)
+                    or cache["ybytes"] != ybytes):
+                cache = self._batch_cache = {"x_d": self._x_d, "stream": st.value or 0, "ybytes": ybytes,
+                                             "y_d": torch.from_numpy(yv).to(dev), "bufs": {}}
+            y_d = cache["y_d"]
             for c0 in range(0, len(live), per):
                 idx = live[c0:c0 + per]
                 nb = len(idx)
                 karr = (_lib.KernelStruct * nb)(*structs[c0:c0 + nb])
                 marr = np.array(means[c0:c0 + nb], dtype=np.float64)
-                K = torch.empty((nb, n, n), dtype=torch.float64, device=dev)
-                z = torch.empty((nb, n), dtype=torch.float64, device=dev)
-                info = torch.empty(nb, dtype=torch.int32, device=dev)
-                o_d = torch.empty((nb, 5), dtype=torch.float64, device=dev)
+                bufs = cache["bufs"].get(nb)
+                if bufs is None:
+                    bufs = (torch.empty((nb, n, n), dtype=torch.float64, device=dev),
+                            torch.empty((nb, n), dtype=torch.float64, device=dev),
+                            torch.empty(nb, dtype=torch.int32, device=dev),
+                            torch.empty((nb, 5), dtype=torch.float64, device=dev))
+                    if 8 * nb * n * n <= (64 << 20):      # (large work spaces are not hoarded)
+                        cache["bufs"][nb] = bufs
+                K, z, info, o_d = bufs
                 o = np.empty((nb, 5), dtype=np.float64)
                 _lib.check(lib.apgp_nll_eval_batch(self._x_d.data_ptr(), n, nb, ctypes.addressof(karr),
                                                    y_d.data_ptr(), marr.ctypes.data, K.data_ptr(), z.data_ptr(),

@@ -194,7 +194,11 @@ int64_t apgp_potrf_backoff_skips(void);
  * evaluated in lock-step.)  Same training set X, y; kerns[batch] / means[batch] on the
  * host; K: batch x n x n work (the factors on return), z: batch x n, info_dev: batch
  * int32, out5_dev / out5_host: batch x 5 doubles laid out as apgp_fit_summary's record.
- * One batched Cholesky (gridDim.y = batch): values bit-identical to single calls.    */
+ * One batched Cholesky (gridDim.y = batch): values bit-identical to single calls.
+ * n <= 128 and batch <= 64 (round 5; the README configuration's restarts): ONE launch of the fused
+ * single-workgroup evaluation of apgp_nll_eval, a workgroup per matrix; kernel constants, shifts and
+ * the records travel through the stream's pinned, device-mapped staging area (each workgroup posts
+ * its own sequence word: no copy, no synchronisation).  Same bits again.                          */
 int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch,
                         const apgp_kernel_t* kerns /*host*/, const double* y,
                         const double* means /*host*/, double* K, double* z,

@@ -226,9 +226,9 @@ def test_nll_batch_is_bit_identical_to_single_evaluations(n, d):
     """apgp_nll_eval_batch: several hyper-vectors through ONE batched
     Gram + Cholesky + solve.  Every entry equals gpUtils._nll of that vector exactly --
     including +inf for a non-positive-definite matrix -- and the GP's own state survives.
-    The single evaluation is ONE fused launch for n <= 64 (nll_small_kernel), the batch always the
-    separate Gram / panel / step / finish launches: same code and operation order, so the same
-    bits, at the block boundaries +- 1."""
+    The single evaluation is ONE fused launch for n <= 128 (nll_small_kernel / nll_two_kernel), the batch too (a workgroup
+    per matrix); above, and in mode 1, the separate Gram / panel / step / finish launches: same code and operation order,
+    so the same bits, at the block boundaries +- 1."""
     import time
     from approxposterior_amd import gpUtils
     rs = np.random.RandomState(5)
@@ -250,6 +250,17 @@ def test_nll_batch_is_bit_identical_to_single_evaluations(n, d):
     t_single = time.time() - t0
     assert np.array_equal(batch, single), (batch, single)
     assert np.isinf(batch[3]) and np.all(np.isfinite(np.delete(batch, 3)))
+    # round 5: up to n = 128 the batch is ONE launch of the fused evaluation (a workgroup per matrix, records through the
+    # stream's pinned staging area) -- against the separate Gram / panel / step / finish launches (mode 1): the same bits
+    from approxposterior_amd import _lib
+    lib = _lib.load()
+    lib.apgp_potrf_mode(1)
+    try:
+        with np.errstate(all="ignore"):
+            batch_ml = gp.nll_batch(P, y)
+    finally:
+        lib.apgp_potrf_mode(0)
+    assert np.array_equal(batch, batch_ml), (batch, batch_ml)
     print("nll_batch N=%d: 7 evaluations %.2f ms batched, %.2f ms one by one" % (n, 1e3 * t_batch, 1e3 * t_single))
 
 
