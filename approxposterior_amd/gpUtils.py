@@ -30,6 +30,7 @@ def defaultHyperPrior(p):
 
 
 _MEMO_SIZE = 64
+_LOCKSTEP_MIN_N = 512     # optimizeGP's restarts run in lock-step (batched device evaluations) from this many training points on
 
 
 def _memoTable(gp, y):
@@ -210,7 +211,12 @@ def _runRestarts(gp, y, x0s, method, options, gpHyperPrior, batchRestarts):
     with several starts run concurrently with batched device evaluations; everything else is the
     reference's sequential loop body (gpUtils.py:232-247)."""
     derivativeFree = method in ["nelder-mead", "powell", "cg"]
-    if batchRestarts and len(x0s) > 1 and derivativeFree and hasattr(gp, "nll_batch"):
+    # (below _LOCKSTEP_MIN_N training points one evaluation is a single fused launch of 30-160 us: the rendezvous of the
+    # lock-step threads costs more than the batch saves -- tools/optgp_restarts_time.py, three Powell restarts: 16.7 against
+    # 32.8 ms at N = 50, 54 against 60 at N = 400, 76 against 60 at N = 600, 114 against 75 at N = 1152.  Same solutions
+    # either way: every restart sees the values it would see alone.)
+    if (batchRestarts and len(x0s) > 1 and derivativeFree and hasattr(gp, "nll_batch")
+            and (batchRestarts == "always" or len(y) >= _LOCKSTEP_MIN_N)):
         res = _minimizeLockStep(gp, y, x0s, method, options, gpHyperPrior)
         # marginal likelihood at each solution: one more batch (the sequential loop's
         # set_parameter_vector + recompute + log_likelihood, gpUtils.py:243-247)
@@ -235,10 +241,12 @@ def optimizeGP(gp, theta, y, seed=None, nGPRestarts=1, method="powell",
     and ``theta`` are accepted and unused, as in the reference (quirk Q6).
 
     With ``batchRestarts`` (default) and a derivative-free ``method`` the restarts run
-    concurrently and their ``_nll`` evaluations are batched on the device; start points,
-    per-restart trajectories and the selected optimum are those of the sequential loop
-    (the optimisers draw no random numbers, and a batched evaluation is bit-identical to a
-    single one).  ``batchRestarts=False`` runs the reference's sequential loop.
+    concurrently and their ``_nll`` evaluations are batched on the device -- from 512 training
+    points on, where a batch saves more than the threads' rendezvous costs (``"always"``:
+    whatever the size); start points, per-restart trajectories and the selected optimum are
+    those of the sequential loop (the optimisers draw no random numbers, and a batched
+    evaluation is bit-identical to a single one).  ``batchRestarts=False`` runs the
+    reference's sequential loop.
 
     Under an initialised ``torch.distributed`` group (``distributed`` None / True; one process per
     GPU, NumPy's global random state identical on every rank -- ``dist.sync_random_state``) every rank

@@ -317,7 +317,7 @@ def test_optimizegp_hip_reproduces_reference_constant(golden_dir):
     pins = json.load(open(os.path.join(golden_dir, "pins.json")))
     want = pins["reference_test_constants"]["test_OptimizeGP.py:91"]
     replay = pins["harness_replay"]["optgp_noamp"]
-    for batch in (True, False):
+    for batch in ("always", True, False):      # (lock-step forced | by size: sequential at N = 50 | sequential)
         np.random.seed(57)
         theta, y = _rosen_set(50)
         gp = gpUtils.defaultGP(theta, y, fitAmp=False)

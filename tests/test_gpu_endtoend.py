@@ -376,7 +376,7 @@ def test_optimizegp_batched_restarts_equal_sequential():
     import time
     from approxposterior_amd import gpUtils, likelihood as lh
     out = {}
-    for mode in (False, True):
+    for mode in (False, "always", True):       # ("always": lock-step whatever the size; True: by size -- sequential at N = 60)
         np.random.seed(57)
         theta = lh.rosenbrockSample(60)
         y = np.array([lh.rosenbrockLnlike(t) + lh.rosenbrockLnprior(t) for t in theta])
@@ -385,5 +385,5 @@ def test_optimizegp_batched_restarts_equal_sequential():
         with np.errstate(all="ignore"):
             gp = gpUtils.optimizeGP(gp, theta, y, seed=57, nGPRestarts=4, batchRestarts=mode)
         out[mode] = (np.array(gp.get_parameter_vector()), time.time() - t0)
-    assert np.array_equal(out[False][0], out[True][0])
-    print("optimizeGP 4 restarts N=60: sequential %.2f s, batched %.2f s" % (out[False][1], out[True][1]))
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][0], out["always"][0])
+    print("optimizeGP 4 restarts N=60: sequential %.2f s, batched %.2f s" % (out[False][1], out["always"][1]))

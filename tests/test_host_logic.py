@@ -283,7 +283,7 @@ def test_lockstep_restarts_follow_the_sequential_trajectories():
         np.random.seed(11)
         gp_b = _BatchingOracleGP(oracle_default_gp(theta, y, False))
         np.random.seed(3)
-        bat = gpUtils.optimizeGP(gp_b, theta, y, nGPRestarts=3, batchRestarts=True)
+        bat = gpUtils.optimizeGP(gp_b, theta, y, nGPRestarts=3, batchRestarts="always")
         p_bat = np.array(bat.get_parameter_vector())
     assert np.array_equal(p_seq, p_bat)
     assert max(gp_b.batches) == 3 and min(gp_b.batches) >= 1      # batched while >1 restart is running
