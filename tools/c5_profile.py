@@ -8,7 +8,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from scipy.optimize import rosen
 from approxposterior_amd import approx, gpUtils, utility as ut
-D, m0, m, nmax = 8, 512, 64, 10
+D, m0, m = 8, 512, 64
+nmax = int(sys.argv[1]) if len(sys.argv) > 1 else 10      # (a shorter loop: python tools/c5_profile.py 2)
 lo, hi = -5.0, 5.0
 bounds = [(lo, hi)] * D
 def lnprior(t):
@@ -32,3 +33,5 @@ pr.disable()
 print("run: %.1f s" % (time.perf_counter() - t0))
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
 print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22)
+print(s.getvalue()[:5000])
