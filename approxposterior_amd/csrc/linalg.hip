@@ -963,6 +963,82 @@ __global__ __launch_bounds__(1024) void pred1_final_kernel(Pred1Args a) {
     }
 }
 
+// The same three steps for n <= 256 through the dense inverse as ONE single-workgroup launch (round 5: the README
+// configuration's point search is 18,600 of these calls at N = 50 .. 90): k* and v stay in LDS; every sum is formed by the
+// thread, in the order, of the kernel it replaces -- pred1_kstar_kernel's workgroup reduction (nparts = 1), winv_gemv_kernel's
+// wavefront per row (four rows at a time), pred1_final_kernel's 1,024 "virtual threads" of which the first 256 are these
+// (the other twelve wavefront partials are zeros) -- so (mu, sigma^2) carry the same bits.
+template <int DPAD>
+__global__ __launch_bounds__(256) void pred1_small_kernel(Pred1Args a, const double* W, long long ldw) {
+    constexpr int XS = DPAD + 2;
+    __shared__ double etab[APGP_EXP_TAB_N];
+    __shared__ double red[4], red2[4];
+    __shared__ __attribute__((aligned(16))) double ks[256];
+    __shared__ double vs[256];
+    apgp_exp_tab_load(etab);
+    __syncthreads();
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long n = a.n;
+    double contrib = 0.0, kv = 0.0;
+    if (t < n) {
+        const double* xr = a.xs + (long long)t * XS;
+        double s = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int d = 0; d < DPAD; d += 2) {
+            const double df0 = a.tt[d] - xr[d], df1 = a.tt[d + 1] - xr[d + 1];
+            s = fma(df0, df0, s);
+            s3 = fma(df1, df1, s3);
+        }
+        kv = a.amp * apgp_exp(-(s + s3), etab);
+        if (a.lin_coef != 0.0) {
+            double ls;
+            APGP_LIN_SUM(ls, DPAD, a.ndim, a.lin_order, a.tt[d_] * xr[d_] * a.lw[d_]);
+            kv = fma(a.lin_coef, ls, kv);
+        }
+        contrib = kv * xr[DPAD];                       // k* alpha
+    }
+    ks[t] = kv;
+    for (int o = 32; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o);
+    if (lane == 0) red[w] = contrib;
+    __syncthreads();
+    // v = W k*: one wavefront per row, as winv_gemv_kernel (shift 0)
+    for (long long i = w; i < n; i += 4) {
+        const double* wr = W + i * ldw;
+        double s0 = 0.0, s1 = 0.0;
+        for (long long k = 2 * lane; k <= i; k += 128) {
+            const f64x2 w2 = *(const f64x2*)(wr + k);
+            s0 = fma(w2.x, ks[k] - 0.0, s0);
+            if (k + 1 <= i) s1 = fma(w2.y, ks[k + 1] - 0.0, s1);
+        }
+        double s = s0 + s1;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) vs[i] = s;
+    }
+    __syncthreads();
+    // sum v^2: virtual thread t of pred1_final_kernel's 1,024
+    double sq = 0.0;
+    if (t < n) sq = fma(vs[t], vs[t], sq);
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) red2[w] = sq;
+    __syncthreads();
+    if (t != 0) return;
+    double q = 0.0;
+    for (int i = 0; i < 4; ++i) q += red2[i];              // (+ twelve zero partials)
+    double mu = 0.0;
+    mu += (red[0] + red[1]) + (red[2] + red[3]);           // mu_part[0]
+    mu += a.mean;
+    double var = a.ktt - q;
+    if (a.has_nan) { mu = NAN; var = NAN; }
+    a.out2[0] = mu;
+    a.out2[1] = var;
+    if (a.mail) {
+        a.mail[0] = mu;
+        a.mail[1] = var;
+        __hip_atomic_store((long long*)(a.mail + 5), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+extern "C" int apgp_potrf_mode(int mode);      // (mode 1 = separate launches everywhere: the bit-identity tests' reference)
 extern "C" int64_t apgp_predict1_work_len(int64_t n) { return n < 1 ? 0 : 2 * apgp_npad(n) + (n + 255) / 256 + 8; }
 
 extern "C" int apgp_predict1_host(const double* t_host, const double* xs, int64_t n, const apgp_kernel_t* kern, double mean,
@@ -997,6 +1073,8 @@ extern "C" int apgp_predict1_host(const double* t_host, const double* xs, int64_
     }
     a.ktt = kc.lin_coef != 0.0 ? fma(kc.lin_coef, ktl, kc.amp) : kc.amp;
     const dim3 grid((unsigned)a.nparts), block(256);
+    const bool fused = winv && n <= 256 && (apgp_potrf_mode(-1) & 15) != 1;
+    if (!fused)
     switch (kc.dpad) {
         case 2: hipLaunchKernelGGL(pred1_kstar_kernel<2>, grid, block, 0, s, a); break;
         case 4: hipLaunchKernelGGL(pred1_kstar_kernel<4>, grid, block, 0, s, a); break;
@@ -1004,7 +1082,9 @@ extern "C" int apgp_predict1_host(const double* t_host, const double* xs, int64_
         case 16: hipLaunchKernelGGL(pred1_kstar_kernel<16>, grid, block, 0, s, a); break;
         default: hipLaunchKernelGGL(pred1_kstar_kernel<32>, grid, block, 0, s, a); break;
     }
-    if (winv) {
+    if (fused) {
+        // (launched below, with the mailbox)
+    } else if (winv) {
         hipLaunchKernelGGL(winv_gemv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, winv, (long long)ldw,
                            (long long)n, (const double*)a.kstar, 0.0, (double*)a.v);
     } else {
@@ -1017,7 +1097,17 @@ extern "C" int apgp_predict1_host(const double* t_host, const double* xs, int64_
     const bool mail = mb && mb->host;
     std::lock_guard<std::mutex> lock(apgp_stream_lock(s));
     if (mail) { a.mail = mb->dev; a.seq = ++mb->seq; }
-    hipLaunchKernelGGL(pred1_final_kernel, dim3(1), dim3(1024), 0, s, a);
+    if (fused) {
+        switch (kc.dpad) {
+            case 2: hipLaunchKernelGGL(pred1_small_kernel<2>, dim3(1), dim3(256), 0, s, a, winv, (long long)ldw); break;
+            case 4: hipLaunchKernelGGL(pred1_small_kernel<4>, dim3(1), dim3(256), 0, s, a, winv, (long long)ldw); break;
+            case 8: hipLaunchKernelGGL(pred1_small_kernel<8>, dim3(1), dim3(256), 0, s, a, winv, (long long)ldw); break;
+            case 16: hipLaunchKernelGGL(pred1_small_kernel<16>, dim3(1), dim3(256), 0, s, a, winv, (long long)ldw); break;
+            default: hipLaunchKernelGGL(pred1_small_kernel<32>, dim3(1), dim3(256), 0, s, a, winv, (long long)ldw); break;
+        }
+    } else {
+        hipLaunchKernelGGL(pred1_final_kernel, dim3(1), dim3(1024), 0, s, a);
+    }
     APGP_CHECK_LAUNCH();
     if (mail) {
         volatile long long* flag = (volatile long long*)(mb->host + 5);

@@ -681,3 +681,43 @@ def test_repeated_single_candidate_prediction_plan_equals_the_generic_path():
     ma, va = ga.predict(y, t, return_var=True)          # (the second call is the short path)
     asum = np.abs(gpo._compute_alpha(y, False)).sum()
     assert abs(ma[0] - mo[0]) <= 1e-10 * asum and abs(va[0] - vo[0]) <= 1e-9
+
+
+@pytest.mark.parametrize("n,D", [(1, 1), (50, 2), (64, 3), (90, 2), (129, 8), (200, 16), (256, 5), (257, 2)])
+def test_single_candidate_prediction_in_one_launch(n, D):
+    """``apgp_predict1_host`` through the dense inverse at n <= 256 (the README configuration's point search: one candidate per
+    call under Nelder-Mead) is ONE single-workgroup launch; every sum is formed in the order of the three launches it replaces
+    (mode 1 keeps those): (mu, sigma^2) bit-identical, and equal to the oracle's within fp64 tolerances."""
+    from approxposterior_amd import _lib
+    go, agp = _mods()
+    lib = _lib.load()
+    X, y = _case(n, D, 31 * n + D) if n > 1 else (np.array([[0.3]]), np.array([0.7]))
+    rs = np.random.RandomState(n)
+    g = agp.GP(kernel=2.5 * agp.ExpSquaredKernel(np.full(D, 4.0), ndim=D), fit_mean=True, mean=float(np.median(y)), white_noise=-10,
+               fit_white_noise=False)
+    g.variance_mode = "inverse"
+    g.compute(X)
+    gpo = go.GP(kernel=2.5 * go.ExpSquaredKernel(np.full(D, 4.0), ndim=D), fit_mean=True, mean=float(np.median(y)), white_noise=-10,
+                fit_white_noise=False)
+    gpo.compute(X)
+    asum = np.abs(gpo._compute_alpha(y, False)).sum()
+    for it in range(6):
+        t = rs.uniform(-5, 5, size=(1, D))
+        if it == 5:
+            t[0, 0] = np.nan
+        out = {}
+        for mode in (0, 1):
+            lib.apgp_potrf_mode(mode)
+            try:
+                g._one_plan = None
+                out[mode] = g.predict(y, t, return_var=True)
+                again = g.predict(y, t, return_var=True)             # (the repeated-call plan)
+                assert np.array_equal(again[0], out[mode][0], equal_nan=True) and np.array_equal(again[1], out[mode][1], equal_nan=True)
+            finally:
+                lib.apgp_potrf_mode(0)
+        assert out[0][0].tobytes() == out[1][0].tobytes() and out[0][1].tobytes() == out[1][1].tobytes()
+        if it < 5:
+            mo, vo = gpo.predict(y, t, return_var=True)
+            assert abs(out[0][0][0] - mo[0]) <= 1e-10 * max(asum, 1.0) and abs(out[0][1][0] - vo[0]) <= 1e-9
+        else:
+            assert np.isnan(out[0][0][0]) and np.isnan(out[0][1][0])
