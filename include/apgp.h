@@ -325,7 +325,9 @@ int apgp_acquire_solve(const double* T, int64_t m, int64_t idx_offset,
  * factor -> one triangular solve (use it above the conditioning gate).  work:
  * apgp_predict1_work_len(n) doubles (device).  out2_host: mu, sigma^2 -- through the
  * stream's pinned mailbox when the call returns (no allocation, copy or stream
- * synchronisation; falls back to copy + synchronisation without pinned memory). */
+ * synchronisation; falls back to copy + synchronisation without pinned memory).
+ * Three small launches; through winv at n <= 256 ONE single-workgroup launch (round 5,
+ * same bits; apgp_potrf_mode 1 keeps the three).                                       */
 int64_t apgp_predict1_work_len(int64_t n);
 int apgp_predict1_host(const double* t_host /*host*/, const double* xs, int64_t n,
                        const apgp_kernel_t* kern /*host*/, double mean,
