@@ -288,6 +288,15 @@ def test_lockstep_restarts_follow_the_sequential_trajectories():
     assert np.array_equal(p_seq, p_bat)
     assert max(gp_b.batches) == 3 and min(gp_b.batches) >= 1      # batched while >1 restart is running
     assert gp_b.batches[-1] == 3                                   # the final mll batch
+    # by size (the default): below gpUtils._LOCKSTEP_MIN_N training points the restarts run one after the other -- a
+    # single evaluation is one fused launch there and the threads' rendezvous costs more than a batch saves -- same result
+    with np.errstate(all="ignore"):
+        np.random.seed(11)
+        gp_c = _BatchingOracleGP(oracle_default_gp(theta, y, False))
+        np.random.seed(3)
+        dflt = gpUtils.optimizeGP(gp_c, theta, y, nGPRestarts=3)
+    assert len(y) < gpUtils._LOCKSTEP_MIN_N and gp_c.batches == []
+    assert np.array_equal(np.array(dflt.get_parameter_vector()), p_seq)
 
 
 def test_lockstep_evaluator_edge_cases():
