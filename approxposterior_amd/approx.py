@@ -160,7 +160,8 @@ class ApproxPosterior(object):
         """Rank 0's float64 arrays on every rank (a no-op without a process group)."""
         if self._ranks() is None:
             return values if len(values) > 1 else values[0]
-        out = tuple(apdist.broadcast_bytes(np.asarray(v, dtype=np.float64), 0, self.group) for v in values)
+        out = tuple(apdist.broadcast_bytes(np.asarray(v, dtype=np.float64), 0, self.group, enabled=self.distributed)
+                    for v in values)
         return out if len(out) > 1 else out[0]
 
     # ------------------------------------------------------- surrogate log-probability
@@ -238,7 +239,7 @@ class ApproxPosterior(object):
         """Re-fit the GP hyper-parameters in place (approx.py:192-226).  Under a process group the
         restarts are spread over the ranks and every rank ends with the same optimum."""
         if self._ranks() is not None:
-            apdist.sync_random_state(0, self.group)      # the restart start points are one global draw
+            apdist.sync_random_state(0, self.group, enabled=self.distributed)      # the restart start points are one global draw
         self.gp = gpUtils.optimizeGP(self.gp, self.theta, self.y, seed=seed,
                                      method=method, options=options, p0=p0,
                                      nGPRestarts=nGPRestarts, gpHyperPrior=gpHyperPrior,
@@ -277,7 +278,8 @@ class ApproxPosterior(object):
             best, value = apdist.sharded_acquire(
                 lambda offset: self.gp.acquire(self.y, mine, kind, bounds=self.bounds, idx_offset=offset,
                                                device_record=True),
-                lo, group=self.group if ranks is not None else None)
+                lo, group=self.group if ranks is not None else None,
+                enabled=self.distributed if ranks is not None else False)     # (no ranks: this process's own record, no gather)
             if best < 0:
                 raise RuntimeError("ERROR: Cannot find a valid solution: no candidate is allowed by the prior")
             point = row(best)
@@ -344,7 +346,7 @@ class ApproxPosterior(object):
             if ranks is not None:
                 # one global random stream: the candidate matrix / restart draws below are the same on
                 # every rank whatever the forward model (rank 0 only) did to rank 0's stream
-                apdist.sync_random_state(0, self.group)
+                apdist.sync_random_state(0, self.group, enabled=self.distributed)
             if self.algorithm == "alternate":      # AGP, BAPE, AGP, ... (approx.py:656-661)
                 self.utility = (ut.AGPUtility, ut.BAPEUtility)[count % 2]
             point, _ = self._selectPoint(self.utility, theta0, nMinObjRestarts, minObjMethod,
@@ -352,12 +354,21 @@ class ApproxPosterior(object):
             points.append(point)
             if not computeLnLike:
                 continue
+            failure = None
+            value = np.zeros(1)
             if chief:
-                like = self._lnlike(point, *fwdArgs, **kwargs)
-                like = like[0] if hasattr(like, "__iter__") else like      # (lnlike, blobs...) allowed
-                value = np.array([like + self._lnprior(point)], dtype=np.float64).reshape(1)
-            else:
-                value = np.zeros(1)
+                try:
+                    like = self._lnlike(point, *fwdArgs, **kwargs)
+                    like = like[0] if hasattr(like, "__iter__") else like      # (lnlike, blobs...) allowed
+                    value = np.array([like + self._lnprior(point)], dtype=np.float64).reshape(1)
+                except Exception as err:       # noqa: BLE001 -- raised on every rank just below
+                    if ranks is None:
+                        raise
+                    failure = err
+            if ranks is not None:
+                # only rank 0 ran the forward model: if it raised there, every rank raises here instead of waiting
+                # for a broadcast that never comes
+                apdist.raise_together(failure, "the forward model (lnlike)", group=self.group, enabled=self.distributed)
             value = self._agree(value)             # the forward model ran once, on rank 0
             values.append(value)
             try:
@@ -438,7 +449,7 @@ class ApproxPosterior(object):
         """
         ranks = self._ranks()
         if ranks is not None:
-            apdist.sync_random_state(0, self.group)
+            apdist.sync_random_state(0, self.group, enabled=self.distributed)
             verbose, cache = verbose and ranks[0] == 0, cache and ranks[0] == 0
         samplerKwargs, mcmcKwargs = mcmcUtils.validateMCMCKwargs(self, samplerKwargs,
                                                                  mcmcKwargs, verbose)
@@ -446,12 +457,14 @@ class ApproxPosterior(object):
             self._requireBoxPrior()
         if onDevice or ranks is not None:
             # one ensemble per rank, seeded base + rank, gathered once along the walker axis
-            # (a single rank without a process group: the local chain, unchanged)
+            # (no ranks -- no process group, or distributed=False inside somebody else's: the local chain, seed
+            # ``base``, and no collective whatever group the process has open)
             base = np.random.randint(0, 2 ** 31 - 1)
             merged = apdist.replicated_ensembles(
                 lambda seed: self._sampleReplica(seed, samplerKwargs, mcmcKwargs, args, kwargs,
                                                  batched, onDevice),
-                seed=base, group=self.group if ranks is not None else None)
+                seed=base, group=self.group if ranks is not None else None,
+                enabled=self.distributed if ranks is not None else False)
             chain, logp, naccept = merged[0], merged[1], merged[2]
             self.sampler = emcee.DeviceChain({"chain": chain, "log_prob": logp, "naccept": naccept,
                                               "coords": chain[-1], "final_log_prob": logp[-1],
@@ -585,7 +598,7 @@ class ApproxPosterior(object):
             return -(self._gpll(x)[0]) if np.isfinite(self._lnprior(x)) else np.inf
 
         if self._ranks() is not None:
-            apdist.sync_random_state(0, self.group)
+            apdist.sync_random_state(0, self.group, enabled=self.distributed)
         best, value = ut.minimizeObjective(minusMean, self.y, self.gp, self.priorSample,
                                            self._lnprior, nRestarts=nRestarts, args=None,
                                            method=method, options=options, bounds=self.bounds,

@@ -20,7 +20,7 @@ Nelder-Mead, utility.py:253-372); this is the multi-GPU form of
 import numpy as np
 
 __all__ = ["shard_bounds", "combine_best", "sharded_acquire", "replicated_ensembles", "context",
-           "broadcast_bytes", "sync_random_state", "all_gather_arrays", "spread_restarts"]
+           "broadcast_bytes", "sync_random_state", "all_gather_arrays", "spread_restarts", "raise_together"]
 
 
 def shard_bounds(m, world_size, rank):
@@ -45,7 +45,7 @@ def combine_best(pairs):
     return best_i, best_u
 
 
-def sharded_acquire(local_acquire, idx_offset, group=None, device=None, records=None):
+def sharded_acquire(local_acquire, idx_offset, group=None, device=None, records=None, enabled=None):
     """Run ``local_acquire(idx_offset) -> (best_global_index, best_u)`` on this
     rank's shard and all-gather the winners.
 
@@ -55,6 +55,8 @@ def sharded_acquire(local_acquire, idx_offset, group=None, device=None, records=
     (a host ``(index, u)`` pair).
     Returns the same (index, u) on every rank.  ``records`` (a list) receives the gathered
     per-rank (u, index) pairs in rank order -- one per rank the collective actually saw.
+    ``enabled`` as in :func:`context`: False = this rank's own record only, whatever process group the
+    process happens to have open (``ApproxPosterior(distributed=False)``).
     """
     import torch
     import torch.distributed as dist
@@ -67,7 +69,7 @@ def sharded_acquire(local_acquire, idx_offset, group=None, device=None, records=
         mine = res.reshape(2)
     else:
         bi, bu = res
-    if not (dist.is_available() and dist.is_initialized()):
+    if context(group, enabled) is None:
         if on_device:
             h = mine.cpu().numpy()
             bu, bi = float(h[0:1].view(np.float64)[0]), int(h[1])
@@ -96,7 +98,7 @@ def sharded_acquire(local_acquire, idx_offset, group=None, device=None, records=
     return combine_best(pairs)
 
 
-def replicated_ensembles(local_sample, seed=0, group=None, device=None):
+def replicated_ensembles(local_sample, seed=0, group=None, device=None, enabled=None):
     """MCMC over the GP surrogate on several GPUs: *replicas only* (SURVEY.md
     section 8e, row "MCMC _gpll").  A stretch-move step couples all walkers of an
     ensemble, so an ensemble does not shard; instead every rank runs its own
@@ -108,9 +110,10 @@ def replicated_ensembles(local_sample, seed=0, group=None, device=None):
     Returns (chain (iterations, world*W, D), log_prob (iterations, world*W)) on every rank.
     ``local_sample`` may return further arrays: (iterations, W) per-step values (e.g. the lnprior blobs)
     or (W,) per-walker values (e.g. the accepted-move counts); each is concatenated along its walker
-    axis and returned after the first two.
+    axis and returned after the first two.  ``enabled`` as in :func:`context` (False: the local ensemble,
+    seed unchanged, no collective).
     """
-    ctx = context(group)
+    ctx = context(group, enabled)
     rank = ctx[0] if ctx is not None else 0
     res = local_sample(int(seed) + rank)
     chain = np.ascontiguousarray(res[0], dtype=np.float64)
@@ -123,7 +126,7 @@ def replicated_ensembles(local_sample, seed=0, group=None, device=None):
             raise ValueError("extra arrays must be (iterations, W) or (W,)")
     if ctx is None:
         return (chain, logp) + tuple(extras)
-    per_rank = all_gather_arrays([chain, logp] + extras, group, device)
+    per_rank = all_gather_arrays([chain, logp] + extras, group, device, enabled)
     out = []
     for k in range(2 + len(extras)):
         axis = 0 if per_rank[0][k].ndim == 1 else 1
@@ -176,13 +179,13 @@ def _global_rank(group, group_rank):
     return dist.get_global_rank(group, group_rank)
 
 
-def broadcast_bytes(buf, src=0, group=None, device=None):
+def broadcast_bytes(buf, src=0, group=None, device=None, enabled=None):
     """Every rank returns rank ``src``'s ``buf`` (a C-contiguous NumPy array; same shape and dtype
     everywhere -- only the bytes travel)."""
     import torch
     import torch.distributed as dist
     arr = np.ascontiguousarray(buf)
-    if context(group) is None:
+    if context(group, enabled) is None:
         return arr
     raw = np.frombuffer(arr.tobytes(), dtype=np.uint8).copy()
     t = torch.from_numpy(raw).to(_carrier(group, device))
@@ -190,28 +193,28 @@ def broadcast_bytes(buf, src=0, group=None, device=None):
     return np.frombuffer(t.cpu().numpy().tobytes(), dtype=arr.dtype).reshape(arr.shape).copy()
 
 
-def sync_random_state(src=0, group=None, device=None):
+def sync_random_state(src=0, group=None, device=None, enabled=None):
     """Give every rank rank ``src``'s global NumPy random state (MT19937 key, position, cached Gaussian):
     afterwards identical calls draw identical numbers on all ranks -- the candidate matrix, restart start
     points and walker initial states are then ONE global draw, not one per rank."""
-    if context(group) is None:
+    if context(group, enabled) is None:
         return
     name, key, pos, has_gauss, gauss = np.random.get_state()
     if name != "MT19937":      # pragma: no cover
         raise RuntimeError("unexpected NumPy bit generator %r" % name)
-    head = broadcast_bytes(np.array([pos, has_gauss], dtype=np.int64), src, group, device)
-    key = broadcast_bytes(np.asarray(key, dtype=np.uint32), src, group, device)
-    gauss = broadcast_bytes(np.array([gauss], dtype=np.float64), src, group, device)
+    head = broadcast_bytes(np.array([pos, has_gauss], dtype=np.int64), src, group, device, enabled)
+    key = broadcast_bytes(np.asarray(key, dtype=np.uint32), src, group, device, enabled)
+    gauss = broadcast_bytes(np.array([gauss], dtype=np.float64), src, group, device, enabled)
     np.random.set_state((name, key, int(head[0]), int(head[1]), float(gauss[0])))
 
 
-def all_gather_arrays(arrays, group=None, device=None):
+def all_gather_arrays(arrays, group=None, device=None, enabled=None):
     """ONE all-gather of a list of equally-shaped (across ranks) float64 arrays: returns
     ``per_rank[r][k]`` = rank r's k-th array.  Without a process group: ``[arrays]``."""
     import torch
     import torch.distributed as dist
     arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays]
-    if context(group) is None:
+    if context(group, enabled) is None:
         return [arrs]
     flat = np.concatenate([a.ravel() for a in arrs]) if arrs else np.empty(0)
     mine = torch.from_numpy(flat).to(_carrier(group, device))
@@ -229,26 +232,60 @@ def all_gather_arrays(arrays, group=None, device=None):
     return out
 
 
-def spread_restarts(n_restarts, run_mine, n_params, group=None, device=None):
+def spread_restarts(n_restarts, run_mine, n_params, group=None, device=None, enabled=None):
     """Optimiser restarts over the ranks (SURVEY.md section 8e, row "GP fit": the fit does not shard,
     its restarts do): restart r belongs to rank ``r % world``; ``run_mine(indices) -> [(mll, p), ...]``
-    runs this rank's restarts; ONE all-gather of (1 + P) doubles per restart slot returns
-    ``(mll (R,), p (R, P))`` in restart order on every rank."""
-    ctx = context(group)
+    runs this rank's restarts; ONE all-gather of (2 + P) doubles per restart slot returns
+    ``(mll (R,), p (R, P))`` in restart order on every rank.
+
+    The ranks do different work before the collective, so a failure must not leave the others waiting
+    in it: an exception in ``run_mine`` is caught, travels as a status word in the same all-gather, and
+    then EVERY rank raises (the failing rank its own exception, the others a ``RuntimeError`` naming it)."""
+    ctx = context(group, enabled)
     rank, world = ctx if ctx is not None else (0, 1)
     mine = list(range(rank, int(n_restarts), world))
-    res = run_mine(mine) if mine else []
-    if len(res) != len(mine):
-        raise ValueError("run_mine must return one (mll, p) per restart index")
+    err = None
+    try:
+        res = run_mine(mine) if mine else []
+        if len(res) != len(mine):
+            raise ValueError("run_mine must return one (mll, p) per restart index")
+    except Exception as e:       # noqa: BLE001 -- re-raised below, after the collective every rank is about to enter
+        if ctx is None:
+            raise
+        err, res = e, []
     slots = (int(n_restarts) + world - 1) // world
-    rec = np.full((slots, 1 + int(n_params)), np.nan)
+    rec = np.full((slots, 2 + int(n_params)), np.nan)
+    rec[:, 0] = 0.0 if err is None else 1.0        # status word of this rank
     for s, (mll, p) in enumerate(res):
-        rec[s, 0] = mll
-        rec[s, 1:] = np.asarray(p, dtype=np.float64)
-    per_rank = all_gather_arrays([rec], group, device)
+        rec[s, 1] = mll
+        rec[s, 2:] = np.asarray(p, dtype=np.float64)
+    per_rank = all_gather_arrays([rec], group, device, enabled)
+    failed = [r for r in range(world) if per_rank[r][0][0, 0] != 0.0] if slots else []
+    if err is not None:
+        raise err
+    if failed:
+        raise RuntimeError("optimiser restarts failed on rank(s) %s" % failed)
     mll = np.empty(int(n_restarts))
     ps = np.empty((int(n_restarts), int(n_params)))
     for r in range(int(n_restarts)):
         row = per_rank[r % world][0][r // world]
-        mll[r], ps[r] = row[0], row[1:]
+        mll[r], ps[r] = row[1], row[2:]
     return mll, ps
+
+
+def raise_together(err, what, src=None, group=None, device=None, enabled=None):
+    """Call on EVERY rank after a step only some ranks worked in (``err``: the exception this rank caught,
+    or None): one all-gather of a status word; if any rank failed, every rank raises -- the failing
+    rank(s) their own exception, the others ``RuntimeError(what ...)`` -- instead of blocking forever in
+    the next collective.  Without a process group: re-raises ``err`` if there is one."""
+    ctx = context(group, enabled)
+    if ctx is None:
+        if err is not None:
+            raise err
+        return
+    flags = all_gather_arrays([np.array([0.0 if err is None else 1.0])], group, device, enabled)
+    failed = [r for r, f in enumerate(flags) if f[0][0] != 0.0]
+    if err is not None:
+        raise err
+    if failed:
+        raise RuntimeError("%s failed on rank(s) %s" % (what, failed))

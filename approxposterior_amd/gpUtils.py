@@ -49,8 +49,21 @@ def _memoTable(gp, y):
 
 
 def _memoKey(p, gp):
+    """``p`` fixes every fitted parameter; what it does not fix must be in the key too: the frozen mean / white noise /
+    yerr, and the kernel OBJECT -- a caller may swap ``gp.kernel`` for another of the same parameter count, or edit a
+    frozen attribute (a LinearKernel's ``order``), without a ``compute()`` in between.  For the two shapes
+    ``defaultGP`` builds without a linear term the objects' identities say it all (they have no frozen attribute);
+    anything else pays for the bytes of the evaluated kernel struct (``GP._factor_key``)."""
     fixed = (float(gp.mean.value), float(gp.white_noise.value), float(gp._yerr2))
-    return np.asarray(p, dtype=np.float64).tobytes(), fixed
+    k = gp.kernel
+    tk = type(k)
+    if tk is george.ExpSquaredKernel:
+        sig = id(k)
+    elif tk is george.Product and type(k.k1) is george.ConstantKernel and type(k.k2) is george.ExpSquaredKernel:
+        sig = (id(k), id(k.k1), id(k.k2))
+    else:
+        sig = gp._factor_key()
+    return np.asarray(p, dtype=np.float64).tobytes(), fixed, sig
 
 
 def _nll(p, gp, y, priorFn=None):
@@ -263,7 +276,8 @@ def optimizeGP(gp, theta, y, seed=None, nGPRestarts=1, method="powell",
             sols, vals = _runRestarts(gp, y, [x0s[i] for i in indices], method, options,
                                       gpHyperPrior, batchRestarts)
             return list(zip(vals, sols))
-        mll, res = apdist.spread_restarts(nGPRestarts, runMine, len(gp.get_parameter_vector()), group)
+        mll, res = apdist.spread_restarts(nGPRestarts, runMine, len(gp.get_parameter_vector()), group,
+                                          enabled=distributed)
     best = int(np.argmax(mll))
     gp.set_parameter_vector(res[best])
     gp.recompute()

@@ -22,14 +22,26 @@ re-derived by anybody.  For N>1:
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 bench.py --gpus 8 ...
+    python bench.py --gpus 8 ...        # no launcher: starts the eight ranks itself (below)
 
 Rank 0 prints ONE JSON line.
+
+``--gpus N`` (N > 1) without a launcher environment: this process -- before it has made a single GPU
+call, and it never makes one -- starts ``python -m torch.distributed.run --nproc-per-node N bench.py ...``
+as a CHILD process (never ``exec``), passes rank 0's JSON line through and exits with the child's code.
+Fewer than N visible devices is an error (exit 3), never a silent one-rank run; a launcher whose
+``WORLD_SIZE`` differs from ``--gpus`` likewise (exit 4).  ``--backend gloo --share-device`` puts all N
+ranks on ``cuda:0`` with host collectives: the whole multi-rank bench (shard bounds, the sweep's device
+record, the all-gather, ``ranks_seen``, ``best_check.vs_ranks``) on a single GPU -- a rehearsal of the
+code path, not a scaling measurement (``config.rehearsal`` says so in the line).
 """
 
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -174,6 +186,8 @@ def fit_leg(agp, dev, seconds_cap=20.0):
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import george_oracle as go
+    from threadpoolctl import threadpool_info
+    blas_threads = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
     out = []
     for n, d in ((50, 2), (1152, 8), (4096, 8)):
         X, y = synthetic_c3(n, d)
@@ -206,7 +220,8 @@ def fit_leg(agp, dev, seconds_cap=20.0):
         flops = n ** 3 / 3.0
         out.append({"n_train": n, "ndim": d, "nll_ms": gpu_ms, "tflops": flops / (gpu_ms * 1e-3) / 1e12,
                     "frac_of_f64_peak": flops / (gpu_ms * 1e-3) / 1e12 / PEAK_F64_TFLOPS,
-                    "cpu_nll_ms": float(np.median(tc)) * 1e3, "cpu_cores": os.cpu_count(), "cpu_kind": "port",
+                    "cpu_nll_ms": float(np.median(tc)) * 1e3, "cpu_cores": os.cpu_count(), "cpu_blas_threads": blas_threads,
+                    "cpu_kind": "port",
                     "ll_rel_diff": abs(ll - llo) / max(1.0, abs(llo))})
     return out
 
@@ -238,39 +253,154 @@ def mid_n_leg(agp, dev):
     return out
 
 
-def cpu_baseline(gpo, fit_s, y, ndim, seconds=12.0, scalar_calls=2000):
-    """Reference-library batched path on the oracle:
-    predict(y, T_chunk, return_var=True) on 4096-candidate chunks + vectorised
-    AGP utility + arg-min, all host cores for BLAS.  george itself is not
-    installable here, so this runs the NumPy/SciPy restatement (same LAPACK
-    calls george's BasicSolver makes): kind = "port"."""
-    rs = np.random.RandomState(1)
-    done = 0
-    best = (np.inf, -1)
+def cpu_baseline(n_train, ndim, metric, seconds=12.0, scalar_calls=2000):
+    """Reference-library batched path on the oracle, timed in a CHILD
+    process that never touches the GPU (``bench.py --cpu-baseline-worker``, below): the host cores are
+    what is measured, so the chunks run over a process pool -- OpenBLAS alone stops scaling long before
+    256 cores and the oracle's kernel-row generation is single-threaded NumPy.  Returns the worker's
+    record (``kind`` "port": george is not installable, this is its NumPy/SciPy restatement making the
+    LAPACK calls george's BasicSolver makes)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--n-train", str(n_train),
+           "--ndim", str(ndim), "--metric", repr(float(metric)), "--cpu-seconds", repr(float(seconds)),
+           "--cpu-scalar-calls", str(int(scalar_calls))]
+    env = dict(os.environ)
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):   # a launcher's "1 thread per rank"
+        env.pop(k, None)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    if proc.returncode != 0:
+        raise RuntimeError("cpu-baseline worker failed with exit code %d" % proc.returncode)
+    return json.loads(proc.stdout.strip().splitlines()[-1])
+
+
+_POOL = {}
+
+
+def _pool_init(threads, n_train, ndim, metric):
+    """A pool worker: its own oracle GP on the same training set (an identical factor in every worker;
+    nothing is shared, so the workers scale like independent processes do) with ``threads`` BLAS threads."""
+    from threadpoolctl import threadpool_limits
+    _POOL["limits"] = threadpool_limits(limits=int(threads))
+    X, y = synthetic_c3(n_train, ndim)
+    gpo, _ = oracle_gp(X, y, metric, ndim)
+    _POOL["gp"], _POOL["y"], _POOL["ndim"] = gpo, y, ndim
+
+
+def _pool_chunk(c):
+    """One 4,096-candidate chunk through the oracle's ``predict(return_var=True)`` -- its four statements
+    (oracle/george_oracle.py GP.predict) timed one by one -- + the vectorised AGP utility + arg-min."""
+    gpo, y, ndim = _POOL["gp"], _POOL["y"], _POOL["ndim"]
+    T = np.random.RandomState(1000 + int(c)).uniform(-5.0, 5.0, size=(4096, ndim))
     t0 = time.time()
-    while time.time() - t0 < seconds:
-        T = rs.uniform(-5.0, 5.0, size=(4096, ndim))
-        mu, var = gpo.predict(y, T, return_var=True)
-        u = agp_utility(mu, var, True)
-        i = int(np.nanargmin(u))
-        if u[i] < best[0]:
-            best = (float(u[i]), done + i)
-        done += len(T)
-    dt = time.time() - t0
-    # (i) reference-faithful scalar path: one candidate per predict call, as
-    # utility.minimizeObjective drives it (utility.py:131) -- SURVEY.md 8(d)(i): >= 2,000 calls
+    Kxs = gpo.kernel.get_value(T, gpo._x)                      # kernel rows k*(T, X): NumPy, one thread
     t1 = time.time()
-    for _ in range(int(scalar_calls)):
-        t = rs.uniform(-5.0, 5.0, size=(1, ndim))
+    mu = np.dot(Kxs, gpo._compute_alpha(y, True)) + gpo.mean.get_value(T)
+    t2 = time.time()
+    KinvKxs = gpo.apply_inverse(Kxs.T)                         # scipy cho_solve, 4096 right-hand sides
+    t3 = time.time()
+    var = gpo.kernel.get_value(T, diag=True) - np.sum(Kxs.T * KinvKxs, axis=0)
+    u = agp_utility(mu, var, True)
+    i = int(np.nanargmin(u))
+    t4 = time.time()
+    return len(T), float(u[i]), int(c) * 4096 + i, t1 - t0, t2 - t1, t3 - t2, t4 - t3
+
+
+def cpu_baseline_worker(args):
+    """Body of ``bench.py --cpu-baseline-worker`` (imports no torch, makes no GPU call).  Prints one JSON
+    object: the ``cpu_baseline`` record of the bench line."""
+    import multiprocessing as mp
+    from threadpoolctl import threadpool_info
+    n, d = args.n_train, args.ndim
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:      # pragma: no cover
+        cores = os.cpu_count() or 1
+    blas = [{"api": i.get("internal_api"), "threads": i.get("num_threads"), "version": i.get("version")}
+            for i in threadpool_info() if i.get("user_api") == "blas"]
+    # one single-threaded worker per core while memory allows (kernel-row generation is single-threaded NumPy and a
+    # one-thread triangular solve is the most efficient one); fewer, wider workers when it does not
+    workers = cores
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+        per_worker = 8.0 * n * n + 4 * 8.0 * 4096 * n + 3e8    # factor + Kxs, its transpose, the solve, slack
+        workers = max(1, min(workers, int(0.5 * avail / per_worker)))
+    except Exception:       # pragma: no cover
+        pass
+    threads = max(1, cores // workers)              # BLAS threads per pool worker
+    X, y = synthetic_c3(n, d)
+    gpo, fit_s = oracle_gp(X, y, args.metric, d)                # all BLAS threads: the fit time reported
+    # (i) reference-faithful scalar path: one candidate per predict call, as utility.minimizeObjective drives it
+    # (utility.py:131) -- SURVEY.md 8(d)(i): >= 2,000 calls; all BLAS threads, one process (the search is sequential)
+    rs = np.random.RandomState(1)
+    t1 = time.time()
+    for _ in range(int(args.cpu_scalar_calls)):
+        t = rs.uniform(-5.0, 5.0, size=(1, d))
         mu, var = gpo.predict(y, t, return_var=True)
         _ = agp_utility(mu, var, True)
     ds = time.time() - t1
-    return {"value": done / dt, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d candidates in %.1f s (4096-candidate chunks, N_train=%d, D=%d, "
-                      "oracle predict+utility+argmin; fit %.2f s excluded)" % (done, dt, len(y), ndim, fit_s),
-            "scalar_path_value": scalar_calls / ds,
-            "scalar_path_sample": "%d single-candidate predict+utility calls in %.1f s "
-                                  "(what the reference's Nelder-Mead search evaluates)" % (scalar_calls, ds)}
+    # (ii) batched path over the pool
+    ctx = mp.get_context("spawn")       # fresh interpreters: no BLAS thread pool inherited across a fork
+    pool = ctx.Pool(workers, initializer=_pool_init, initargs=(threads, n, d, args.metric))
+    try:
+        pool.map(_pool_chunk, range(workers), chunksize=1)      # untimed: every worker fitted, pages touched
+        done, best, parts, at = 0, (np.inf, -1), np.zeros(4), workers
+        t0 = time.time()
+        while True:
+            for m, bu, bi, a, b, c, e in pool.map(_pool_chunk, range(at, at + workers), chunksize=1):
+                done += m
+                parts += (a, b, c, e)
+                if bu < best[0]:
+                    best = (bu, bi)
+            at += workers
+            if time.time() - t0 >= args.cpu_seconds:
+                break
+        dt = time.time() - t0
+    finally:
+        pool.terminate()
+        pool.join()
+    tot = float(parts.sum())
+    print(json.dumps({
+        "value": done / dt, "unit": "candidates/s", "cores": workers * threads, "kind": "port",
+        "host_cores_visible": cores, "pool_workers": workers, "blas_threads_per_worker": threads,
+        "blas_threadpoolctl": blas,
+        "split": {"kernel_rows": parts[0] / tot, "mean": parts[1] / tot, "cho_solve": parts[2] / tot,
+                  "variance_utility_argmin": parts[3] / tot,
+                  "note": "share of the workers' summed time per statement of the oracle's predict"},
+        "sample": "%d candidates in %.1f s (4096-candidate chunks over %d processes x %d BLAS threads, N_train=%d, "
+                  "D=%d, oracle predict+utility+argmin; fit %.2f s excluded)" % (done, dt, workers, threads, n, d, fit_s),
+        "scalar_path_value": args.cpu_scalar_calls / ds,
+        "scalar_path_sample": "%d single-candidate predict+utility calls in %.1f s, one process, %s BLAS threads "
+                              "(what the reference's Nelder-Mead search evaluates)"
+                              % (args.cpu_scalar_calls, ds, blas[0]["threads"] if blas else "?")}))
+    return 0
+
+
+def self_launch(args, argv):
+    """``--gpus N`` (N > 1) without a launcher: start the N ranks as a child ``torch.distributed.run`` and pass
+    rank 0's line through.  Nothing here touches the GPU (``torch.cuda.device_count()`` only counts), and the
+    program is never replaced (no ``os.exec*``): a child process, its exit code returned."""
+    import torch
+    ndev = torch.cuda.device_count()
+    need = 1 if args.share_device else args.gpus
+    if ndev < need:
+        sys.stderr.write("bench.py: --gpus %d needs %d visible GPU(s), %d found -- refusing to run fewer ranks than "
+                         "asked for (use --backend gloo --share-device to rehearse on one GPU)\n" % (args.gpus, need, ndev))
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def main():
@@ -294,24 +424,48 @@ def main():
                          "well-conditioned workload; the headline) or the blocked substitution against L "
                          "(secondary measurement; what ill-conditioned factors get)")
     ap.add_argument("--no-fit-leg", action="store_true", help="skip the _nll timings (GPU and oracle)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collectives of a multi-rank run: RCCL over xGMI (nccl) or host collectives (gloo)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="all ranks on cuda:0 (needs --backend gloo): rehearses the multi-rank path on ONE GPU")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.share_device and args.backend != "gloo":
+        ap.error("--share-device needs --backend gloo (RCCL refuses two ranks on one device)")
+
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # torch.distributed.run
+    if args.gpus > 1 and not launched:
+        return self_launch(args, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     if world != args.gpus:
         if rank == 0:
-            sys.stderr.write("WARNING: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n" % (args.gpus, world))
+            sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s) -- refusing to report a line "
+                             "whose n_gpus is not what was asked for\n" % (args.gpus, world))
+        return 4
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d has no device %d (%d visible)\n" % (rank, local_rank, torch.cuda.device_count()))
+        return 3
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # torch.distributed.run
     if launched:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from approxposterior_amd import gp as agp
     from approxposterior_amd import dist as adist
@@ -390,7 +544,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     if launched:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kms = [a.elapsed_time(b) for a, b in kernel_ms]
@@ -417,6 +571,9 @@ def main():
                        "candidate_draw": "numpy RandomState(1).uniform(-5, 5, (candidates_total, D)); "
                                          "rank r owns rows [r M/world, (r+1) M/world)",
                        "sharding": "candidates split by rank, one 16 B/rank all-gather",
+                       "backend": (args.backend if launched else None),
+                       "rehearsal": ("all %d ranks share cuda:0 (host collectives): exercises the multi-rank code "
+                                     "path, NOT a scaling measurement" % world) if args.share_device else None,
                        "fit_ms_warm": fit_ms, "fit_ms_warm_runs": fit_runs, "fit_phases_ms": fit_phases,
                        "fit_ms_cold_first_call": fit_ms_cold,
                        "h2d_candidates_ms": h2d_ms,
@@ -436,15 +593,13 @@ def main():
             out["roofline"]["kernel"] = out["roofline"]["kernel"].replace(", 0>", ", 2>" if N <= 2048 else ", 1>")
             out["roofline"]["traffic"] = None
             out["roofline"]["traffic_source"] = None
-        need_oracle = (not args.no_check) or (world == 1 and not args.no_cpu_baseline)
-        if need_oracle:
-            gpo, fit_s = oracle_gp(X, y, args.metric, D)
         if not args.no_check:
+            gpo, fit_s = oracle_gp(X, y, args.metric, D)
             chk = check_best(gpo, y, cands_all, best, records=records)
             out["best_checked"] = bool(chk["in_chunk"] and chk["vs_sample"] and chk["vs_ranks"] is not False)
             out["best_check"] = chk
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gpo, fit_s, y, D, args.cpu_seconds, args.cpu_scalar_calls)
+            out["cpu_baseline"] = cpu_baseline(N, D, args.metric, args.cpu_seconds, args.cpu_scalar_calls)
             # the same reference-faithful scalar path on the GPU (one candidate per predict call:
             # apgp_predict1_host), beside the oracle's scalar_path_value
             rs1 = np.random.RandomState(2)
@@ -461,7 +616,8 @@ def main():
         print(json.dumps(out))
     if launched:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -235,3 +235,121 @@ def test_spread_restarts_sync_and_broadcast_world2(tmp_path):
     assert apdist.context() is None and apdist.context(enabled=False) is None
     with pytest.raises(RuntimeError):
         apdist.context(enabled=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# distributed=False inside somebody else's process group: the ranks run DIFFERENT problems,
+# a different number of collective-free steps each; nothing may touch the group -- no deadlock, no merged chains, no
+# winner from the other rank's candidate matrix.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _independent(out_path, rank):
+    from approxposterior_amd import approx, likelihood as lh
+    stub = _stub_module()
+    approx.george = stub
+    np.random.seed(11 + rank)
+    rs = np.random.RandomState(40 + rank)                  # a different training set per rank
+    theta = rs.uniform(-5, 5, size=(20 + 3 * rank, 2))
+    y = np.array([lh.rosenbrockLnlike(t) + lh.rosenbrockLnprior(t) for t in theta])
+    k = stub.ExpSquaredKernel(metric=np.array([3.0, 5.0]), ndim=2)
+    gp = stub.GP(kernel=k, fit_mean=True, mean=np.median(y), white_noise=-12, fit_white_noise=False)
+    gp.compute(theta)
+    ap = approx.ApproxPosterior(theta=theta, y=y, gp=gp, lnprior=lh.rosenbrockLnprior, lnlike=lh.rosenbrockLnlike,
+                                priorSample=lh.rosenbrockSample, bounds=BOUNDS, algorithm="agp", distributed=False)
+    assert ap._ranks() is None
+    pts = []
+    with np.errstate(all="ignore"):
+        for _ in range(1 + rank):                           # rank 1 does more (collective-free) steps than rank 0
+            pts.append(ap.findNextPoint(nCandidates=307 + rank, deviceCandidates=True, computeLnLike=True, cache=False,
+                                        verbose=False, nGPRestarts=2, gpOptions={"maxiter": 2})[0])
+        ap.runMCMC(samplerKwargs={"nwalkers": 6}, mcmcKwargs={"iterations": 12 + rank}, onDevice=True, cache=False,
+                   estBurnin=False, thinChains=False)
+    np.savez(out_path, pts=np.array(pts), chain=ap.sampler.get_chain(), theta=ap.theta, p=ap.gp.get_parameter_vector(),
+             rows=np.array(stub.GP.calls["acquire_rows"]), seeds=np.array(stub.GP.calls["sample_seeds"]))
+
+
+def _independent_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _independent(os.path.join(out_dir, "g_r%d.npz" % rank), rank)
+    dist.barrier()                                          # the group is intact: nobody left a half-done collective in it
+    dist.destroy_process_group()
+
+
+def _independent_alone(rank, out_dir):
+    sys.path.insert(0, ROOT)
+    _independent(os.path.join(out_dir, "a_r%d.npz" % rank), rank)
+
+
+def test_distributed_false_never_touches_the_process_group(tmp_path):
+    out = str(tmp_path)
+    mp.spawn(_independent_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ctx = mp.get_context("spawn")
+    for r in range(2):
+        proc = ctx.Process(target=_independent_alone, args=(r, out))
+        proc.start(); proc.join()
+        assert proc.exitcode == 0
+    for r in range(2):
+        grouped, alone = (np.load(os.path.join(out, "%s_r%d.npz" % (tag, r))) for tag in ("g", "a"))
+        for key in ("pts", "chain", "theta", "p", "rows", "seeds"):
+            assert np.array_equal(grouped[key], alone[key]), (r, key)    # as if the other rank did not exist
+        assert grouped["chain"].shape == (12 + r, 6, 2)                  # this rank's 6 walkers, not 12
+        assert grouped["rows"].tolist() == [307 + r] * (1 + r)           # the whole matrix, not a shard
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# rank-asymmetric work fails on one rank: every rank raises; nobody waits in a collective.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _failing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from approxposterior_amd import approx, dist as apdist, likelihood as lh
+    seen = {}
+
+    def run_mine(indices):
+        if rank == 1:
+            raise np.linalg.LinAlgError("restart blew up on rank 1")
+        return [(0.0, np.zeros(2)) for _ in indices]
+    try:
+        apdist.spread_restarts(4, run_mine, 2)
+    except Exception as err:      # noqa: BLE001
+        seen["restarts"] = "%s: %s" % (type(err).__name__, err)
+
+    stub = _stub_module()
+    approx.george = stub
+    rs = np.random.RandomState(4)
+    theta = rs.uniform(-5, 5, size=(20, 2))
+    y = np.array([lh.rosenbrockLnlike(t) + lh.rosenbrockLnprior(t) for t in theta])
+    gp = stub.GP(kernel=stub.ExpSquaredKernel(metric=np.array([3.0, 5.0]), ndim=2), fit_mean=True, mean=np.median(y),
+                 white_noise=-12, fit_white_noise=False)
+    gp.compute(theta)
+
+    def lnlike(t, *a, **kw):
+        raise FloatingPointError("the forward model diverged")
+    ap = approx.ApproxPosterior(theta=theta, y=y, gp=gp, lnprior=lh.rosenbrockLnprior, lnlike=lnlike,
+                                priorSample=lh.rosenbrockSample, bounds=BOUNDS, algorithm="agp")
+    try:
+        with np.errstate(all="ignore"):
+            ap.findNextPoint(nCandidates=200, cache=False, verbose=False)
+    except Exception as err:      # noqa: BLE001
+        seen["lnlike"] = "%s: %s" % (type(err).__name__, err)
+    dist.barrier()
+    with open(os.path.join(out_dir, "fail_r%d.txt" % rank), "w") as f:
+        f.write(seen.get("restarts", "-") + "\n" + seen.get("lnlike", "-") + "\n")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_failure_on_one_rank_raises_on_every_rank(tmp_path):
+    out = str(tmp_path)
+    mp.spawn(_failing_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = (open(os.path.join(out, "fail_r%d.txt" % r)).read().splitlines() for r in range(2))
+    assert r1[0].startswith("LinAlgError: restart blew up on rank 1")           # the failing rank: its own exception
+    assert r0[0].startswith("RuntimeError: optimiser restarts failed on rank(s) [1]")
+    assert r0[1].startswith("FloatingPointError: the forward model diverged")   # rank 0 ran the forward model
+    assert r1[1].startswith("RuntimeError: the forward model (lnlike) failed on rank(s) [0]")
