@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libapgp.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_DIM = 32
 
 UTIL_AGP, UTIL_BAPE, UTIL_JONES, UTIL_NONE = 0, 1, 2, 3
@@ -57,6 +57,7 @@ SIGNATURES = {
     "apgp_potrf_mode": (ctypes.c_int, [ctypes.c_int]),
     "apgp_potrf_fallbacks": (_I64, []),
     "apgp_potrf_backoff_skips": (_I64, []),
+    "apgp_nll_side_batches": (_I64, []),
     "apgp_nll_eval_batch": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "apgp_trsv": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, ctypes.c_int, _P, _P, _P]),
     "apgp_trsv_mode": (ctypes.c_int, [ctypes.c_int]),

@@ -1331,8 +1331,9 @@ static long long potrf_plan(int64_t n, int64_t lda, hipStream_t s) {
 // Caller holds apgp_stream_lock(s).  The summary's info slot reads PP_ABORTED if the launch gave up.
 // s0 > 0 (hybrid): block columns 0 .. s0 - 1 were factorised and applied to the whole trailing matrix by the
 // launch-per-step path (z blocks and running right-hand side included); this launch factorises the trailing matrix.
+// cu_budget > 0: the CUs this launch may count on (apgp_nll_eval_batch runs several launches side by side).
 static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, int32_t* info_dev, hipStream_t s,
-                                double* out5, double* mail, long long seq, long long s0 = 0) {
+                                double* out5, double* mail, long long seq, long long s0 = 0, int cu_budget = 0) {
     const int dev = apgp_stream_device(s);
     const long long nb_all = (n + PB - 1) / PB, nb = nb_all - s0;
     PersistArgs q;
@@ -1384,7 +1385,7 @@ static int potrf_persist_locked(double* A, int64_t n, int64_t lda, double* z, in
     }
     const long long tiles0 = (nb - 1) * (nb - 2) / 2;                   // tiles of the first update step: one per workgroup
     long long nupd = tiles0;
-    const long long room = potrf_device_cus(dev) - nb;
+    const long long room = (cu_budget > 0 ? cu_budget : potrf_device_cus(dev)) - nb;
     if (nupd > room) nupd = room;
     // (not one workgroup per tile of the first update step: a tile takes ~3.5 us of a 20 us step, and every further
     // update workgroup costs the row workgroups memory latency -- 30 % of the first step's tiles + 8 measured best:
@@ -1598,6 +1599,106 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
     return nll_fetch(mb, mail, seq, s, out5_dev, out5_host);
 }
 
+// ---- a small batch of mid-size evaluations: their persistent launches SIDE BY SIDE (round 6) -------------------------
+// One persistent Cholesky occupies nb + ~30 % of its first step's tiles workgroups (67 of 256 CUs at n = 1152) and is a
+// latency chain: several of them run next to each other at little more than the time of one.  Each matrix gets its own
+// stream -- the caller's for matrix 0, library-owned non-blocking side streams for the others, forked from and joined to
+// the caller's stream by events -- hence its own scratch, flags and mailbox; each launch sizes its update workgroups to
+// 1 / batch of the CUs, so all workgroups of all launches are resident together.  Every matrix runs exactly the code of
+// the single call (Gram launch, persistent launch, finish launch): the same bits.  A launch that gives up (another
+// process holds CUs) sends the whole batch to the batched launch-per-step path, as the single call does.
+#define PP_SIDE_MAX 7
+struct PpSideSet {
+    std::mutex mu;                 // one batch at a time per device: the side streams are shared
+    bool tried = false, ok = false;
+    hipStream_t st[PP_SIDE_MAX];
+    hipEvent_t fork, join[PP_SIDE_MAX];
+};
+static PpSideSet* pp_side_set(int dev) {
+    static PpSideSet sets[64];
+    if (dev < 0 || dev >= 64) return nullptr;
+    PpSideSet* ss = &sets[dev];
+    std::lock_guard<std::mutex> lock(ss->mu);
+    if (!ss->tried) {
+        ss->tried = true;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+        if (cur != dev && hipSetDevice(dev) != hipSuccess) return nullptr;
+        bool ok = hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < PP_SIDE_MAX; ++i)
+            ok = hipStreamCreateWithFlags(&ss->st[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&ss->join[i], hipEventDisableTiming) == hipSuccess;
+        if (cur != dev) (void)hipSetDevice(cur);
+        ss->ok = ok;
+    }
+    return ss->ok ? ss : nullptr;
+}
+static std::atomic<long long> g_pp_side_batches{0};
+extern "C" int64_t apgp_nll_side_batches(void) { return g_pp_side_batches.load(); }
+
+// 0: done (out5_host filled); 1: not applicable or gave up -- nothing of the result is valid, the caller runs the
+// batched launch-per-step path from the Gram matrices; < 0: error
+static int nll_batch_side_by_side(const double* X, int64_t n, int64_t batch, const apgp_kernel_t* kerns, const double* y,
+                                  const double* means, double* K, double* z, int32_t* info_dev, double* out5_dev,
+                                  double* out5_host, hipStream_t s) {
+    const int mode = g_potrf_mode.load();
+    if (mode != 0 && mode != 3) return 1;
+    if (potrf_plan(n, n, s) != 0) return 1;                               // one persistent launch per matrix, no hybrid
+    const int dev = apgp_stream_device(s);
+    const int cus = potrf_device_cus(dev);
+    const long long nb = (n + PB - 1) / PB;
+    const int budget = (int)(cus / batch);
+    if (budget < nb + 2) return 1;                                        // every launch: its row workgroups + >= 2 update workgroups
+    PpSideSet* ss = pp_side_set(dev);
+    if (!ss) return 1;
+    std::lock_guard<std::mutex> batch_lock(ss->mu);
+    ApgpMailbox* mbs[PP_SIDE_MAX + 1];
+    hipStream_t sts[PP_SIDE_MAX + 1];
+    for (int64_t b = 0; b < batch; ++b) {
+        sts[b] = b == 0 ? s : ss->st[b - 1];
+        mbs[b] = apgp_stream_mailbox(sts[b]);
+        if (!mbs[b] || !mbs[b]->host) return 1;
+    }
+    if (pp_backoff_take(dev)) return 1;
+    if (hipEventRecord(ss->fork, s) != hipSuccess) return 1;
+    long long seqs[PP_SIDE_MAX + 1];
+    int rc = 0;
+    int64_t launched = 0;
+    for (int64_t b = 0; b < batch && rc == 0; ++b) {
+        std::lock_guard<std::mutex> lock(apgp_stream_lock(sts[b]));
+        if (b > 0 && hipStreamWaitEvent(sts[b], ss->fork, 0) != hipSuccess) { rc = -2; break; }
+        seqs[b] = ++mbs[b]->seq;
+        rc = apgp_gram_with_rhs(X, n, kerns + b, K + b * n * n, n, y, means[b], z + b * n, info_dev + b, (void*)sts[b]);
+        if (rc == 0)
+            rc = potrf_persist_locked(K + b * n * n, n, n, z + b * n, info_dev + b, sts[b], out5_dev + 5 * b, mbs[b]->dev,
+                                      seqs[b], 0, budget);
+        if (rc == 0) launched = b + 1;
+    }
+    bool gave_up = false;
+    for (int64_t b = 0; b < launched; ++b) {
+        std::lock_guard<std::mutex> lock(apgp_stream_lock(sts[b]));
+        const int rw = mailbox_wait(mbs[b], seqs[b], sts[b], out5_host + 5 * b);
+        if (rw != 0 && rc == 0) rc = rw;
+        if (rw == 0 && out5_host[5 * b + 4] == PP_ABORTED) gave_up = true;
+    }
+    // the caller's stream continues behind every side stream (the records are out, the finish kernels may not be)
+    for (int64_t b = 1; b < launched; ++b)
+        if (hipEventRecord(ss->join[b - 1], sts[b]) != hipSuccess || hipStreamWaitEvent(s, ss->join[b - 1], 0) != hipSuccess)
+            if (rc == 0) rc = -2;
+    if (rc != 0) {
+        if (rc == -2) apgp_set_error("apgp_nll_eval_batch: side-by-side launch failed");
+        return rc;
+    }
+    if (gave_up) {
+        g_potrf_fallbacks.fetch_add(1);
+        pp_backoff_report(dev, true);
+        return 1;
+    }
+    pp_backoff_report(dev, false);
+    g_pp_side_batches.fetch_add(1);
+    return 0;
+}
+
 // `batch` _nll evaluations at different hyper-parameters of the SAME training set in one call
 // (several hyper-vectors per launch for optimizeGP's restarts):
 // batch Gram launches, ONE batched Cholesky (gridDim.y = batch), batch summary launches, one
@@ -1655,9 +1756,13 @@ extern "C" int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch, co
             return 0;
         }
     }
+    hipStream_t s = (hipStream_t)stream;
+    if (batch >= 2 && batch <= PP_SIDE_MAX + 1) {
+        rc = nll_batch_side_by_side(X, n, batch, kerns, y, means, K, z, info_dev, out5_dev, out5_host, s);
+        if (rc <= 0) return rc;                                            // (1: not applicable / gave up -- the batched launches below)
+    }
     for (int64_t b = 0; b < batch; ++b)
         if ((rc = apgp_gram_with_rhs(X, n, kerns + b, K + b * n * n, n, y, means[b], z + b * n, info_dev + b, stream)) != 0) return rc;
-    hipStream_t s = (hipStream_t)stream;
     if ((rc = potrf_run(K, n, n, batch, n * n, y, means, z, info_dev, s, true, out5_dev)) != 0) return rc;
     if (hipMemcpyAsync(out5_host, out5_dev, 5 * sizeof(double) * batch, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {

@@ -885,6 +885,18 @@ class GP(object):
             raise
         return ll if np.isfinite(ll) else -np.inf
 
+    # Powell look-ahead (gpUtils._powellAhead): how many points beyond the one asked for are worth evaluating in the same
+    # device call -- where a small batch costs little more than one evaluation: n <= 128 (ONE launch, a workgroup per
+    # matrix) and the mid sizes whose persistent launches run side by side (apgp_nll_eval_batch); 0 = off.
+    LOOKAHEAD_MAX_N = 1664
+    lookahead = None              # None: by size; 0: off; k: that many points
+
+    def lookahead_width(self):
+        if self.lookahead is not None:
+            return int(self.lookahead)
+        n = 0 if self._x is None else len(self._x)
+        return 4 if 0 < n <= self.LOOKAHEAD_MAX_N else 0
+
     def nll_batch(self, P, y):
         """Negative marginal log-likelihood at each hyper-parameter vector of ``P`` (B x P),
         evaluated by ONE batched Gram + Cholesky + solve call (``apgp_nll_eval_batch``;

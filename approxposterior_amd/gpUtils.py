@@ -11,6 +11,7 @@ public names and argument meaning (``defaultHyperPrior`` :22-43, ``_nll`` :46-80
 one Gram + Cholesky + solve on the GPU through the C ABI.
 """
 
+import sys
 from collections import OrderedDict
 
 import numpy as np
@@ -49,12 +50,15 @@ def _memoTable(gp, y):
 
 
 def _memoKey(p, gp):
-    """``p`` fixes every fitted parameter; what it does not fix must be in the key too: the frozen mean / white noise /
+    """``p`` fixes every fitted parameter; what it does not fix must be in the key too: a frozen mean / white noise,
     yerr, and the kernel OBJECT -- a caller may swap ``gp.kernel`` for another of the same parameter count, or edit a
     frozen attribute (a LinearKernel's ``order``), without a ``compute()`` in between.  For the two shapes
     ``defaultGP`` builds without a linear term the objects' identities say it all (they have no frozen attribute);
     anything else pays for the bytes of the evaluated kernel struct (``GP._factor_key``)."""
-    fixed = (float(gp.mean.value), float(gp.white_noise.value), float(gp._yerr2))
+    yerr2 = gp._yerr2
+    frozen = (None if gp.fit_mean else float(gp.mean.value),
+              None if gp.fit_white_noise else float(gp.white_noise.value),
+              yerr2 if type(yerr2) is float else np.asarray(yerr2, dtype=np.float64).tobytes())
     k = gp.kernel
     tk = type(k)
     if tk is george.ExpSquaredKernel:
@@ -63,7 +67,66 @@ def _memoKey(p, gp):
         sig = (id(k), id(k.k1), id(k.k2))
     else:
         sig = gp._factor_key()
-    return np.asarray(p, dtype=np.float64).tobytes(), fixed, sig
+    return np.asarray(p, dtype=np.float64).tobytes(), frozen, sig
+
+
+def _powellAhead(width):
+    """The points SciPy's Powell line search is going to ask for NEXT, known before any value is (gpUtils.py:238:
+    ``minimize(_nll, method="powell")``).  ``_linesearch_powell`` minimises ``myfunc(alpha) = f(p + alpha xi)`` with
+    Brent's method, which first brackets from (0, 1): f(0) is the current point (a memo hit), then f(1), then
+    f(2.618034) if f(0) > f(1) else f(-1.618034); when that third value already closes the bracket (two line
+    searches in three) Brent's first step is a golden-section one whose abscissa depends only on which of the two
+    brackets it is.  So when f(1) is asked for, the four abscissae after it are known; an evaluation occupies a
+    quarter of the chip, so they ride along with f(1) in one batched device call and the next two answers come from
+    the memo -- SciPy sees the same values in the same order, bit for bit.
+
+    The abscissae are recomputed with SciPy's own constants and expressions from the frames of the caller
+    (``bracket`` <- ``Brent.get_bracket_info``: ``_gold``, ``tol``, ``_cg``, ``_mintol``) and the points as
+    ``p + alpha * xi`` from ``myfunc``'s closure, exactly as ``myfunc`` forms them.  Anything unexpected in those
+    frames (another SciPy, another method, another call site): no look-ahead, nothing else changes.  A wrong guess
+    costs idle-CU work only: a point that is never asked for is never used.
+
+    Returns up to ``width`` points (most likely first), or None."""
+    try:
+        line = sys._getframe(2)                        # _nll's caller: SciPy's function wrapper <- myfunc(alpha)
+        for _ in range(4):                             # (a caller's own thin wrapper around _nll may sit in between)
+            if line is None or line.f_code.co_name == "myfunc":
+                break
+            line = line.f_back
+        if line is None or line.f_code.co_name != "myfunc":
+            return None
+        brack = line.f_back
+        if brack is None or brack.f_code.co_name != "bracket":
+            return None
+        loc, bl = line.f_locals, brack.f_locals
+        alpha, base, xi = loc["alpha"], loc["p"], loc["xi"]
+        if "fb" in bl or "fa" not in bl or not (alpha == 1.0 and bl["xa"] == 0.0 and bl["xb"] == 1.0):
+            return None                                # not "fb = func(xb)" of a (0, 1) start
+        gold = bl["_gold"]
+        info = brack.f_back
+        brent = info.f_locals.get("self") if info is not None and info.f_code.co_name == "get_bracket_info" else None
+        xa, xb = bl["xa"], bl["xb"]
+        out = []
+        for lo, hi in ((xa, xb), (xb, xa)):            # f(0) > f(1): no swap; f(0) < f(1): (xa, xb) swapped
+            xc = hi + gold * (hi - lo)
+            out.append((xc, None))
+        if brent is not None and width > 2:
+            for (lo, hi), (xc, _) in zip(((xa, xb), (xb, xa)), list(out)):
+                # Brent.optimize on the bracket (lo, hi, xc): x = hi; deltax = 0 -> a golden-section step
+                x = hi
+                a, b = (lo, xc) if lo < xc else (xc, lo)
+                tol1 = brent.tol * np.abs(x) + brent._mintol
+                xmid = 0.5 * (a + b)
+                deltax = (a - x) if x >= xmid else (b - x)
+                rat = brent._cg * deltax
+                if np.abs(rat) < tol1:
+                    u = x + tol1 if rat >= 0 else x - tol1
+                else:
+                    u = x + rat
+                out.append((u, None))
+        return [base + a_ * xi for a_, _ in out[:width]]
+    except (KeyError, AttributeError, ValueError, TypeError):
+        return None
 
 
 def _nll(p, gp, y, priorFn=None):
@@ -83,6 +146,19 @@ def _nll(p, gp, y, priorFn=None):
         if hit is not None:
             table.move_to_end(key)
             return hit
+        width = gp.lookahead_width() if hasattr(gp, "lookahead_width") else 0
+        if width > 0:
+            ahead = _powellAhead(width)
+            if ahead:
+                ahead = [q for q in ahead if priorFn is None or np.isfinite(priorFn(q))]
+            if ahead:
+                vals = gp.nll_batch(np.array([p] + ahead), y)      # entry b: what _nll(P[b]) returns, bit for bit
+                for q, v in zip(ahead, vals[1:]):
+                    table[_memoKey(q, gp)] = float(v)
+                val = table[key] = float(vals[0])
+                while len(table) > _MEMO_SIZE:
+                    table.popitem(last=False)
+                return val
     ll = gp.log_likelihood(y, quiet=True)
     val = -ll if np.isfinite(ll) else np.inf
     if table is not None:

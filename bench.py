@@ -266,7 +266,12 @@ def cpu_baseline(n_train, ndim, metric, seconds=12.0, scalar_calls=2000):
     env = dict(os.environ)
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):   # a launcher's "1 thread per rank"
         env.pop(k, None)
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, timeout=420.0 + 4.0 * seconds)
+    except subprocess.TimeoutExpired:
+        # the bench line is not held hostage by the host-side baseline: say so instead of a number
+        return {"value": None, "unit": "candidates/s", "cores": None, "kind": "port",
+                "sample": "cpu-baseline worker exceeded its time limit and was stopped"}
     if proc.returncode != 0:
         raise RuntimeError("cpu-baseline worker failed with exit code %d" % proc.returncode)
     return json.loads(proc.stdout.strip().splitlines()[-1])
@@ -279,6 +284,9 @@ def _pool_init(threads, n_train, ndim, metric):
     """A pool worker: its own oracle GP on the same training set (an identical factor in every worker;
     nothing is shared, so the workers scale like independent processes do) with ``threads`` BLAS threads."""
     from threadpoolctl import threadpool_limits
+    import scipy.linalg  # noqa: F401 -- SciPy carries its OWN OpenBLAS: loaded before the limit below, or it is not limited
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import george_oracle  # noqa: F401
     _POOL["limits"] = threadpool_limits(limits=int(threads))
     X, y = synthetic_c3(n_train, ndim)
     gpo, _ = oracle_gp(X, y, metric, ndim)
@@ -340,6 +348,8 @@ def cpu_baseline_worker(args):
     ds = time.time() - t1
     # (ii) batched path over the pool
     ctx = mp.get_context("spawn")       # fresh interpreters: no BLAS thread pool inherited across a fork
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = str(threads)    # read by the workers' BLAS libraries when THEY load them (this process's are loaded)
     pool = ctx.Pool(workers, initializer=_pool_init, initargs=(threads, n, d, args.metric))
     try:
         pool.map(_pool_chunk, range(workers), chunksize=1)      # untimed: every worker fitted, pages touched

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define APGP_ABI_VERSION 7
+#define APGP_ABI_VERSION 8
 #define APGP_MAX_DIM 32          /* feature dimension D supported by the kernels (instantiated for D padded to 2 / 4 / 8 / 16 / 32) */
 #define APGP_ROW_BLOCK 512       /* rows per packed L^-1 row block (sweep tile)  */
 #define APGP_K_CHUNK 16          /* contraction depth per packed tile            */
@@ -198,7 +198,15 @@ int64_t apgp_potrf_backoff_skips(void);
  * n <= 128 and batch <= 64 (round 5; the README configuration's restarts): ONE launch of the fused
  * single-workgroup evaluation of apgp_nll_eval, a workgroup per matrix; kernel constants, shifts and
  * the records travel through the stream's pinned, device-mapped staging area (each workgroup posts
- * its own sequence word: no copy, no synchronisation).  Same bits again.                          */
+ * its own sequence word: no copy, no synchronisation).  Same bits again.
+ * 128 < n <= 3200 and 2 <= batch <= 8 (round 6; the look-ahead points of a Powell line search,
+ * gpUtils.py:238): the matrices' persistent launches run SIDE BY SIDE -- matrix 0 on `stream`, the
+ * others on library-owned non-blocking streams forked from / joined to it by events -- each
+ * counting on 1 / batch of the CUs: a batch costs little more than one evaluation (a persistent
+ * launch is a latency chain on a quarter of the chip).  Every matrix runs the launches of the
+ * single call: same bits.  A launch that gives up sends the batch to the batched launch-per-step
+ * path.  apgp_nll_side_batches: batches served side by side so far (process-wide).              */
+int64_t apgp_nll_side_batches(void);
 int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch,
                         const apgp_kernel_t* kerns /*host*/, const double* y,
                         const double* means /*host*/, double* K, double* z,

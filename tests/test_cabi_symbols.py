@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_abi_version_and_sizes():
     lib = _lib.load()
-    assert lib.apgp_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.apgp_abi_version() == _lib.ABI_VERSION == 8
     assert lib.apgp_npad(1) == 512 and lib.apgp_npad(512) == 512 and lib.apgp_npad(513) == 1024
     # packed L^-1: row block ib holds (ib+1)*32 tiles of 512 x 16 doubles
     for n, nrb in ((100, 1), (4096, 8), (4097, 9)):

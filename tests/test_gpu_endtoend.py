@@ -221,7 +221,7 @@ def test_default_gp_with_linear_order_end_to_end():
     assert np.isfinite(ap.gp.log_likelihood(ap.y))
 
 
-@pytest.mark.parametrize("n,d", [(50, 2), (64, 3), (65, 2), (90, 2), (128, 8), (129, 4), (700, 5)])
+@pytest.mark.parametrize("n,d", [(50, 2), (64, 3), (65, 2), (90, 2), (128, 8), (129, 4), (700, 5), (1152, 8), (1601, 3)])
 def test_nll_batch_is_bit_identical_to_single_evaluations(n, d):
     """apgp_nll_eval_batch: several hyper-vectors through ONE batched
     Gram + Cholesky + solve.  Every entry equals gpUtils._nll of that vector exactly --
@@ -261,6 +261,15 @@ def test_nll_batch_is_bit_identical_to_single_evaluations(n, d):
     finally:
         lib.apgp_potrf_mode(0)
     assert np.array_equal(batch, batch_ml), (batch, batch_ml)
+    if n > 128:
+        # round 6: a batch of 2 .. 8 mid-size matrices = their persistent launches side by side (own stream, scratch and
+        # mailbox each, 1 / batch of the CUs each); the first call above took that path -- same bits as the single calls
+        # (asserted above) -- and so do the smaller batches a Powell look-ahead asks for
+        before = lib.apgp_nll_side_batches()
+        for B in (2, 3, 5):
+            with np.errstate(all="ignore"):
+                assert np.array_equal(gp.nll_batch(P[:B], y), single[:B])
+        assert lib.apgp_nll_side_batches() == before + 3 or lib.apgp_potrf_backoff_skips() > 0
     print("nll_batch N=%d: 7 evaluations %.2f ms batched, %.2f ms one by one" % (n, 1e3 * t_batch, 1e3 * t_single))
 
 

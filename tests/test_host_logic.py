@@ -326,3 +326,109 @@ def test_lockstep_evaluator_edge_cases():
 
     with pytest.raises(RuntimeError):
         gpUtils._minimizeLockStep(Broken(), None, [np.zeros(2), np.ones(2)], "powell", None, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Powell look-ahead (gpUtils._powellAhead): the points SciPy is going to ask for next are evaluated with the one it
+# asks for now; SciPy must see the same values in the same order (gpUtils.py:238).
+# ---------------------------------------------------------------------------------------------------------------
+
+def _lookahead_stub(width):
+    import george_oracle as go
+    from approxposterior_amd import gpUtils
+
+    class Stub(go.GP):
+        """The oracle GP + the three members gpUtils._nll's memo / look-ahead use."""
+        _nllMemo = None
+        rounds = 0            # device rounds: single evaluations + batches
+        batched = 0           # points evaluated in batches
+        fit_white_noise = False
+
+        def lookahead_width(self):
+            return width
+
+        def log_likelihood(self, y, quiet=False):
+            Stub.rounds += 1
+            return super().log_likelihood(y, quiet=quiet)
+
+        def nll_batch(self, P, y):
+            Stub.rounds += 1
+            Stub.batched += len(P)
+            saved = self.get_parameter_vector()
+            out = []
+            for q in P:
+                self.set_parameter_vector(q)
+                ll = go.GP.log_likelihood(self, y, quiet=True)
+                out.append(-ll if np.isfinite(ll) else np.inf)
+            self.set_parameter_vector(saved)
+            return np.array(out)
+
+        # (the oracle's recompute() goes through compute(): the memo is not dropped there, as the HIP GP's is not by
+        # its own refactorisations -- only a user's compute() on a new training set does that)
+
+    return Stub, gpUtils, go
+
+
+def test_powell_lookahead_serves_scipy_the_same_values_in_fewer_device_rounds(monkeypatch):
+    from scipy.optimize import minimize, rosen
+    results = {}
+    for width in (0, 2, 4):
+        Stub, gpUtils, go = _lookahead_stub(width)
+        monkeypatch.setattr(gpUtils, "george", go)           # _memoKey compares kernel types with the module's names
+        rs = np.random.RandomState(3)
+        X = rs.uniform(-5, 5, size=(60, 3))
+        y = np.array([-rosen(x) / 100.0 for x in X])
+        gp = Stub(kernel=go.ExpSquaredKernel(np.fabs(rs.randn(3)) + 0.5, ndim=3), fit_mean=True, mean=np.median(y),
+                  white_noise=-12, fit_white_noise=False)
+        gp.compute(X)
+        seen = []
+
+        def fn(p, *args):
+            v = gpUtils._nll(p, *args)
+            seen.append((np.array(p).tobytes(), v))
+            return v
+        x0 = [np.median(y)] + list(rs.randn(3))
+        with np.errstate(all="ignore"):
+            res = minimize(fn, x0, args=(gp, y, gpUtils.defaultHyperPrior), method="powell",
+                           options={"maxiter": 4})
+        results[width] = (res["x"].tobytes(), res["nfev"], seen, Stub.rounds, Stub.batched)
+    base = results[0]
+    assert base[4] == 0
+    for width in (2, 4):
+        got = results[width]
+        assert got[0] == base[0] and got[1] == base[1]       # the same optimum, the same number of SciPy evaluations
+        assert got[2] == base[2]                             # every point and every value SciPy saw, in order, bit for bit
+        assert got[4] > 0
+    # two line searches in three stop bracketing after the third point: width 4 saves two rounds there, width 2 one
+    assert results[4][3] < results[2][3] < base[3]
+    assert results[4][3] <= 0.88 * base[3], (results[4][3], base[3])
+
+
+def test_powell_lookahead_abscissae_are_scipys():
+    """The look-ahead recomputes SciPy's abscissae from SciPy's frames; pin them for the SciPy in this image."""
+    from scipy.optimize import minimize
+    from approxposterior_amd import gpUtils
+    asked, guessed = [], []
+
+    def f(p):
+        asked.append(np.array(p))
+        got = gpUtils._powellAhead(4)
+        # (called from the objective itself: one frame less than from inside _nll -- shift by wrapping)
+        return float(np.sum((p - np.array([0.3, -1.2])) ** 2) + 0.1 * np.sum(p ** 4))
+
+    def g(p):        # same depth as _nll -> _powellAhead: objective -> helper
+        asked.append(np.array(p))
+        pts = gpUtils._powellAhead(4)
+        if pts is not None:
+            guessed.append((len(asked) - 1, [np.array(q) for q in pts]))
+        return float(np.sum((p - np.array([0.3, -1.2])) ** 2) + 0.1 * np.sum(p ** 4))
+    minimize(g, np.array([2.0, 1.5]), method="powell", options={"maxiter": 3})
+    assert guessed, "no line search was recognised: SciPy's Powell has changed shape -- see gpUtils._powellAhead"
+    hits = 0
+    for at, pts in guessed:
+        assert len(pts) == 4
+        nxt = asked[at + 1]
+        assert any(np.array_equal(nxt, q) for q in pts[:2])          # the third bracket point is one of the first two
+        if at + 2 < len(asked) and any(np.array_equal(asked[at + 2], q) for q in pts[2:]):
+            hits += 1                                                 # Brent's first step, when the bracket closed at once
+    assert hits >= len(guessed) // 3
