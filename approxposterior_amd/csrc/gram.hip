@@ -37,7 +37,7 @@ struct GramArgs {
 // group g); each thread produces 16 rows of its column so that a wavefront
 // writes 64 consecutive doubles (512 B) of one row at a time.
 template <int DPAD>
-__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+__device__ __forceinline__ void gram_body(const GramArgs& a) {
     __shared__ double xi[64][DPAD + 1];
     __shared__ double xj[64][DPAD + 1];
     __shared__ double etab[APGP_EXP_TAB_N];
@@ -78,6 +78,18 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     }
 }
 
+template <int DPAD>
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) { gram_body<DPAD>(a); }
+
+// `batch` Gram matrices of the SAME training set at different hyper-parameters in ONE launch (gridDim.y = batch): the
+// argument records of all matrices travel in the kernel-argument segment, a workgroup picks its own by blockIdx.y and runs
+// the single launch's body -- the same values (apgp_nll_eval_batch for a Powell look-ahead, potrf.hip).
+#define APGP_GRAM_BATCH_MAX 6
+struct GramBatchArgs { GramArgs m[APGP_GRAM_BATCH_MAX]; };
+static_assert(sizeof(GramBatchArgs) <= 4096, "kernel-argument segment");
+template <int DPAD>
+__global__ __launch_bounds__(256) void gram_batch_kernel(GramBatchArgs b) { gram_body<DPAD>(b.m[blockIdx.y]); }
+
 // Gram matrix; with z != NULL also z = y - shift and *info_dev = "no failure yet" for the
 // factorisation that follows (apgp_nll_eval: two launches fewer per evaluation)
 int apgp_gram_with_rhs(const double* X, int64_t n, const apgp_kernel_t* kern, double* K, int64_t ldk,
@@ -97,6 +109,34 @@ int apgp_gram_with_rhs(const double* X, int64_t n, const apgp_kernel_t* kern, do
         case 8: hipLaunchKernelGGL(gram_kernel<8>, grid, block, 0, s, a); break;
         case 16: hipLaunchKernelGGL(gram_kernel<16>, grid, block, 0, s, a); break;
         default: hipLaunchKernelGGL(gram_kernel<32>, grid, block, 0, s, a); break;
+    }
+    APGP_CHECK_LAUNCH();
+    return 0;
+}
+
+// the batched form: matrix b = K + b n^2 (ld n), right-hand side z + b n = y - shifts[b], info word info_dev + b
+int apgp_gram_with_rhs_batch(const double* X, int64_t n, int64_t batch, const apgp_kernel_t* kerns, double* K,
+                             const double* y, const double* shifts, double* z, int32_t* info_dev, void* stream) {
+    APGP_CHECK_ARG(X && K && kerns, "null pointer");
+    APGP_CHECK_ARG(n >= 1 && batch >= 1 && batch <= APGP_GRAM_BATCH_MAX, "n >= 1 and 1 <= batch <= 6 required");
+    GramBatchArgs g;
+    for (int64_t b = 0; b < batch; ++b) {
+        GramArgs& a = g.m[b];
+        APGP_CHECK_ARG(apgp_make_kernconst(kerns + b, &a.kc) == 0, "kernel parameters");
+        APGP_CHECK_ARG(a.kc.dpad == g.m[0].kc.dpad && a.kc.ndim == g.m[0].kc.ndim, "kernels of one batch share their dimension");
+        a.X = X; a.K = K + b * n * n; a.n = n; a.ldk = n;
+        a.y = y; a.z = z ? z + b * n : nullptr; a.info = info_dev ? info_dev + b : nullptr; a.shift = shifts ? shifts[b] : 0.0;
+    }
+    for (int64_t b = batch; b < APGP_GRAM_BATCH_MAX; ++b) g.m[b] = g.m[0];
+    const long long nb = (n + 63) / 64;
+    dim3 grid((unsigned)(nb * (nb + 1) / 2), (unsigned)batch), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (g.m[0].kc.dpad) {
+        case 2: hipLaunchKernelGGL(gram_batch_kernel<2>, grid, block, 0, s, g); break;
+        case 4: hipLaunchKernelGGL(gram_batch_kernel<4>, grid, block, 0, s, g); break;
+        case 8: hipLaunchKernelGGL(gram_batch_kernel<8>, grid, block, 0, s, g); break;
+        case 16: hipLaunchKernelGGL(gram_batch_kernel<16>, grid, block, 0, s, g); break;
+        default: hipLaunchKernelGGL(gram_batch_kernel<32>, grid, block, 0, s, g); break;
     }
     APGP_CHECK_LAUNCH();
     return 0;

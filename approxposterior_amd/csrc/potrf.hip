@@ -61,6 +61,9 @@ struct PotrfArgs {
     // then reports PP_ABORTED in the summary's info slot and the host re-runs on the multi-launch path
     const unsigned long long* abort_word;
     unsigned long long abort_id;
+    // batched persistent factorisation (round 6): matrix y's abort word / mailbox record lie y * batch_abort words /
+    // y * batch_mail doubles further on (0, 0: one abort word, the record of matrix 0 only -- everything before round 6)
+    long long batch_abort = 0, batch_mail = 0;
     // hybrid factorisation (large n: the first block columns by the launch-per-step path, the rest by ONE persistent
     // launch on the trailing matrix): the step that hands over applies its block column to the whole trailing matrix and
     // writes the first tile column back instead of carrying on with the panel (no_panel); the persistent launch sees the
@@ -103,6 +106,8 @@ __device__ __forceinline__ void potrf_select(PotrfArgs& a) {
     a.info += blockIdx.y;
     if (a.dscr) a.dscr += (long long)blockIdx.y * a.batch_dscr;
     if (a.out5) a.out5 += 5 * (long long)blockIdx.y;
+    if (a.abort_word) a.abort_word += (long long)blockIdx.y * a.batch_abort;
+    if (a.mail) a.mail += (long long)blockIdx.y * a.batch_mail;
 }
 
 // Panel step of block column j, three wavefronts per workgroup; workgroup b owns the 64 panel rows
@@ -1207,7 +1212,7 @@ __global__ __launch_bounds__(256) void potrf_finish_kernel(PotrfArgs a) {
             a.out5[2] = mx;
             a.out5[3] = zz;
             a.out5[4] = aborted ? -7777.0 /* PP_ABORTED */ : (double)sinfo;
-            if (a.mail && blockIdx.y == 0) {
+            if (a.mail && (blockIdx.y == 0 || a.batch_mail != 0)) {
                 a.mail[0] = 2.0 * sl;
                 a.mail[1] = mn;
                 a.mail[2] = mx;
@@ -1599,40 +1604,17 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
     return nll_fetch(mb, mail, seq, s, out5_dev, out5_host);
 }
 
-// ---- a small batch of mid-size evaluations: their persistent launches SIDE BY SIDE (round 6) -------------------------
+// ---- a small batch of mid-size evaluations: their persistent factorisations SIDE BY SIDE in one launch (round 6) -----
 // One persistent Cholesky occupies nb + ~30 % of its first step's tiles workgroups (67 of 256 CUs at n = 1152) and is a
-// latency chain: several of them run next to each other at little more than the time of one.  Each matrix gets its own
-// stream -- the caller's for matrix 0, library-owned non-blocking side streams for the others, forked from and joined to
-// the caller's stream by events -- hence its own scratch, flags and mailbox; each launch sizes its update workgroups to
-// 1 / batch of the CUs, so all workgroups of all launches are resident together.  Every matrix runs exactly the code of
-// the single call (Gram launch, persistent launch, finish launch): the same bits.  A launch that gives up (another
-// process holds CUs) sends the whole batch to the batched launch-per-step path, as the single call does.
-#define PP_SIDE_MAX 7
-struct PpSideSet {
-    std::mutex mu;                 // one batch at a time per device: the side streams are shared
-    bool tried = false, ok = false;
-    hipStream_t st[PP_SIDE_MAX];
-    hipEvent_t fork, join[PP_SIDE_MAX];
-};
-static PpSideSet* pp_side_set(int dev) {
-    static PpSideSet sets[64];
-    if (dev < 0 || dev >= 64) return nullptr;
-    PpSideSet* ss = &sets[dev];
-    std::lock_guard<std::mutex> lock(ss->mu);
-    if (!ss->tried) {
-        ss->tried = true;
-        int cur = -1;
-        if (hipGetDevice(&cur) != hipSuccess) return nullptr;
-        if (cur != dev && hipSetDevice(dev) != hipSuccess) return nullptr;
-        bool ok = hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; ok && i < PP_SIDE_MAX; ++i)
-            ok = hipStreamCreateWithFlags(&ss->st[i], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&ss->join[i], hipEventDisableTiming) == hipSuccess;
-        if (cur != dev) (void)hipSetDevice(cur);
-        ss->ok = ok;
-    }
-    return ss->ok ? ss : nullptr;
-}
+// latency chain: several of them next to each other take little more than the time of one (measured, N = 1152:
+// 2 / 3 / 4 matrices 366 / 382 / 402 us against 342 for one).  Three launches, as for a single evaluation: the batched
+// Gram launch (gram.hip), potrf_persist_batch_kernel (gridDim.y = batch; every matrix with its own scratch region, flags
+// and granule streams, its update workgroups sized to 1 / batch of the CUs so that all workgroups of all matrices are
+// resident together) and the batched finish launch, whose records come back through the stream's pinned staging area
+// (one sequence word per matrix).  Every matrix runs exactly the code of the single call: the same bits.  A matrix whose
+// workgroups give up (another process holds CUs) sends the whole batch to the batched launch-per-step path.
+int apgp_gram_with_rhs_batch(const double* X, int64_t n, int64_t batch, const apgp_kernel_t* kerns, double* K,
+                             const double* y, const double* shifts, double* z, int32_t* info_dev, void* stream);   // gram.hip
 static std::atomic<long long> g_pp_side_batches{0};
 extern "C" int64_t apgp_nll_side_batches(void) { return g_pp_side_batches.load(); }
 
@@ -1643,55 +1625,102 @@ static int nll_batch_side_by_side(const double* X, int64_t n, int64_t batch, con
                                   double* out5_host, hipStream_t s) {
     const int mode = g_potrf_mode.load();
     if (mode != 0 && mode != 3) return 1;
+    if (batch < 2 || batch > PP_BATCH_MAX) return 1;
     if (potrf_plan(n, n, s) != 0) return 1;                               // one persistent launch per matrix, no hybrid
     const int dev = apgp_stream_device(s);
     const int cus = potrf_device_cus(dev);
     const long long nb = (n + PB - 1) / PB;
-    const int budget = (int)(cus / batch);
-    if (budget < nb + 2) return 1;                                        // every launch: its row workgroups + >= 2 update workgroups
-    PpSideSet* ss = pp_side_set(dev);
-    if (!ss) return 1;
-    std::lock_guard<std::mutex> batch_lock(ss->mu);
-    ApgpMailbox* mbs[PP_SIDE_MAX + 1];
-    hipStream_t sts[PP_SIDE_MAX + 1];
-    for (int64_t b = 0; b < batch; ++b) {
-        sts[b] = b == 0 ? s : ss->st[b - 1];
-        mbs[b] = apgp_stream_mailbox(sts[b]);
-        if (!mbs[b] || !mbs[b]->host) return 1;
-    }
+    const long long budget = cus / batch;                                 // CUs per matrix
+    if (budget < nb + 2) return 1;                                        // its row workgroups + >= 2 update workgroups
+    std::lock_guard<std::mutex> lock(apgp_stream_lock(s));
+    double* io_dev = nullptr;
+    double* io = apgp_stream_pinned_io(s, (size_t)batch * 8, &io_dev);
+    ApgpMailbox* mb = io ? apgp_stream_mailbox(s) : nullptr;
+    if (!io || !mb || !mb->host) return 1;
     if (pp_backoff_take(dev)) return 1;
-    if (hipEventRecord(ss->fork, s) != hipSuccess) return 1;
-    long long seqs[PP_SIDE_MAX + 1];
-    int rc = 0;
-    int64_t launched = 0;
-    for (int64_t b = 0; b < batch && rc == 0; ++b) {
-        std::lock_guard<std::mutex> lock(apgp_stream_lock(sts[b]));
-        if (b > 0 && hipStreamWaitEvent(sts[b], ss->fork, 0) != hipSuccess) { rc = -2; break; }
-        seqs[b] = ++mbs[b]->seq;
-        rc = apgp_gram_with_rhs(X, n, kerns + b, K + b * n * n, n, y, means[b], z + b * n, info_dev + b, (void*)sts[b]);
-        if (rc == 0)
-            rc = potrf_persist_locked(K + b * n * n, n, n, z + b * n, info_dev + b, sts[b], out5_dev + 5 * b, mbs[b]->dev,
-                                      seqs[b], 0, budget);
-        if (rc == 0) launched = b + 1;
+    int rc = apgp_gram_with_rhs_batch(X, n, batch, kerns, K, y, means, z, info_dev, (void*)s);
+    if (rc != 0) return rc;
+    PersistBatchArgs qb;
+    PotrfArgs full;
+    {
+        PotrfArgs& a = full;
+        a.A = K; a.rhs = z; a.n = n; a.lda = n; a.j0 = 0; a.shift = 0.0; a.info = info_dev; a.out5 = out5_dev;
+        a.batch_A = n * n; a.batch_rhs = n; a.no_panel = 0; a.info_j0 = 0; a.pair_mode = 0; a.defer8 = 0; a.deferred8 = 0;
+        a.zoff = nb * (long long)(PB * PB); a.batch_dscr = a.zoff + nb * PB;
+        a.dscr = apgp_stream_scratch(0, s, (size_t)a.batch_dscr * (size_t)batch);
     }
-    bool gave_up = false;
-    for (int64_t b = 0; b < launched; ++b) {
-        std::lock_guard<std::mutex> lock(apgp_stream_lock(sts[b]));
-        const int rw = mailbox_wait(mbs[b], seqs[b], sts[b], out5_host + 5 * b);
-        if (rw != 0 && rc == 0) rc = rw;
-        if (rw == 0 && out5_host[5 * b + 4] == PP_ABORTED) gave_up = true;
+    bool fresh = false;
+    unsigned long long* calls = nullptr;
+    pp_u64* pw = (pp_u64*)apgp_stream_scratch_ex(2, s, (size_t)PP_SCRATCH_WORDS * (size_t)batch, &fresh, &calls);
+    if (!full.dscr || !pw) {
+        apgp_set_error("apgp_nll_eval_batch: scratch allocation failed");
+        return -2;
     }
-    // the caller's stream continues behind every side stream (the records are out, the finish kernels may not be)
-    for (int64_t b = 1; b < launched; ++b)
-        if (hipEventRecord(ss->join[b - 1], sts[b]) != hipSuccess || hipStreamWaitEvent(s, ss->join[b - 1], 0) != hipSuccess)
-            if (rc == 0) rc = -2;
-    if (rc != 0) {
-        if (rc == -2) apgp_set_error("apgp_nll_eval_batch: side-by-side launch failed");
-        return rc;
+    unsigned long long id = ++*calls;
+    if ((unsigned)id == 0u) { fresh = true; id = ++*calls; }             // (the 32-bit granule tag wrapped: start over)
+    if (fresh && hipMemsetAsync(pw, 0, (size_t)PP_SCRATCH_WORDS * 8 * (size_t)batch, s) != hipSuccess) {
+        apgp_set_error("apgp_nll_eval_batch: memset failed");
+        return -2;
+    }
+    const long long seq = ++mb->seq;
+    full.abort_word = pw + PP_CTL_ABORT; full.abort_id = id; full.batch_abort = PP_SCRATCH_WORDS;
+    full.mail = io_dev; full.batch_mail = 8; full.seq = seq;
+    for (int64_t b = 0; b < PP_BATCH_MAX; ++b) {
+        const int64_t m = b < batch ? b : 0;                              // (unused records: copies of matrix 0's, never read)
+        PersistArgs& q = qb.m[b];
+        q.a = full;
+        q.a.A = K + m * n * n; q.a.rhs = z + m * n; q.a.info = info_dev + m; q.a.out5 = out5_dev + 5 * m;
+        q.a.dscr = full.dscr + m * full.batch_dscr;
+        q.a.batch_A = 0; q.a.batch_rhs = n; q.a.batch_abort = 0; q.a.batch_mail = 0; q.a.mail = nullptr;
+        q.ctl = pw + m * (long long)PP_SCRATCH_WORDS; q.strm = q.ctl + PP_CTL_WORDS; q.zstrm = q.strm + PP_STRM_WORDS;
+        q.a.abort_word = q.ctl + PP_CTL_ABORT; q.a.abort_id = id;
+        q.call_id = id;
+        q.timeout = 5000000ull;                                           // 50 ms of the 100 MHz clock
+        q.nb = (int)nb;
+        q.debug = 0;
+    }
+    {
+        static std::mutex attr_mu;
+        static bool attr_set[64] = {false};
+        std::lock_guard<std::mutex> alock(attr_mu);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            if (hipFuncSetAttribute((const void*)potrf_persist_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess) {
+                apgp_set_error("apgp_nll_eval_batch: hipFuncSetAttribute failed");
+                return -2;
+            }
+            attr_set[dev] = true;
+        }
+    }
+    const long long tiles0 = (nb - 1) * (nb - 2) / 2;
+    long long nupd = (tiles0 * PP_NUPD_PCT + 99) / 100 + 8;               // as the single launch (potrf_persist_locked) ...
+    if (nupd > tiles0) nupd = tiles0;
+    if (nupd > budget - nb) nupd = budget - nb;                           // ... within this matrix's share of the CUs
+    if (nupd < 1) nupd = 1;
+    hipLaunchKernelGGL(potrf_persist_batch_kernel, dim3((unsigned)(nb + nupd), (unsigned)batch), dim3(PP_THREADS), PP_LDS_BYTES, s, qb);
+    hipLaunchKernelGGL(potrf_finish_kernel, dim3((unsigned)nb, (unsigned)batch), dim3(256), 0, s, full);
+    APGP_CHECK_LAUNCH();
+    // the records: one sequence word per matrix (bounded spin, then the ordinary synchronisation)
+    bool gave_up = false, synced = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t b = 0; b < batch; ++b) {
+        volatile long long* flag = (volatile long long*)(io + 8 * b + 5);
+        unsigned spins = 0;
+        while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(800)) {
+                if (synced || hipStreamSynchronize(s) != hipSuccess || __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                    apgp_set_error("apgp_nll_eval_batch: result record not written");
+                    return -2;
+                }
+                synced = true;
+            }
+        }
+        for (int i = 0; i < 5; ++i) out5_host[5 * b + i] = io[8 * b + i];
+        if (out5_host[5 * b + 4] == PP_ABORTED) gave_up = true;
     }
     if (gave_up) {
         g_potrf_fallbacks.fetch_add(1);
         pp_backoff_report(dev, true);
+        if (hipStreamSynchronize(s) != hipSuccess) return -2;             // (nothing of the launch is still running when the re-run starts)
         return 1;
     }
     pp_backoff_report(dev, false);
@@ -1757,7 +1786,7 @@ extern "C" int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch, co
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    if (batch >= 2 && batch <= PP_SIDE_MAX + 1) {
+    if (batch >= 2 && batch <= PP_BATCH_MAX) {
         rc = nll_batch_side_by_side(X, n, batch, kerns, y, means, K, z, info_dev, out5_dev, out5_host, s);
         if (rc <= 0) return rc;                                            // (1: not applicable / gave up -- the batched launches below)
     }

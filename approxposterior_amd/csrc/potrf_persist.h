@@ -856,7 +856,8 @@ __device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
 #include "potrf_persist_sg.h"
 #endif
 
-__device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, const unsigned lds_off) {
+// karg_off: byte offset of `q` in the kernel-argument segment (the batched kernel passes one record per matrix)
+__device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, const unsigned lds_off, const unsigned karg_off = 0) {
     const PotrfArgs& a = q.a;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -883,7 +884,7 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
 
     PpKarg karg;
     {
-        const unsigned long long kp = (unsigned long long)(size_t)__builtin_amdgcn_kernarg_segment_ptr();
+        const unsigned long long kp = (unsigned long long)(size_t)__builtin_amdgcn_kernarg_segment_ptr() + karg_off;
         karg.lo = (unsigned)kp; karg.hi = (unsigned)(kp >> 32);
     }
 #ifdef PP_STAMPS
@@ -1095,5 +1096,23 @@ __device__ __forceinline__ void pp_update_role(const PersistArgs& q, double* lds
 __global__ __launch_bounds__(PP_THREADS) void potrf_persist_kernel(PersistArgs q) {
     extern __shared__ __attribute__((aligned(16))) double pp_lds[];
     if ((int)blockIdx.x < q.nb) pp_row_role(q, pp_lds, (unsigned)(size_t)(__attribute__((address_space(3))) double*)pp_lds);
+    else pp_update_role(q, pp_lds);
+}
+
+// Round 6: up to PP_BATCH_MAX matrices of the SAME size factorised side by side by ONE launch (gridDim.y = batch;
+// apgp_nll_eval_batch: the look-ahead points of a Powell line search).  One persistent factorisation is a latency chain
+// on nb + a few dozen CUs; matrix y's workgroups (blockIdx.x as in the single launch) read THEIR argument record --
+// own matrix, right-hand side, info word, scratch (factor blocks, flags, granule streams) -- from the kernel-argument
+// segment and never look at another matrix: the code and the bits of `batch` single launches, at little more than the
+// time of one.  The host sizes gridDim.x so that all workgroups of all matrices are resident at once.
+#define PP_BATCH_MAX 6
+struct PersistBatchArgs { PersistArgs m[PP_BATCH_MAX]; };
+static_assert(sizeof(PersistBatchArgs) <= 4096, "kernel-argument segment");
+__global__ __launch_bounds__(PP_THREADS) void potrf_persist_batch_kernel(PersistBatchArgs qb) {
+    extern __shared__ __attribute__((aligned(16))) double pp_lds[];
+    const unsigned y = blockIdx.y;
+    const PersistArgs& q = qb.m[y];
+    if ((int)blockIdx.x < q.nb)
+        pp_row_role(q, pp_lds, (unsigned)(size_t)(__attribute__((address_space(3))) double*)pp_lds, y * (unsigned)sizeof(PersistArgs));
     else pp_update_role(q, pp_lds);
 }

@@ -886,16 +886,53 @@ class GP(object):
         return ll if np.isfinite(ll) else -np.inf
 
     # Powell look-ahead (gpUtils._powellAhead): how many points beyond the one asked for are worth evaluating in the same
-    # device call -- where a small batch costs little more than one evaluation: n <= 128 (ONE launch, a workgroup per
-    # matrix) and the mid sizes whose persistent launches run side by side (apgp_nll_eval_batch); 0 = off.
-    LOOKAHEAD_MAX_N = 1664
+    # device call -- where a small batch costs little more than one evaluation (apgp_nll_eval_batch: one launch with a
+    # workgroup per matrix up to n = 128; the persistent factorisations side by side in one launch above that, each on
+    # 1 / batch of the CUs -- tools/nll_side_batch.py, profiles/r06c_*: 5 matrices 1.04 / 1.15 / 1.19 x one evaluation at
+    # n = 512 / 832 / 1152, 3 matrices 1.14 x at 1664, 2 matrices 1.13 x at 2048); 0 = off.
     lookahead = None              # None: by size; 0: off; k: that many points
 
     def lookahead_width(self):
         if self.lookahead is not None:
             return int(self.lookahead)
         n = 0 if self._x is None else len(self._x)
-        return 4 if 0 < n <= self.LOOKAHEAD_MAX_N else 0
+        if n <= 0:
+            return 0
+        return 4 if n <= 1344 else (2 if n <= 1728 else (1 if n <= 2112 else 0))
+
+    def _fast_structs(self, P, out):
+        """The C ABI's kernel structs + means of the hyper-vectors ``P`` (B x len(self)) written straight into ``out``
+        (B x 36 doubles = B ``apgp_kernel_t``), for the two kernel shapes ``defaultGP`` builds without a linear term
+        (gpUtils.py:160-165) -- every field by the expression ``_kernel_struct`` uses after ``set_parameter_vector``, so
+        the same bits, without touching the object's state.  None for any other kernel."""
+        k = self.kernel
+        tk = type(k)
+        if tk is ExpSquaredKernel:
+            amp_dim, d = 0, k.ndim
+        elif tk is Product and type(k.k1) is ConstantKernel and type(k.k2) is ExpSquaredKernel:
+            amp_dim, d = k.k1.ndim, k.k2.ndim
+        else:
+            return None
+        at = 0
+        if self.fit_mean:
+            means = P[:, 0].copy(); at += 1
+        else:
+            means = np.full(len(P), float(self.mean.value))
+        ints = out.view(np.int32)
+        out[:] = 0.0
+        ints[:, 0] = d
+        for b in range(len(P)):
+            q = P[b]
+            wn = float(q[at]) if self.fit_white_noise else self.white_noise.value
+            c = at + int(self.fit_white_noise)
+            if amp_dim:
+                out[b, 1] = float(amp_dim * np.exp(float(q[c])))
+                c += 1
+            else:
+                out[b, 1] = 1.0
+            out[b, 2] = float(self._yerr2) + float(np.exp(wn))
+            out[b, 3:3 + d] = np.exp(-np.array(q[c:c + d], dtype=np.float64))
+        return means
 
     def nll_batch(self, P, y):
         """Negative marginal log-likelihood at each hyper-parameter vector of ``P`` (B x P),
@@ -907,9 +944,32 @@ class GP(object):
         torch, dev, lib = self._rt()
         if self._x is None:
             raise RuntimeError("You need to compute the model first")
-        yv = self._check_dimensions(y)
         P = np.atleast_2d(np.asarray(P, dtype=np.float64))
         B, n = len(P), len(self._x)
+        if P.shape[1] != len(self):
+            raise ValueError("dimension mismatch")
+        cache = self._batch_cache
+        fast = None
+        if (B <= 8 and cache is not None and cache["x"] is self._x and type(y) is np.ndarray and y.dtype == np.float64
+                and y.size == n and y.flags.c_contiguous and cache["ybytes"] == y.tobytes()
+                and torch.cuda.current_device() == dev.index and cache["stream"] == (self._stream(torch).value or 0)):
+            # a small batch on the training set, y and stream of the previous one (the look-ahead of a Powell line search,
+            # the rounds of a lock-step fit): buffers, argument list and struct array are ready
+            fast = cache["plans"].get(B)
+        if fast is not None:
+            karr, o, args, fn = fast
+            means = self._fast_structs(P, karr)
+            if means is not None:
+                marr = fast_means = cache["means"][:B]
+                marr[:] = means
+                self.kernel.dirty = True          # (the buffers the object's own factor may share are not touched; as below)
+                self._computed = False
+                _lib.check(fn(*args), "apgp_nll_eval_batch")
+                with np.errstate(all="ignore"):
+                    ll = (-0.5 * (n * np.log(2.0 * np.pi) + o[:, 0])) - 0.5 * o[:, 3]
+                bad = (o[:, 4] != 0.0) | ~np.isfinite(o[:, 0]) | ~np.isfinite(ll)
+                return np.where(bad, np.inf, -ll)
+        yv = self._check_dimensions(y)
         out = np.full(B, np.inf)
         saved = self.get_parameter_vector()
         structs, means, live = [], [], []
@@ -936,12 +996,12 @@ class GP(object):
             # the rounds of a lock-step fit (gpUtils._minimizeLockStep) come back with the same y, batch size and stream a few
             # hundred times: the device copy of y and the work buffers are kept (the call is synchronous: nothing of the
             # previous round is in flight)
-            cache = self._batch_cache
             ybytes = yv.tobytes()
             if (cache is None or cache["x_d"] is not self._x_d or cache["stream"] != (st.value or 0)
-                    or cache["ybytes"] != ybytes):
-                cache = self._batch_cache = {"x_d": self._x_d, "stream": st.value or 0, "ybytes": ybytes,
-                                             "y_d": torch.from_numpy(yv).to(dev), "bufs": {}}
+                    or cache["ybytes"] != ybytes or cache["x"] is not self._x):
+                cache = self._batch_cache = {"x_d": self._x_d, "x": self._x, "stream": st.value or 0, "ybytes": ybytes,
+                                             "y_d": torch.from_numpy(yv).to(dev), "bufs": {}, "plans": {},
+                                             "means": np.empty(8, dtype=np.float64)}
             y_d = cache["y_d"]
             for c0 in range(0, len(live), per):
                 idx = live[c0:c0 + per]
@@ -962,6 +1022,14 @@ class GP(object):
                                                    y_d.data_ptr(), marr.ctypes.data, K.data_ptr(), z.data_ptr(),
                                                    info.data_ptr(), o_d.data_ptr(), o.ctypes.data, st),
                            "apgp_nll_eval_batch")
+                if nb == B and B <= 8 and nb in cache["bufs"] and ctypes.sizeof(_lib.KernelStruct) == 36 * 8:
+                    # the next batch of this size on this training set, y and stream: everything but the hyper-vectors ready
+                    ka = np.zeros((B, 36), dtype=np.float64)
+                    oo = np.empty((B, 5), dtype=np.float64)
+                    cache["plans"][B] = (ka, oo, [self._x_d.data_ptr(), n, B, ka.ctypes.data, y_d.data_ptr(),
+                                                  cache["means"].ctypes.data, K.data_ptr(), z.data_ptr(), info.data_ptr(),
+                                                  o_d.data_ptr(), oo.ctypes.data, ctypes.c_void_p(st.value)],
+                                         lib.apgp_nll_eval_batch)
                 for j, b in enumerate(idx):
                     if int(o[j, 4]) != 0 or not np.isfinite(o[j, 0]):
                         continue

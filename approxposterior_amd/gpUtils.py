@@ -107,11 +107,14 @@ def _powellAhead(width):
         brent = info.f_locals.get("self") if info is not None and info.f_code.co_name == "get_bracket_info" else None
         xa, xb = bl["xa"], bl["xb"]
         out = []
-        for lo, hi in ((xa, xb), (xb, xa)):            # f(0) > f(1): no swap; f(0) < f(1): (xa, xb) swapped
+        # f(0) < f(1): SciPy swaps (xa, xb) and goes on to -1.618034 (three line searches in four: a unit step along a
+        # direction is usually too long) -- that case first; f(0) > f(1): no swap, 2.618034
+        cases = ((xb, xa), (xa, xb))
+        for lo, hi in cases:
             xc = hi + gold * (hi - lo)
             out.append((xc, None))
         if brent is not None and width > 2:
-            for (lo, hi), (xc, _) in zip(((xa, xb), (xb, xa)), list(out)):
+            for (lo, hi), (xc, _) in zip(cases, list(out)):
                 # Brent.optimize on the bracket (lo, hi, xc): x = hi; deltax = 0 -> a golden-section step
                 x = hi
                 a, b = (lo, xc) if lo < xc else (xc, lo)

@@ -199,13 +199,14 @@ int64_t apgp_potrf_backoff_skips(void);
  * single-workgroup evaluation of apgp_nll_eval, a workgroup per matrix; kernel constants, shifts and
  * the records travel through the stream's pinned, device-mapped staging area (each workgroup posts
  * its own sequence word: no copy, no synchronisation).  Same bits again.
- * 128 < n <= 3200 and 2 <= batch <= 8 (round 6; the look-ahead points of a Powell line search,
- * gpUtils.py:238): the matrices' persistent launches run SIDE BY SIDE -- matrix 0 on `stream`, the
- * others on library-owned non-blocking streams forked from / joined to it by events -- each
- * counting on 1 / batch of the CUs: a batch costs little more than one evaluation (a persistent
- * launch is a latency chain on a quarter of the chip).  Every matrix runs the launches of the
- * single call: same bits.  A launch that gives up sends the batch to the batched launch-per-step
- * path.  apgp_nll_side_batches: batches served side by side so far (process-wide).              */
+ * 128 < n <= 3200 and 2 <= batch <= 6 (round 6; the look-ahead points of a Powell line search,
+ * gpUtils.py:238): the matrices' persistent factorisations run SIDE BY SIDE in one launch (gridDim.y
+ * = batch; a batched Gram launch before it, the batched finish launch after it: three launches as
+ * for one evaluation), each matrix on 1 / batch of the CUs with its own scratch, flags and record:
+ * a batch costs little more than one evaluation (a persistent factorisation is a latency chain on a
+ * quarter of the chip).  Every matrix runs the code of the single call: same bits.  A matrix that
+ * gives up sends the batch to the batched launch-per-step path (as n > 3200 and batch > 6 go
+ * anyway).  apgp_nll_side_batches: batches served side by side so far (process-wide).            */
 int64_t apgp_nll_side_batches(void);
 int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch,
                         const apgp_kernel_t* kerns /*host*/, const double* y,

@@ -262,14 +262,14 @@ def test_nll_batch_is_bit_identical_to_single_evaluations(n, d):
         lib.apgp_potrf_mode(0)
     assert np.array_equal(batch, batch_ml), (batch, batch_ml)
     if n > 128:
-        # round 6: a batch of 2 .. 8 mid-size matrices = their persistent launches side by side (own stream, scratch and
-        # mailbox each, 1 / batch of the CUs each); the first call above took that path -- same bits as the single calls
-        # (asserted above) -- and so do the smaller batches a Powell look-ahead asks for
+        # round 6: a batch of 2 .. 6 mid-size matrices = their persistent factorisations side by side in ONE launch (own
+        # scratch, flags and record each, 1 / batch of the CUs each) -- the batches a Powell look-ahead asks for; the same
+        # bits as the single calls (7 matrices, above: the batched launch-per-step path)
         before = lib.apgp_nll_side_batches()
-        for B in (2, 3, 5):
+        for B in (2, 3, 4, 6):
             with np.errstate(all="ignore"):
                 assert np.array_equal(gp.nll_batch(P[:B], y), single[:B])
-        assert lib.apgp_nll_side_batches() == before + 3 or lib.apgp_potrf_backoff_skips() > 0
+        assert lib.apgp_nll_side_batches() == before + 4 or lib.apgp_potrf_backoff_skips() > 0
     print("nll_batch N=%d: 7 evaluations %.2f ms batched, %.2f ms one by one" % (n, 1e3 * t_batch, 1e3 * t_single))
 
 
@@ -396,3 +396,43 @@ def test_optimizegp_batched_restarts_equal_sequential():
         out[mode] = (np.array(gp.get_parameter_vector()), time.time() - t0)
     assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][0], out["always"][0])
     print("optimizeGP 4 restarts N=60: sequential %.2f s, batched %.2f s" % (out[False][1], out["always"][1]))
+
+
+@pytest.mark.parametrize("n,d,amp", [(90, 2, True), (400, 3, False), (1152, 8, False)])
+def test_powell_lookahead_same_optimum_fewer_device_rounds(n, d, amp):
+    """gpUtils._nll's look-ahead (round 6): when SciPy's Powell asks for f(1) of a line search, the abscissae it asks for
+    next ride along in ONE batched device call -- side-by-side persistent factorisations above n = 128, a workgroup per
+    matrix below -- and SciPy sees the same values in the same order: the optimum of optimizeGP (gpUtils.py:184-257) is the
+    same in every bit with and without, in fewer device rounds."""
+    from approxposterior_amd import gpUtils, _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(n)
+    X = rs.uniform(-5, 5, size=(n, d))
+    y = np.sin(X).sum(axis=1) + 0.1 * rs.randn(n)
+    got = {}
+    for ahead in (0, None):
+        np.random.seed(4)
+        gp = gpUtils.defaultGP(X, y, fitAmp=amp)
+        gp.lookahead = ahead
+        seen = []
+        inner = gpUtils._nll
+
+        def spy(p, *args):
+            v = inner(p, *args)
+            seen.append((np.array(p).tobytes(), v))
+            return v
+        gpUtils._nll = spy
+        try:
+            before = lib.apgp_nll_side_batches()
+            with np.errstate(all="ignore"):
+                gp = gpUtils.optimizeGP(gp, X, y, seed=1, nGPRestarts=1, method="powell", options={"maxiter": 3})
+            side = lib.apgp_nll_side_batches() - before
+        finally:
+            gpUtils._nll = inner
+        got[ahead] = (np.array(gp.get_parameter_vector()), seen, side, gp.log_likelihood(y))
+    assert np.array_equal(got[0][0], got[None][0])                  # the optimum: every bit
+    assert got[0][1] == got[None][1] and len(got[0][1]) > 50        # every point and value SciPy saw, in order
+    assert got[0][3] == got[None][3]
+    assert got[0][2] == 0
+    if n > 128:
+        assert got[None][2] >= len(got[None][1]) // 14 or lib.apgp_potrf_backoff_skips() > 0     # ~ one batch per line search

@@ -20,9 +20,17 @@ for N in [int(a) for a in sys.argv[1:]] or [512, 1152]:
     def f(p):
         cnt[0] += 1
         return gpUtils._nll(p, g, y)
-    minimize(f, p0, method="powell", options={"maxfev": 200})
-    torch.cuda.synchronize(); cnt[0] = 0
-    t0 = time.perf_counter()
-    minimize(f, p0, method="powell", options={"maxfev": 1500})
-    t1 = time.perf_counter()
-    print("N = %4d: %.3f ms per evaluation inside scipy Powell (%d evaluations)" % (N, (t1 - t0) / cnt[0] * 1e3, cnt[0]), flush=True)
+    lib = _lib.load()
+    for ahead in (0, None):       # without / with the Powell look-ahead (gpUtils._powellAhead; width by size)
+        g.lookahead = ahead
+        g._nllMemo = None
+        minimize(f, p0, method="powell", options={"maxfev": 200})
+        g._nllMemo = None
+        torch.cuda.synchronize(); cnt[0] = 0
+        sb = lib.apgp_nll_side_batches()
+        t0 = time.perf_counter()
+        res = minimize(f, p0, method="powell", options={"maxfev": 1500})
+        t1 = time.perf_counter()
+        print("N = %4d, look-ahead %-4s: %.1f ms for %d evaluations of scipy's Powell = %.3f ms each (side-by-side batches %d; f = %.10g)"
+              % (N, "off" if ahead == 0 else "on(%d)" % g.lookahead_width(), (t1 - t0) * 1e3, cnt[0], (t1 - t0) / cnt[0] * 1e3,
+                 lib.apgp_nll_side_batches() - sb, res["fun"]), flush=True)
