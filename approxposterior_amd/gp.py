@@ -898,7 +898,7 @@ class GP(object):
         n = 0 if self._x is None else len(self._x)
         if n <= 0:
             return 0
-        return 4 if n <= 1344 else (2 if n <= 1728 else (1 if n <= 2112 else 0))
+        return 5 if n <= 832 else (4 if n <= 1344 else (2 if n <= 1728 else (1 if n <= 2112 else 0)))
 
     def _fast_structs(self, P, out):
         """The C ABI's kernel structs + means of the hyper-vectors ``P`` (B x len(self)) written straight into ``out``

@@ -70,18 +70,52 @@ def _memoKey(p, gp):
     return np.asarray(p, dtype=np.float64).tobytes(), frozen, sig
 
 
+def _brentGolden(brent, x, a, b):
+    """Abscissa of a golden-section step of ``scipy.optimize._optimize.Brent.optimize`` from the state (x; a, b), with
+    its own expressions; None when its convergence test would stop the loop instead."""
+    tol1 = brent.tol * np.abs(x) + brent._mintol
+    tol2 = 2.0 * tol1
+    xmid = 0.5 * (a + b)
+    if np.abs(x - xmid) < (tol2 - 0.5 * (b - a)):
+        return None
+    deltax = (a - x) if x >= xmid else (b - x)
+    rat = brent._cg * deltax
+    if np.abs(rat) < tol1:
+        return x + tol1 if rat >= 0 else x - tol1
+    return x + rat
+
+
+def _brentAhead(brent, xa, xb, xc):
+    """The first TWO abscissae of ``Brent.optimize`` on the bracket (xa, xb, xc) -- ``(u1, u2 if f(u1) > f(xb), u2 if
+    f(u1) <= f(xb))`` -- none of which depends on a function value: the loop starts from x = w = v = xb with deltax = 0,
+    so its first step is a golden-section one; after it either v == x (f(u1) > fx: u1 becomes w, an end of the interval
+    moves to u1) or w == v (f(u1) <= fx: u1 becomes x), and with two of the three points equal the parabola's numerator
+    and denominator are both exactly 0, the fit is rejected and the second step is a golden-section one too, from a state
+    that depends only on which of the two it was.  (The third step interpolates three distinct points: values needed.)"""
+    x = xb
+    a, b = (xa, xc) if xa < xc else (xc, xa)
+    u1 = _brentGolden(brent, x, a, b)
+    if u1 is None:
+        return None, None, None
+    ag, bg = (u1, b) if u1 < x else (a, u1)            # f(u1) > fx: the interval's end on u1's side moves to u1
+    al, bl = (x, b) if u1 >= x else (a, x)             # f(u1) <= fx: x moves to u1, the old x closes the other side
+    return u1, _brentGolden(brent, x, ag, bg), _brentGolden(brent, u1, al, bl)
+
+
 def _powellAhead(width):
     """The points SciPy's Powell line search is going to ask for NEXT, known before any value is (gpUtils.py:238:
     ``minimize(_nll, method="powell")``).  ``_linesearch_powell`` minimises ``myfunc(alpha) = f(p + alpha xi)`` with
     Brent's method, which first brackets from (0, 1): f(0) is the current point (a memo hit), then f(1), then
-    f(2.618034) if f(0) > f(1) else f(-1.618034); when that third value already closes the bracket (two line
-    searches in three) Brent's first step is a golden-section one whose abscissa depends only on which of the two
-    brackets it is.  So when f(1) is asked for, the four abscissae after it are known; an evaluation occupies a
-    quarter of the chip, so they ride along with f(1) in one batched device call and the next two answers come from
-    the memo -- SciPy sees the same values in the same order, bit for bit.
+    f(-1.618034) if f(0) < f(1) (four line searches in five: a unit step is usually too long) else f(2.618034); when that
+    third value closes the bracket (nine times in ten), Brent's first two steps are golden-section steps whose abscissae
+    depend only on which bracket it is and on whether the first step improved (:func:`_brentAhead`).  So when f(1) is
+    asked for, the abscissae of up to three further evaluations are known up to a handful of cases; an evaluation
+    occupies a quarter of the chip, so the likely ones ride along with f(1) in ONE batched device call and the next
+    answers come from the memo -- SciPy sees the same values in the same order, bit for bit.  The same at the two later
+    points where a miss can still look ahead: the third bracket point (its Brent steps) and Brent's first step (its second).
 
-    The abscissae are recomputed with SciPy's own constants and expressions from the frames of the caller
-    (``bracket`` <- ``Brent.get_bracket_info``: ``_gold``, ``tol``, ``_cg``, ``_mintol``) and the points as
+    The abscissae are recomputed with SciPy's own constants and expressions from the frames of the caller (``bracket`` <-
+    ``Brent.get_bracket_info`` <- ``Brent.optimize``: ``_gold``, ``tol``, ``_cg``, ``_mintol``) and the points as
     ``p + alpha * xi`` from ``myfunc``'s closure, exactly as ``myfunc`` forms them.  Anything unexpected in those
     frames (another SciPy, another method, another call site): no look-ahead, nothing else changes.  A wrong guess
     costs idle-CU work only: a point that is never asked for is never used.
@@ -95,39 +129,47 @@ def _powellAhead(width):
             line = line.f_back
         if line is None or line.f_code.co_name != "myfunc":
             return None
-        brack = line.f_back
-        if brack is None or brack.f_code.co_name != "bracket":
+        site = line.f_back
+        if site is None:
             return None
-        loc, bl = line.f_locals, brack.f_locals
+        loc = line.f_locals
         alpha, base, xi = loc["alpha"], loc["p"], loc["xi"]
-        if "fb" in bl or "fa" not in bl or not (alpha == 1.0 and bl["xa"] == 0.0 and bl["xb"] == 1.0):
-            return None                                # not "fb = func(xb)" of a (0, 1) start
-        gold = bl["_gold"]
-        info = brack.f_back
-        brent = info.f_locals.get("self") if info is not None and info.f_code.co_name == "get_bracket_info" else None
-        xa, xb = bl["xa"], bl["xb"]
-        out = []
-        # f(0) < f(1): SciPy swaps (xa, xb) and goes on to -1.618034 (three line searches in four: a unit step along a
-        # direction is usually too long) -- that case first; f(0) > f(1): no swap, 2.618034
-        cases = ((xb, xa), (xa, xb))
-        for lo, hi in cases:
-            xc = hi + gold * (hi - lo)
-            out.append((xc, None))
-        if brent is not None and width > 2:
-            for (lo, hi), (xc, _) in zip(cases, list(out)):
-                # Brent.optimize on the bracket (lo, hi, xc): x = hi; deltax = 0 -> a golden-section step
-                x = hi
-                a, b = (lo, xc) if lo < xc else (xc, lo)
-                tol1 = brent.tol * np.abs(x) + brent._mintol
-                xmid = 0.5 * (a + b)
-                deltax = (a - x) if x >= xmid else (b - x)
-                rat = brent._cg * deltax
-                if np.abs(rat) < tol1:
-                    u = x + tol1 if rat >= 0 else x - tol1
-                else:
-                    u = x + rat
-                out.append((u, None))
-        return [base + a_ * xi for a_, _ in out[:width]]
+        where = site.f_code.co_name
+        abscissae = []
+        if where == "bracket":
+            bl = site.f_locals
+            info = site.f_back
+            brent = info.f_locals.get("self") if info is not None and info.f_code.co_name == "get_bracket_info" else None
+            if "fa" not in bl or "fc" in bl or "w" in bl:
+                return None
+            if "fb" not in bl:
+                # fb = func(xb) of a (0, 1) start
+                if not (alpha == 1.0 and bl["xa"] == 0.0 and bl["xb"] == 1.0):
+                    return None
+                gold, xa, xb = bl["_gold"], bl["xa"], bl["xb"]
+                # f(0) < f(1): SciPy swaps (xa, xb) and goes on to -1.618034 -- that case first; else no swap, 2.618034
+                cB, cA = xa + gold * (xa - xb), xb + gold * (xb - xa)
+                uB = uA = (None, None, None)
+                if brent is not None and width > 1:
+                    uB, uA = _brentAhead(brent, xb, xa, cB), _brentAhead(brent, xa, xb, cA)
+                abscissae = [cB, uB[0], uB[1], cA, uA[0], uB[2], uA[1], uA[2]]
+            else:
+                # fc = func(xc): if it closes the bracket, Brent's first two steps on (xa, xb, xc)
+                if brent is None or alpha != bl["xc"]:
+                    return None
+                abscissae = list(_brentAhead(brent, bl["xa"], bl["xb"], bl["xc"]))
+        elif where == "optimize":
+            ol = site.f_locals
+            brent = ol.get("self")
+            if brent is None or ol.get("iter") != 0 or not (ol["x"] == ol["w"] == ol["v"]):
+                return None
+            u1, ugt, ule = _brentAhead(brent, ol["xa"], ol["xb"], ol["xc"])
+            if u1 is None or u1 != alpha:
+                return None
+            abscissae = [ugt, ule]                     # Brent's first step: its second, for either outcome
+        else:
+            return None
+        return [base + a_ * xi for a_ in abscissae if a_ is not None][:width]
     except (KeyError, AttributeError, ValueError, TypeError):
         return None
 

@@ -405,30 +405,32 @@ def test_powell_lookahead_serves_scipy_the_same_values_in_fewer_device_rounds(mo
 
 
 def test_powell_lookahead_abscissae_are_scipys():
-    """The look-ahead recomputes SciPy's abscissae from SciPy's frames; pin them for the SciPy in this image."""
+    """The look-ahead recomputes SciPy's abscissae from SciPy's frames; pin them for the SciPy in this image: at f(1) of
+    a line search the third bracket point is always among the guesses, and most of the evaluations that follow a
+    recognised call site are too."""
     from scipy.optimize import minimize
     from approxposterior_amd import gpUtils
     asked, guessed = [], []
 
-    def f(p):
-        asked.append(np.array(p))
-        got = gpUtils._powellAhead(4)
-        # (called from the objective itself: one frame less than from inside _nll -- shift by wrapping)
-        return float(np.sum((p - np.array([0.3, -1.2])) ** 2) + 0.1 * np.sum(p ** 4))
-
     def g(p):        # same depth as _nll -> _powellAhead: objective -> helper
         asked.append(np.array(p))
-        pts = gpUtils._powellAhead(4)
+        pts = gpUtils._powellAhead(8)
         if pts is not None:
             guessed.append((len(asked) - 1, [np.array(q) for q in pts]))
-        return float(np.sum((p - np.array([0.3, -1.2])) ** 2) + 0.1 * np.sum(p ** 4))
-    minimize(g, np.array([2.0, 1.5]), method="powell", options={"maxiter": 3})
-    assert guessed, "no line search was recognised: SciPy's Powell has changed shape -- see gpUtils._powellAhead"
-    hits = 0
-    for at, pts in guessed:
-        assert len(pts) == 4
-        nxt = asked[at + 1]
-        assert any(np.array_equal(nxt, q) for q in pts[:2])          # the third bracket point is one of the first two
-        if at + 2 < len(asked) and any(np.array_equal(asked[at + 2], q) for q in pts[2:]):
-            hits += 1                                                 # Brent's first step, when the bracket closed at once
-    assert hits >= len(guessed) // 3
+        return float(np.sum((p - np.array([0.3, -1.2, 0.8])) ** 2) + 0.1 * np.sum(p ** 4) + np.sin(3.0 * p[0]))
+    minimize(g, np.array([2.0, 1.5, -0.7]), method="powell", options={"maxiter": 6})
+    starts = [(at, pts) for at, pts in guessed if len(pts) >= 4]         # f(1) of a line search: all eight cases
+    assert len(starts) >= 6, "no line search was recognised: SciPy's Powell has changed shape -- see gpUtils._powellAhead"
+    third = two_more = 0
+    for at, pts in starts:
+        assert len(pts) == 8
+        assert any(np.array_equal(asked[at + 1], q) for q in (pts[0], pts[3]))        # -1.618034 or 2.618034
+        third += 1
+        nxt = asked[at + 2:at + 4]
+        if len(nxt) == 2 and all(any(np.array_equal(a, q) for q in pts) for a in nxt):
+            two_more += 1                                                  # the bracket closed: Brent's first two steps
+    assert two_more >= len(starts) // 2, (two_more, len(starts))
+    later = [(at, pts) for at, pts in guessed if len(pts) < 4]             # third bracket point / Brent's first step
+    for at, pts in later:
+        if at + 1 < len(asked) and len(pts) == 2:                          # Brent's first step: the second is one of the two
+            assert any(np.array_equal(asked[at + 1], q) for q in pts)
