@@ -138,8 +138,10 @@ __device__ __forceinline__ void apgp_exp_tab_load(double* tab_lds) {
     if (threadIdx.x < APGP_EXP_TAB_N) tab_lds[threadIdx.x] = apgp_exp_tab_init[threadIdx.x];
 }
 
+// x <= 0 (every caller passes minus a sum of squares, or NaN, which fmax turns into -700 as before): the upper clamp the
+// generic form needs is dead and dropped -- one fp64 operation of ~15 per value on the pipe the sweep's MFMAs share.
 __device__ __forceinline__ double apgp_exp(double x, const double* tab_lds) {
-    x = fmin(fmax(x, -700.0), 700.0);
+    x = fmax(x, -700.0);
     const double magic = 6755399441055744.0;                       // 1.5 * 2^52
     const double t = fma(x, 0x1.71547652b82fep+5 /* 32/ln2 */, magic);
     const double kf = t - magic;                                   // round(x * 32/ln2)
@@ -166,7 +168,7 @@ __device__ __forceinline__ void apgp_exp4(const double (&xin)[4], double (&out)[
     double x[4], t[4], kf[4], r[4], p[4], T[4], res[4];
     int j[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = fmin(fmax(xin[i], -700.0), 700.0);
+    for (int i = 0; i < 4; ++i) x[i] = fmax(xin[i], -700.0);         // (x <= 0: see apgp_exp)
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i] = fma(x[i], 0x1.71547652b82fep+5, magic);
 #pragma unroll

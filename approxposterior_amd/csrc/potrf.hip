@@ -174,11 +174,7 @@ extern "C" int apgp_debug_read_fstamps(unsigned long long* out) {
 // never the GPU hang
 // PANEL_SPIN_WHILE_T: an expired guard also raises the LDS word `trip_` (if any): the persistent kernel turns that into its
 // global abort word, so that the host re-runs the evaluation instead of trusting values computed from stale operands
-#ifdef PP_EXP_FASTPOLL   // (timing experiment: LDS spins without the sleep)
-#define PANEL_SPIN_WHILE_T(cond, trip_) do { unsigned guard_ = 0; while (cond) { if (++guard_ > (1u << 20)) { if (trip_) lds_store_volatile((trip_), 1); break; } } } while (0)
-#else
 #define PANEL_SPIN_WHILE_T(cond, trip_) do { unsigned guard_ = 0; while (cond) { __builtin_amdgcn_s_sleep(1); if (++guard_ > (1u << 18)) { if (trip_) lds_store_volatile((trip_), 1); break; } } } while (0)
-#endif
 #define PANEL_SPIN_WHILE(cond) PANEL_SPIN_WHILE_T(cond, (int*)nullptr)
 // (a C++ volatile store through a generic pointer becomes a FLAT system-scope store plus
 // s_waitcnt vmcnt(0) -- hundreds of cycles per pivot on the critical path; this is the LDS store)

@@ -53,15 +53,8 @@ typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef PP_AUTO_NB
 #define PP_AUTO_NB 50
 #endif
-#ifndef PP_SG16
-#define PP_SG16 1                                 // round 5: 16-column super-groups + catch-up on the matrix cores (potrf_persist_sg.h); 0: round 4's step
-#endif
-#if PP_SG16 && defined(PP_EXP_PAIR_LIGHT)
-#define PP_W_RECV 4                               // wavefront of the receiver role (see pp_row_role)
-#else
-#define PP_W_RECV 3
-#endif
 //                              // block columns up to which the persistent launch is the default
+#define PP_W_RECV 3                               // wavefront of the receiver role (see pp_row_role)
 #define PP_THREADS 512
 #define PP_CHUNK (64 * 18)                        // a 16-column chunk of a 64-row tile, rows padded to 18 (apgp_gemm64_tile's)
 // LDS map of a row workgroup (doubles)
@@ -182,13 +175,7 @@ __device__ __forceinline__ bool pp_give_up(PpSpin& sp, pp_u64* ctl, const pp_u64
 // exit and marks the CALL aborted, PP_ROLE_EXIT; before round 5 the wait just fell through and the wavefront went on with
 // stale operands while the launch could still finish "successfully")
 __device__ __forceinline__ void pp_lds_wait_ge(const int* p, int need, int* trip) {
-#ifdef PP_EXP_SLOWPOLL   // (timing experiment: the matrix wavefronts poll eight times less often)
-    { unsigned guard_ = 0; while (lds_load_volatile(p) < need) { __builtin_amdgcn_s_sleep(8); if (++guard_ > (1u << 18)) { lds_store_volatile(trip, 1); break; } } }
-#elif defined(PP_EXP_FASTWAIT)   // (timing experiment: no sleep between the looks of the persistent kernel's own LDS waits)
-    { unsigned guard_ = 0; while (lds_load_volatile(p) < need) { if (++guard_ > (1u << 20)) { lds_store_volatile(trip, 1); break; } } }
-#else
     PANEL_SPIN_WHILE_T(lds_load_volatile(p) < need, trip);
-#endif
     PANEL_FENCE();
 }
 
@@ -235,34 +222,13 @@ __device__ __forceinline__ void pp_solve_wave(const int lane, double (&x)[PB], c
 template <bool TWO>
 __device__ __forceinline__ void pp_kstep(const double* Ach, const double* Bch, const int ks, const int lane, const int wr, const int wc,
                                          const int (&bcol)[4], double (&acc)[2][2][4], double (&acc2)[2][2][4]) {
-#ifdef PP_EXP_NOMFMA     // (timing experiment: no products)
-    return;
-#endif
     double af[2], bf[2][4];
-#ifdef PP_EXP_NOLDS      // (timing experiment: the products without their LDS operand reads)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { af[i] = (double)(lane + i + ks); asm volatile("" : "+v"(af[i])); }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { bf[j][r] = (double)(lane + r + j); asm volatile("" : "+v"(bf[j][r])); }
-#else
 #pragma unroll
     for (int i = 0; i < 2; ++i) af[i] = Ach[(wr + 16 * i + (lane & 15)) * 18 + ks * 4 + (lane >> 4)];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int j = 0; j < 2; ++j) bf[j][r] = Bch[(wc + 16 * j + bcol[r]) * 18 + ks * 4 + (lane >> 4)];
-#endif
-#ifdef PP_EXP_LDSONLY    // (timing experiment: the operand reads without the products)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) asm volatile("" : : "v"(af[i]));
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" : : "v"(bf[j][r]));
-    return;
-#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -352,150 +318,6 @@ __device__ __forceinline__ PpStep pp_step(double* lds, int s_in, long long n) {
 }
 
 
-#if !PP_SG16
-// ---------------- wavefront 0: the diagonal block (s, s); at step r also z_r ----------------
-__device__ PP_NOINLINE void pp_role_factor(unsigned lds_off, PpKarg karg) {
-    pp_args_ptr q = pp_args(karg);
-    double* lds = pp_lds_base(lds_off);
-    const int lane = threadIdx.x & 63;
-    const long long n = q->a.n;
-    __builtin_amdgcn_s_setprio(3);         // (shares its SIMD with a matrix wavefront: the critical path goes first)
-    PP_STEP_LOOP_BEGIN(lds)
-    const PpStep p = pp_step(lds, s_in, n);
-    if (lane == 0) {
-        int* nx = (int*)(lds + PP_INTS) + 8 * ((s_in + 1) & 1);   // the next step's counters (nobody uses them before the barrier)
-        nx[0] = 0; nx[1] = 0; nx[2] = 0; nx[3] = 0; nx[4] = 0; nx[5] = 0; nx[6] = 0; nx[7] = 0;
-    }
-    double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
-    double* invd = lds + PP_INVD;
-    double* zblk = lds + PP_ZBLK;
-    const double* zrow = lds + PP_ZROW;
-    const int bs = p.bs, s = p.s, r = p.r;
-    PP_STAMP(s, 0);
-    PP_STAMPP(s, 20);
-    double rowv[PB];                                           // row `lane` of the diagonal block
-#pragma unroll
-    for (int k = 0; k < PB; k += 2) {
-        const f64x2 v = *(const f64x2*)(&Ls[lane][k]);
-        rowv[k] = (lane < bs && k <= lane) ? v.x : ((k == lane) ? 1.0 : 0.0);
-        rowv[k + 1] = (lane < bs && k + 1 <= lane) ? v.y : ((k + 1 == lane) ? 1.0 : 0.0);
-    }
-    PotrfArgs pa;
-    pa.A = q->a.A; pa.rhs = nullptr;                           // (the forward solve is a separate pass below)
-    pa.n = n; pa.lda = q->a.lda; pa.j0 = p.j0; pa.shift = 0.0; pa.info = q->a.info; pa.out5 = nullptr; pa.mail = nullptr; pa.seq = 0;
-    pa.dscr = q->a.dscr; pa.batch_dscr = 0; pa.zoff = q->a.zoff; pa.batch_A = 0; pa.batch_rhs = 0; pa.abort_word = nullptr; pa.abort_id = 0; pa.no_panel = 0; pa.info_j0 = q->a.info_j0;
-    panel_factor_wave<false>(pa, p.j0, bs, lane, rowv, 0.0, Ls, invd, zblk, p.cnt + 0, p.cnt + 1, r == s ? 0 : PB, 1, p.abl);
-    PP_STAMP(s, 1);
-    if (r == s && q->a.rhs) {
-        // z_s = L_ss^-1 (rhs block s): the operations of the pass that rides along in panel_factor_wave, in its
-        // order, on the finished factor (Ls, invd) -- the 4 x 4 blocks of Ls ARE its d[][] bit for bit
-        pp_lds_wait_ge(p.cnt + 4, 1, p.abl);
-        double ri = lane < bs ? zrow[lane] : 0.0;
-        static_for<PB / CB>([&](auto cc_) {
-            constexpr int c0 = CB * decltype(cc_)::value;
-            double d[CB][CB], zb[CB], inv[CB], x[CB];
-#pragma unroll
-            for (int rr = 0; rr < CB; ++rr) {
-#pragma unroll
-                for (int qq = 0; qq < rr; ++qq) d[rr][qq] = Ls[c0 + rr][c0 + qq];
-                zb[rr] = bcast_lane(ri, c0 + rr);
-                inv[rr] = invd[c0 + rr];
-                x[rr] = Ls[lane][c0 + rr];
-            }
-#pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                double zacc = zb[k];
-#pragma unroll
-                for (int m = 0; m < k; ++m) zacc = fma(-zb[m], d[k][m], zacc);
-                zb[k] = zacc * inv[k];
-            }
-            double racc = ri;
-#pragma unroll
-            for (int k = 0; k < CB; ++k) racc = fma(-x[k], zb[k], racc);
-            ri = lane >= c0 + CB ? racc : ri;
-#pragma unroll
-            for (int k = 0; k < CB; ++k) ri = lane == c0 + k ? zb[k] : ri;
-        });
-        if (lane < bs) (q->a.dscr + q->a.zoff)[p.j0 + lane] = ri;
-        if (s + 1 < q->nb) {
-            const unsigned tag = (unsigned)q->call_id;
-            const pp_u32x4 g = {(unsigned)__double2loint(ri), tag, (unsigned)__double2hiint(ri), tag};
-            const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)q->zstrm, 0, (int)(PP_ZSTRM_WORDS * 8), 0x00020000);
-            PP_STORE16(g, rs_z, (unsigned)(lane * 16), (unsigned)(s * 1024), 16);
-        }
-    }
-    PP_STEP_LOOP_END()
-}
-
-// ---------------- wavefront 1: the 64 rows of tile (r, s) ----------------
-__device__ PP_NOINLINE void pp_role_solve(unsigned lds_off, PpKarg karg) {
-    pp_args_ptr q = pp_args(karg);
-    double* lds = pp_lds_base(lds_off);
-    const int lane = threadIdx.x & 63;
-    const long long n = q->a.n, lda = q->a.lda;
-    __builtin_amdgcn_s_setprio(3);
-    PP_STEP_LOOP_BEGIN(lds)
-    const PpStep p = pp_step(lds, s_in, n);
-    if (p.s >= 1) {
-        // L(r, s-1) went to memory at the end of the previous step (below): drained by now -- publish it
-        pp_drain();
-        if (lane == 0) pp_st(q->ctl + PP_CTL_ROWDONE + p.r, (q->call_id << 8) | (pp_u64)p.s);
-        PP_STAMP(p.s, 8);
-    }
-    if (p.r > p.s) {
-    const double (*Ls)[PB + 2] = (const double (*)[PB + 2])(lds + PP_LS);
-    const long long row = (long long)p.r * PB + lane;
-    const bool has_row = row < n;
-    double rowv[PB];                                           // row `lane` of tile (r, s)
-    if (p.s == 0) {
-        const double* src = q->a.A + (has_row ? row : 0) * lda;
-#pragma unroll
-        for (int k = 0; k < PB; ++k) rowv[k] = has_row ? src[k] : 0.0;
-    } else {
-        const double (*St)[PB + 2] = (const double (*)[PB + 2])p.As_cur;
-#pragma unroll
-        for (int k = 0; k < PB; k += 2) {
-            const f64x2 v = *(const f64x2*)(&St[lane][k]);
-            rowv[k] = has_row ? v.x : 0.0;
-            rowv[k + 1] = has_row ? v.y : 0.0;
-        }
-        PANEL_FENCE();
-    }
-    pp_solve_wave(lane, rowv, Ls, lds + PP_INVD, p.cnt + 0, p.As_cur, p.cnt + 2, p.abl);
-    PP_STAMP(p.s, 2);
-    PP_STAMPP(p.s, 21);
-    {
-        // L(r, s) from LDS (this wavefront's published groups) to memory, coalesced write-through stores: this wavefront
-        // is idle until the step ends, and the update workgroups need the rows as early as possible (they have one step
-        // to apply them to column s + 2).  The flag follows at the head of the next step, once the stores have drained.
-        // (The receiving wavefront did this until the hand-over got shorter: it starts ~2 us later, when the last group has
-        // arrived, and was the last one at the step's barrier.)
-        const int r = p.r, s = p.s;
-        const __amdgpu_buffer_rsrc_t rs_A = __builtin_amdgcn_make_buffer_rsrc((void*)q->a.A, 0, (int)(q->a.lda * n * 8), 0x00020000);
-        // (eight LDS reads in flight, then their eight stores; rows past n fall outside the buffer descriptor and are
-        // dropped by its range check -- with a branch per row every store waited for its own LDS read: 2.5 us)
-        const unsigned row_b = (unsigned)(lda * 8);
-        const unsigned off0 = (unsigned)((((long long)r * PB + (lane >> 5)) * lda + (long long)s * PB + 2 * (lane & 31)) * 8);
-        const double* src0 = p.As_cur + ((lane & 31) >> 3) * PP_CHUNK + (lane >> 5) * 18 + (2 * (lane & 31) & 15);
-#pragma unroll
-        for (int b8 = 0; b8 < 4; ++b8) {
-            f64x2 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = *(const f64x2*)(src0 + (b8 * 8 + k) * 2 * 18);
-            PANEL_FENCE();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const pp_u32x4 w4 = __builtin_bit_cast(pp_u32x4, v[k]);
-                PP_STORE16(w4, rs_A, off0 + (unsigned)(b8 * 8 + k) * 2u * row_b, 0, 16);
-            }
-            PANEL_FENCE();
-        }
-    }
-    }
-    PP_STEP_LOOP_END()
-}
-
-#endif   // !PP_SG16
 
 // ---------------- wavefront 3: receiver -- z of the previous block column, then the groups of L(s+1, s) ----------------
 // rhs_r: the running right-hand side of the forward solve for this lane's matrix row
@@ -621,106 +443,6 @@ __device__ PP_NOINLINE void pp_role_recv(unsigned lds_off, PpKarg karg, double r
     PP_STEP_LOOP_END()
 }
 
-#if !PP_SG16
-// ---------------- wavefronts 4-7: the next tile and the next diagonal block ----------------
-__device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
-    pp_args_ptr q = pp_args(karg);
-    double* lds = pp_lds_base(lds_off);
-    const int t = threadIdx.x, lane = t & 63;
-    const long long n = q->a.n;
-    PP_STEP_LOOP_BEGIN(lds)
-    const PpStep p = pp_step(lds, s_in, n);
-    const int s = p.s, r = p.r;
-    double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
-    const double* Bs = lds + PP_BS;
-    int* xprog = p.cnt + 2; int* bprog = p.cnt + 3;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int mw = wv - 4;
-    const int wr = (mw >> 1) * 32, wc = (mw & 1) * 32;         // this wavefront's 32 x 32 quadrant of both products
-    bool dead = false;
-    if (r > s) {
-    int bcol[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) bcol[rr] = ((lane & 15) - 4 * rr) & 15;
-    double v[2][2][4], v2[2][2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { v[i][j][rr] = 0.0; v2[i][j][rr] = 0.0; }
-    const bool producer = p.producer;
-    // No memory access in these wavefronts: the tiles' values in memory are fetched by wavefront 2 once its helper duty is
-    // over (coalesced, into the LDS places of the hand-over) and the products are subtracted from them there.  (With the 64
-    // requests here, in the accumulator layout -- sixteen cache lines per load -- the k-steps stood still for 2.5-3 us and
-    // were three groups behind when the last group arrived.)  A rolled loop: the sixteen k-steps differ in LDS addresses only.
-#ifdef PP_STAMPS
-#define PP_KSTAMPS() do { if (mw == 0) { if (g == 0) PP_STAMP(s, 11); if (g == 5) PP_STAMP(s, 9); if (g == 12) PP_STAMP(s, 12); if (g == 14) PP_STAMP(s, 14); if (g == 15) PP_STAMP(s, 4); } } while (0)
-#else
-#define PP_KSTAMPS() do { } while (0)
-#endif
-    if (producer) {
-#pragma unroll 1
-        for (int g = 0; g < PB / CB; ++g) {
-            pp_lds_wait_ge(xprog, g + 1, p.abl);
-            const double* Ach = p.As_cur + (g >> 2) * PP_CHUNK;
-            pp_kstep<false>(Ach, Ach, g & 3, lane, wr, wc, bcol, v, v2);
-            PP_KSTAMPS();
-        }
-    } else {
-#pragma unroll 1
-        for (int g = 0; g < PB / CB; ++g) {
-            pp_lds_wait_ge(xprog, g + 1, p.abl);
-            pp_lds_wait_ge(bprog, g + 1, p.abl);
-            pp_kstep<true>(p.As_cur + (g >> 2) * PP_CHUNK, Bs + (g >> 2) * PP_CHUNK, g & 3, lane, wr, wc, bcol, v, v2);
-            PP_KSTAMPS();
-        }
-    }
-    // hand-over: the staged values minus the products, in place -- the next tile in the free parity of As ([64][66]) for
-    // wavefront 1, the next diagonal block in Ls (staged there by wavefront 2).  (Reading the staged values before the last
-    // k-step, while the wavefront waits for the last group anyway, changed nothing: the hand-over is bound by its 32
-    // scattered ds_write_b64 per wavefront -- 3-4-way bank conflicts of the accumulator layout at a row stride of 66
-    // doubles, which is the conflict-free stride for the row-per-lane accesses of the panel code.)
-    pp_lds_wait_ge(p.cnt + 5, 1, p.abl);
-    if (lds_load_volatile(p.cnt + 5) != 1) dead = true;
-    if (mw == 0) PP_STAMP(s, 5);
-    double (*St)[PB + 2] = (double (*)[PB + 2])p.As_prev;
-    {
-        // all the reads first, then the differences, then the stores (St and Ls may alias as far as the compiler knows: written
-        // element by element every read waited for the store before it -- 64 LDS round trips, 1.5 us)
-        double sv[2][2][4], lv[2][2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
-                    lv[i][j][rr] = Ls[lr][lc];
-                    sv[i][j][rr] = St[lr][lc];       // (the producer's own tile is not in St: read, unused)
-                }
-        PANEL_FENCE();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int lr = wr + 16 * i + apgp_mma16_row(lane), lc = wc + 16 * j + apgp_mma16_col(lane, rr);
-                    if (producer) Ls[lr][lc] = lv[i][j][rr] - v[i][j][rr];
-                    else {
-                        St[lr][lc] = sv[i][j][rr] - v[i][j][rr];
-                        Ls[lr][lc] = lv[i][j][rr] - v2[i][j][rr];
-                    }
-                }
-    }
-    if (mw == 0) PP_STAMP(s, 6);
-    if (dead) lds_store_volatile(p.abl, 1);
-    }
-    PP_STEP_LOOP_END()
-}
-
-#endif   // !PP_SG16
 
 // ---------------- wavefront 2: the factorisation's helper for the first eight column groups; then -- idle otherwise -- it
 // watches the flags of the two tiles the matrix wavefronts subtract their products from (tile (r, s+1) and the next
@@ -830,31 +552,7 @@ __device__ PP_NOINLINE void pp_stage_tiles(unsigned lds_off, PpKarg karg, int s_
     __syncthreads();                                           // the step's barrier (see pp_role_helper)
 }
 
-#if !PP_SG16
-__device__ PP_NOINLINE void pp_role_helper(unsigned lds_off, PpKarg karg) {
-    pp_args_ptr q = pp_args(karg);
-    double* lds = pp_lds_base(lds_off);
-    const int lane = threadIdx.x & 63;
-    const long long n = q->a.n;
-    double (*Ls)[PB + 2] = (double (*)[PB + 2])(lds + PP_LS);
-    PP_STEP_LOOP_BEGIN(lds)
-    const long long j0 = (long long)s_in * PB;
-    int* cnt = (int*)(lds + PP_INTS) + 8 * (s_in & 1);
-    __builtin_amdgcn_s_setprio(3);         // (the factorisation waits for these columns at group 8)
-    panel_helper_wave((int)((n - j0) < PB ? (n - j0) : PB), lane, Ls, cnt + 0, cnt + 1, (int*)(lds + PP_INTS) + 17 + (s_in & 1));
-    __builtin_amdgcn_s_setprio(0);
-    PP_STAMP(s_in, 16);
-    // (the step's barrier is the last thing pp_stage_tiles does -- it is called exactly when the step has one -- so that the
-    // reloads of the registers the call saved, 115 of them, come after the barrier instead of before it: this wavefront
-    // was the last one to arrive)
-    if (r_ > s_in) pp_stage_tiles(lds_off, karg, s_in);
-    }
-    PP_ROLE_EXIT(lds, q);
-}
-
-#else
 #include "potrf_persist_sg.h"
-#endif
 
 // karg_off: byte offset of `q` in the kernel-argument segment (the batched kernel passes one record per matrix)
 __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, const unsigned lds_off, const unsigned karg_off = 0) {
@@ -900,23 +598,11 @@ __device__ __forceinline__ void pp_row_role(const PersistArgs& q, double* lds, c
     // factorisation loses ~500 cycles whenever a k-step's 32 MFMAs meet one of its column groups.  Other pairings were
     // measured (factorisation + receiver, solver + helper, matrix wavefronts with each other; receiver and helper swapped;
     // ...): the factorisation gets faster, the helper or the last k-step slower, the step stays within 2 %.
-#if PP_SG16 && defined(PP_EXP_PAIR_LIGHT)
-    // (measured, round 5: the two row-per-lane wavefronts each paired with a wavefront that hardly touches the double-precision
-    // pipe -- receiver, stager -- and the four matrix wavefronts in pairs on the other two SIMDs: wavefronts 0 F | 1 S | 2 M0 |
-    // 3 M2 | 4 receiver | 5 stager | 6 M1 | 7 M3.  The factorisation finishes 1 us earlier, the k-steps 3 us later: 0.378
-    // against 0.337 ms at n = 1152 -- MFMA streams that share a SIMD halve each other)
-    if (w == 0) pp_role_factor(lo, karg);
-    else if (w == 1) pp_role_solve(lo, karg);
-    else if (w == PP_W_RECV) pp_role_recv(lo, karg, rhs_r);
-    else if (w == 5) pp_role_helper(lo, karg);
-    else pp_role_matrix(lo, karg);
-#else
     if (w == 0) pp_role_factor(lo, karg);
     else if (w == 1) pp_role_solve(lo, karg);
     else if (w == 3) pp_role_recv(lo, karg, rhs_r);
     else if (w >= 4) pp_role_matrix(lo, karg);
     else pp_role_helper(lo, karg);
-#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -452,13 +452,9 @@ __device__ PP_NOINLINE void pp_role_matrix(unsigned lds_off, PpKarg karg) {
     const double* Bs = lds + PP_BS;
     double* xfer = lds + PP_XFER;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-#ifdef PP_EXP_PAIR_LIGHT
-    const int mw = ((wv & 1) << 1) | (wv >> 2);               // wavefronts 2, 6, 3, 7 -> 0, 1, 2, 3 (pp_row_role: pairs on two SIMDs)
-#else
     // wavefront 4 shares its SIMD with the factorising wavefront: it takes the quadrant ABOVE the diagonal (wr = 0, wc = 32),
     // whose share of the next diagonal block is never read and is skipped -- half the MFMAs of the others per k-step
     const int mw = (wv - 4) ^ 1;
-#endif
     const int wr = (mw >> 1) * 32, wc = (mw & 1) * 32;         // this wavefront's 32 x 32 quadrant of both products
     bool dead = false;
     {
