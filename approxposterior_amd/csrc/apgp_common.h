@@ -18,6 +18,12 @@ void apgp_set_error(const char* fmt, ...);
         }                                                           \
     } while (0)
 
+// Sizes the entry points accept: beyond them nothing fits a device anyway, and the size arithmetic (n * n, tile counts,
+// grid dimensions) stays inside int64 / unsigned -- found by the sanitizer build (tools/run_asan.sh: apgp_grad_work_len(2^40)
+// overflowed).  The *_len functions return -1 above the limits.
+#define APGP_MAX_N (1ll << 24)         /* training points */
+#define APGP_MAX_M (1ll << 40)         /* candidates per call */
+
 #define APGP_CHECK_LAUNCH()                                                       \
     do {                                                                          \
         hipError_t e__ = hipGetLastError();                                       \
@@ -138,10 +144,12 @@ __device__ __forceinline__ void apgp_exp_tab_load(double* tab_lds) {
     if (threadIdx.x < APGP_EXP_TAB_N) tab_lds[threadIdx.x] = apgp_exp_tab_init[threadIdx.x];
 }
 
-// x <= 0 (every caller passes minus a sum of squares, or NaN, which fmax turns into -700 as before): the upper clamp the
-// generic form needs is dead and dropped -- one fp64 operation of ~15 per value on the pipe the sweep's MFMAs share.
+// (Every caller passes x <= 0, so the upper clamp is dead arithmetic -- and it stays: round 6 measured the sweep without it,
+// same registers, no spill, 313 against 252 ms per C3 call on one box (profiles/r06i_exp_variants_ab.txt): hipcc schedules
+// the four interleaved chains of apgp_exp4 differently once the v_min is gone and the feeders' fp64 operations land
+// between the matrix wavefronts' MFMAs.  A 64-entry table with a degree-5 polynomial: 251 ms, i.e. nothing.)
 __device__ __forceinline__ double apgp_exp(double x, const double* tab_lds) {
-    x = fmax(x, -700.0);
+    x = fmin(fmax(x, -700.0), 700.0);
     const double magic = 6755399441055744.0;                       // 1.5 * 2^52
     const double t = fma(x, 0x1.71547652b82fep+5 /* 32/ln2 */, magic);
     const double kf = t - magic;                                   // round(x * 32/ln2)
@@ -168,7 +176,7 @@ __device__ __forceinline__ void apgp_exp4(const double (&xin)[4], double (&out)[
     double x[4], t[4], kf[4], r[4], p[4], T[4], res[4];
     int j[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = fmax(xin[i], -700.0);         // (x <= 0: see apgp_exp)
+    for (int i = 0; i < 4; ++i) x[i] = fmin(fmax(xin[i], -700.0), 700.0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i] = fma(x[i], 0x1.71547652b82fep+5, magic);
 #pragma unroll

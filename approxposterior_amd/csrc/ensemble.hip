@@ -479,7 +479,7 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
                                     uint64_t seed, double* coords, double* logp, double* chain,
                                     double* logp_chain, int64_t* naccept, void* stream) {
     APGP_CHECK_ARG(xs && kern && lo && hi && coords && logp && naccept, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && iterations >= 0 && nensembles >= 1, "n, iterations, nensembles");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && iterations >= 0 && nensembles >= 1, "n, iterations, nensembles");
     KernConst kc;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
     APGP_CHECK_ARG(nwalkers >= 2 && nwalkers % 2 == 0 && nwalkers <= ENS_MAXW, "nwalkers must be even and <= 256");

@@ -159,13 +159,14 @@ __global__ __launch_bounds__(256) void kinv_solve_step_kernel(KinvSolveArgs a) {
 }
 
 extern "C" int64_t apgp_kinv_solve_work_len(int64_t n) {
+    if (n > APGP_MAX_N) return -1;
     const int64_t np = apgp_round_up(n < 1 ? 1 : n, 64);
     return np * np;
 }
 
 extern "C" int apgp_kinv_solve(const double* L, int64_t n, int64_t ldl, double* xwork, double* kinv, void* stream) {
     APGP_CHECK_ARG(L && xwork && kinv, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && ldl >= n, "n >= 1 and ldl >= n required");
     hipStream_t s = (hipStream_t)stream;
     KinvSolveArgs a;
     a.L = L; a.X = xwork; a.Y = kinv; a.n = n; a.ldl = ldl; a.np = apgp_round_up(n, 64);
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(1024) void grad_final_kernel(const double* partial,
 }
 
 extern "C" int64_t apgp_grad_work_len(int64_t n) {
+    if (n < 0 || n > APGP_MAX_N) return -1;
     int64_t nb = (n + 63) / 64;
     return n * n + nb * nb * (2 + APGP_MAX_DIM);
 }
@@ -315,7 +317,7 @@ extern "C" int apgp_grad_loglik(const double* X, const double* alpha, const doub
                                 int64_t n, const apgp_kernel_t* kern, double* work, double* out,
                                 void* stream) {
     APGP_CHECK_ARG(X && alpha && kern && work && out, "null pointer");
-    APGP_CHECK_ARG(n >= 1, "n >= 1 required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N, "n >= 1 required");
     const long long np = apgp_round_up(n, 64);
     // winv == NULL: `work` already holds K^-1 (its lower tiles), formed by apgp_kinv_solve (the solve route)
     APGP_CHECK_ARG(!winv || ldw >= np, "winv must be the padded dense inverse left in apgp_trtri_pack's work buffer");

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void gram_batch_kernel(GramBatchArgs b) { gram
 int apgp_gram_with_rhs(const double* X, int64_t n, const apgp_kernel_t* kern, double* K, int64_t ldk,
                        const double* y, double shift, double* z, int32_t* info_dev, void* stream) {
     APGP_CHECK_ARG(X && K && kern, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && ldk >= n, "n >= 1 and ldk >= n required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && ldk >= n, "n >= 1 and ldk >= n required");
     GramArgs a;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &a.kc) == 0, "kernel parameters");
     a.X = X; a.K = K; a.n = n; a.ldk = ldk;
@@ -118,7 +118,7 @@ int apgp_gram_with_rhs(const double* X, int64_t n, const apgp_kernel_t* kern, do
 int apgp_gram_with_rhs_batch(const double* X, int64_t n, int64_t batch, const apgp_kernel_t* kerns, double* K,
                              const double* y, const double* shifts, double* z, int32_t* info_dev, void* stream) {
     APGP_CHECK_ARG(X && K && kerns, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && batch >= 1 && batch <= APGP_GRAM_BATCH_MAX, "n >= 1 and 1 <= batch <= 6 required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && batch >= 1 && batch <= APGP_GRAM_BATCH_MAX, "n >= 1 and 1 <= batch <= 6 required");
     GramBatchArgs g;
     for (int64_t b = 0; b < batch; ++b) {
         GramArgs& a = g.m[b];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void kernel_cross_kernel(CrossArgs a) {
 extern "C" int apgp_kernel_cross(const double* X1, int64_t m, const double* X2, int64_t n,
                                  const apgp_kernel_t* kern, double* C, int64_t ldc, void* stream) {
     APGP_CHECK_ARG(X1 && X2 && C && kern, "null pointer");
-    APGP_CHECK_ARG(m >= 1 && n >= 1 && ldc >= n, "m >= 1, n >= 1 and ldc >= n required");
+    APGP_CHECK_ARG(m >= 1 && m <= APGP_MAX_M && n >= 1 && n <= APGP_MAX_N && ldc >= n, "m >= 1, n >= 1 and ldc >= n required");
     CrossArgs a;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &a.kc) == 0, "kernel parameters");
     a.X1 = X1; a.X2 = X2; a.C = C; a.m = m; a.n = n; a.ldc = ldc;

@@ -23,9 +23,10 @@ __device__ __forceinline__ void trtri_static_for(F&& f) {
 // ---------------------------------------------------------------------------
 // sizes
 // ---------------------------------------------------------------------------
-extern "C" int64_t apgp_npad(int64_t n) { return apgp_round_up(n, APGP_ROW_BLOCK); }
+extern "C" int64_t apgp_npad(int64_t n) { return (n < 0 || n > APGP_MAX_N) ? -1 : apgp_round_up(n, APGP_ROW_BLOCK); }
 
 extern "C" int64_t apgp_packed_linv_len(int64_t n) {
+    if (n < 0 || n > APGP_MAX_N) return -1;
     int64_t nrb = apgp_npad(n) / APGP_ROW_BLOCK;
     // row block ib holds (ib+1)*CPB tiles of ROW_BLOCK x K_CHUNK doubles
     const int64_t cpb = APGP_ROW_BLOCK / APGP_K_CHUNK;
@@ -33,10 +34,12 @@ extern "C" int64_t apgp_packed_linv_len(int64_t n) {
 }
 
 extern "C" int64_t apgp_packed_train_len(int64_t n, int32_t ndim) {
+    if (n < 0 || n > APGP_MAX_N || ndim < 1 || ndim > APGP_MAX_DIM) return -1;
     return apgp_npad(n) * apgp_xs_stride(ndim);
 }
 
 extern "C" int64_t apgp_trtri_work_len(int64_t n) {
+    if (n < 0 || n > APGP_MAX_N) return -1;
     int64_t np = apgp_round_up(n, 64);
     return 2 * np * np;
 }
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(1024) void logdet_kernel(const double* L, long long
 
 extern "C" int apgp_logdet(const double* L, int64_t n, int64_t ldl, double* out3, void* stream) {
     APGP_CHECK_ARG(L && out3, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && ldl >= n, "n >= 1 and ldl >= n required");
     // legacy 3-value form: the kernel writes 5 doubles, callers of this entry pass >= 5
     hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, (long long)n,
                        (long long)ldl, (const double*)NULL, (const int*)NULL, out3);
@@ -92,7 +95,7 @@ extern "C" int apgp_logdet(const double* L, int64_t n, int64_t ldl, double* out3
 extern "C" int apgp_fit_summary(const double* L, int64_t n, int64_t ldl, const double* z,
                                 const int32_t* info_dev, double* out5, void* stream) {
     APGP_CHECK_ARG(L && out5, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && ldl >= n, "n >= 1 and ldl >= n required");
     hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, (long long)n,
                        (long long)ldl, z, (const int*)info_dev, out5);
     APGP_CHECK_LAUNCH();
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256) void trsv_persist_kernel(TrsvPArgs a) {
 extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
                          int trans, double* x, double* sumsq, void* stream) {
     APGP_CHECK_ARG(L && b && x, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && ldl >= n, "n >= 1 and ldl >= n required");
     hipStream_t st = (hipStream_t)stream;
     if (n >= 256 && (n + 63) / 64 <= TRSV_P_MAX_NB && !g_trsv_multi_launch.load()) {
         // ONE persistent launch (trsv_persist_kernel): flags-free granule hand-offs, call-unique tags and tickets (the
@@ -848,13 +851,13 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const double* x, long long 
 }
 
 extern "C" int64_t apgp_winv_apply_work_len(int64_t n) {
-    return n < 1 ? 0 : ((n + WA_RCH - 1) / WA_RCH) * n;
+    return n < 1 ? 0 : (n > APGP_MAX_N ? -1 : ((n + WA_RCH - 1) / WA_RCH) * n);
 }
 
 extern "C" int apgp_winv_apply(const double* winv, int64_t ldw, int64_t n, const double* b, double shift,
                                int trans, double* x, double* sumsq, double* work, void* stream) {
     APGP_CHECK_ARG(winv && b && x, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && ldw >= n, "n >= 1 and ldw >= n required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && ldw >= n, "n >= 1 and ldw >= n required");
     APGP_CHECK_ARG(!trans || work, "work (apgp_winv_apply_work_len doubles) required for the transposed product");
     APGP_CHECK_ARG(!trans || shift == 0.0, "shift applies to the forward product only");
     APGP_CHECK_ARG(x != b, "x must not alias b");
@@ -1039,13 +1042,13 @@ __global__ __launch_bounds__(256) void pred1_small_kernel(Pred1Args a, const dou
 }
 
 extern "C" int apgp_potrf_mode(int mode);      // (mode 1 = separate launches everywhere: the bit-identity tests' reference)
-extern "C" int64_t apgp_predict1_work_len(int64_t n) { return n < 1 ? 0 : 2 * apgp_npad(n) + (n + 255) / 256 + 8; }
+extern "C" int64_t apgp_predict1_work_len(int64_t n) { return n < 1 ? 0 : (n > APGP_MAX_N ? -1 : 2 * apgp_npad(n) + (n + 255) / 256 + 8); }
 
 extern "C" int apgp_predict1_host(const double* t_host, const double* xs, int64_t n, const apgp_kernel_t* kern, double mean,
                                   const double* winv, int64_t ldw, const double* L, int64_t ldl, double* work,
                                   double* out2_host, void* stream) {
     APGP_CHECK_ARG(t_host && xs && kern && work && out2_host, "null pointer");
-    APGP_CHECK_ARG(n >= 1, "n >= 1 required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N, "n >= 1 required");
     APGP_CHECK_ARG((winv && ldw >= n) || (L && ldl >= n), "the dense inverse (ldw >= n) or the factor (ldl >= n) is required");
     KernConst kc;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
@@ -1285,7 +1288,7 @@ __global__ __launch_bounds__(256) void pack_linv_kernel(const double* W, long lo
 extern "C" int apgp_trtri_pack(const double* L, int64_t n, int64_t ldl, double* work,
                                double* packed, double* winv_dense, void* stream) {
     APGP_CHECK_ARG(L && work, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && ldl >= n, "n >= 1 and ldl >= n required");
     hipStream_t s = (hipStream_t)stream;
     const long long np = apgp_round_up(n, 64);
     const int nb = (int)(np / 64);
@@ -1354,7 +1357,7 @@ __global__ __launch_bounds__(256) void pack_train_kernel(PackTrainArgs a) {
 extern "C" int apgp_pack_train(const double* X, const double* alpha, int64_t n,
                                const apgp_kernel_t* kern, double* xs, void* stream) {
     APGP_CHECK_ARG(X && alpha && xs && kern, "null pointer");
-    APGP_CHECK_ARG(n >= 1, "n >= 1 required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N, "n >= 1 required");
     PackTrainArgs a;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &a.kc) == 0, "kernel parameters");
     a.X = X; a.alpha = alpha; a.xs = xs; a.n = n; a.npad = apgp_npad(n);

@@ -1531,7 +1531,7 @@ extern "C" int apgp_potrf(double* A, int64_t n, int64_t lda, const double* y, do
                           int32_t* info_dev, void* stream) {
     APGP_CHECK_ARG(A && info_dev, "null pointer");
     APGP_CHECK_ARG((y == NULL) == (z == NULL), "y and z must be given together");
-    APGP_CHECK_ARG(n >= 1 && lda >= n, "n >= 1 and lda >= n required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && lda >= n, "n >= 1 and lda >= n required");
     return potrf_run(A, n, lda, 1, 0, y, &shift, z, info_dev, (hipStream_t)stream);
 }
 
@@ -1547,7 +1547,7 @@ extern "C" int apgp_nll_eval(const double* X, int64_t n, const apgp_kernel_t* ke
                              void* stream) {
     APGP_CHECK_ARG(X && kern && K && info_dev && out5_dev && out5_host, "null pointer");
     APGP_CHECK_ARG((y == NULL) == (z == NULL), "y and z must be given together");
-    APGP_CHECK_ARG(n >= 1, "n >= 1 required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N, "n >= 1 required");
     hipStream_t s = (hipStream_t)stream;
     int rc;
     // The record comes back through the stream's pinned mailbox: the last kernel's last lane writes it straight
@@ -1734,7 +1734,7 @@ extern "C" int apgp_nll_eval_batch(const double* X, int64_t n, int64_t batch, co
                                    int32_t* info_dev, double* out5_dev, double* out5_host, void* stream) {
     APGP_CHECK_ARG(X && kerns && y && means && K && z && info_dev && out5_dev && out5_host, "null pointer");
     APGP_CHECK_ARG(batch >= 1 && batch <= 65535, "1 <= batch <= 65535 required");
-    APGP_CHECK_ARG(n >= 1, "n >= 1 required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N, "n >= 1 required");
     int rc;
     if (n <= 2 * PB && batch <= 64 && (g_potrf_mode.load() == 0 || g_potrf_mode.load() == 3)) {
         // README sizes (round 5): ONE launch of the fused evaluation, a workgroup per matrix (nll_small_kernel /

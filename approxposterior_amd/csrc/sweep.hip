@@ -1154,6 +1154,7 @@ static int launch_sweep(const SweepArgs& a0, hipStream_t s, bool solve) {
 // parked operands | 2 x S2_SPLIT_MAX x SW_CAND x nrb row-block shares of the split last round]
 extern "C" int64_t apgp_acquire_work_len(int64_t m, int64_t n) {
     if (m < 1 || n < 1) return 0;
+    if (m > APGP_MAX_M || n > APGP_MAX_N) return -1;
     const long long ncb = (m + SW_CAND - 1) / SW_CAND;
     const long long slots = ncb < SW_GRID ? ncb : SW_GRID;
     return 2 * ncb + slots * s2_ncache(n) * SW_BCH + 2 * (long long)S2_SPLIT_MAX * SW_CAND * s2_nrb(n);
@@ -1165,7 +1166,7 @@ static int acquire_impl(bool solve, const double* T, int64_t m, int64_t idx_offs
                         double zeta, double ybest, double* mu, double* var, double* u, void* part,
                         apgp_best_t* best, void* stream) {
     APGP_CHECK_ARG(T && packed_linv && xs && kern, "null pointer");
-    APGP_CHECK_ARG(m >= 1 && n >= 1, "m >= 1 and n >= 1 required");
+    APGP_CHECK_ARG(m >= 1 && m <= APGP_MAX_M && n >= 1 && n <= APGP_MAX_N, "m >= 1 and n >= 1 required");
     APGP_CHECK_ARG(kind >= APGP_UTIL_AGP && kind <= APGP_UTIL_NONE, "unknown utility kind");
     APGP_CHECK_ARG(kind == APGP_UTIL_NONE || best, "best required for an acquisition");
     APGP_CHECK_ARG(part || (kind == APGP_UTIL_NONE && n <= S2_ROWS),
@@ -1302,7 +1303,7 @@ extern "C" int64_t apgp_packed_lsolve_len(int64_t n) { return apgp_packed_linv_l
 
 extern "C" int apgp_pack_lsolve(const double* L, int64_t n, int64_t ldl, double* packed, void* stream) {
     APGP_CHECK_ARG(L && packed, "null pointer");
-    APGP_CHECK_ARG(n >= 1 && ldl >= n, "n >= 1 and ldl >= n required");
+    APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && ldl >= n, "n >= 1 and ldl >= n required");
     const long long nrb = apgp_npad(n) / APGP_ROW_BLOCK;
     const long long ntiles = (APGP_ROW_BLOCK / APGP_K_CHUNK) * nrb * (nrb + 1) / 2;
     hipLaunchKernelGGL(pack_lsolve_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, L,
@@ -1365,7 +1366,7 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(MeanArgs a) {
 extern "C" int apgp_predict_mean(const double* T, int64_t m, const double* xs, int64_t n,
                                  const apgp_kernel_t* kern, double mean, double* mu, void* stream) {
     APGP_CHECK_ARG(T && xs && kern && mu, "null pointer");
-    APGP_CHECK_ARG(m >= 1 && n >= 1, "m >= 1 and n >= 1 required");
+    APGP_CHECK_ARG(m >= 1 && m <= APGP_MAX_M && n >= 1 && n <= APGP_MAX_N, "m >= 1 and n >= 1 required");
     KernConst kc;
     APGP_CHECK_ARG(apgp_make_kernconst(kern, &kc) == 0, "kernel parameters");
     MeanArgs a;
@@ -1400,7 +1401,8 @@ extern "C" int apgp_predict_mean_host(const double* T_host, int64_t m, const dou
                                       const apgp_kernel_t* kern, double mean, double* mu_host,
                                       double* work, void* stream) {
     APGP_CHECK_ARG(T_host && mu_host && work && kern, "null pointer");
-    APGP_CHECK_ARG(m >= 1, "m >= 1 required");
+    APGP_CHECK_ARG(m >= 1 && m <= APGP_MAX_M, "m >= 1 required");
+    APGP_CHECK_ARG(kern->ndim >= 1 && kern->ndim <= APGP_MAX_DIM, "kernel parameters");   // (sizes the staging area below)
     hipStream_t s = (hipStream_t)stream;
     const size_t tn = (size_t)m * (size_t)kern->ndim;
     {

@@ -293,23 +293,24 @@ def _pool_init(threads, n_train, ndim, metric):
     _POOL["gp"], _POOL["y"], _POOL["ndim"] = gpo, y, ndim
 
 
-def _pool_chunk(c):
-    """One 4,096-candidate chunk through the oracle's ``predict(return_var=True)`` -- its four statements
+def _pool_chunk(job):
+    """One chunk of candidates through the oracle's ``predict(return_var=True)`` -- its four statements
     (oracle/george_oracle.py GP.predict) timed one by one -- + the vectorised AGP utility + arg-min."""
+    c, m = job
     gpo, y, ndim = _POOL["gp"], _POOL["y"], _POOL["ndim"]
-    T = np.random.RandomState(1000 + int(c)).uniform(-5.0, 5.0, size=(4096, ndim))
+    T = np.random.RandomState(1000 + int(c)).uniform(-5.0, 5.0, size=(int(m), ndim))
     t0 = time.time()
     Kxs = gpo.kernel.get_value(T, gpo._x)                      # kernel rows k*(T, X): NumPy, one thread
     t1 = time.time()
     mu = np.dot(Kxs, gpo._compute_alpha(y, True)) + gpo.mean.get_value(T)
     t2 = time.time()
-    KinvKxs = gpo.apply_inverse(Kxs.T)                         # scipy cho_solve, 4096 right-hand sides
+    KinvKxs = gpo.apply_inverse(Kxs.T)                         # scipy cho_solve, one right-hand side per candidate
     t3 = time.time()
     var = gpo.kernel.get_value(T, diag=True) - np.sum(Kxs.T * KinvKxs, axis=0)
     u = agp_utility(mu, var, True)
     i = int(np.nanargmin(u))
     t4 = time.time()
-    return len(T), float(u[i]), int(c) * 4096 + i, t1 - t0, t2 - t1, t3 - t2, t4 - t3
+    return len(T), float(u[i]), int(c) * int(m) + i, t1 - t0, t2 - t1, t3 - t2, t4 - t3
 
 
 def cpu_baseline_worker(args):
@@ -351,12 +352,15 @@ def cpu_baseline_worker(args):
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[k] = str(threads)    # read by the workers' BLAS libraries when THEY load them (this process's are loaded)
     pool = ctx.Pool(workers, initializer=_pool_init, initargs=(threads, n, d, args.metric))
+    # chunks of 4,096 candidates while a wave of them over all workers stays inside the time budget; on a
+    # many-core host, where the workers share the memory bandwidth (one chunk took 92 s with 256 of them at N = 4096), 1,024
+    chunk = 4096 if workers <= 32 else 1024
     try:
-        pool.map(_pool_chunk, range(workers), chunksize=1)      # untimed: every worker fitted, pages touched
+        pool.map(_pool_chunk, [(c, 64) for c in range(workers)], chunksize=1)     # untimed: every worker fitted, pages touched
         done, best, parts, at = 0, (np.inf, -1), np.zeros(4), workers
         t0 = time.time()
         while True:
-            for m, bu, bi, a, b, c, e in pool.map(_pool_chunk, range(at, at + workers), chunksize=1):
+            for m, bu, bi, a, b, c, e in pool.map(_pool_chunk, [(c, chunk) for c in range(at, at + workers)], chunksize=1):
                 done += m
                 parts += (a, b, c, e)
                 if bu < best[0]:
@@ -376,8 +380,8 @@ def cpu_baseline_worker(args):
         "split": {"kernel_rows": parts[0] / tot, "mean": parts[1] / tot, "cho_solve": parts[2] / tot,
                   "variance_utility_argmin": parts[3] / tot,
                   "note": "share of the workers' summed time per statement of the oracle's predict"},
-        "sample": "%d candidates in %.1f s (4096-candidate chunks over %d processes x %d BLAS threads, N_train=%d, "
-                  "D=%d, oracle predict+utility+argmin; fit %.2f s excluded)" % (done, dt, workers, threads, n, d, fit_s),
+        "sample": "%d candidates in %.1f s (%d-candidate chunks over %d processes x %d BLAS threads, N_train=%d, "
+                  "D=%d, oracle predict+utility+argmin; fit %.2f s excluded)" % (done, dt, chunk, workers, threads, n, d, fit_s),
         "scalar_path_value": args.cpu_scalar_calls / ds,
         "scalar_path_sample": "%d single-candidate predict+utility calls in %.1f s, one process, %s BLAS threads "
                               "(what the reference's Nelder-Mead search evaluates)"

@@ -73,7 +73,8 @@ def main():
             if any(a is _lib._KP for a in args):
                 buf = (ctypes.c_double * 64)()
                 argv = [ctypes.byref(bad) if a is _lib._KP else
-                        (ctypes.addressof(buf) if a is ctypes.c_void_p else (0.0 if a is ctypes.c_double else 4))
+                        (ctypes.addressof(buf) if a is ctypes.c_void_p else
+                         (ctypes.cast(buf, a) if hasattr(a, "contents") else (0.0 if a is ctypes.c_double else 4)))
                         for a in args]
                 rc = fn(*argv)
                 assert rc != 0 or res is not ctypes.c_int, (name, ndim, rc)
