@@ -19,4 +19,10 @@ for N in (512, 1152, 3072, 4096):
     for i in range(10):
         gp.set_parameter_vector(p + 1e-3 * (i % 3))
         gp.log_likelihood(y, quiet=True)
+    if N <= 1152:
+        # round 6: what a Powell look-ahead asks for -- 5 hyper-vectors, their persistent factorisations side by side in ONE
+        # launch (gram_batch_kernel, potrf_persist_batch_kernel, potrf_finish_kernel with gridDim.y = 5)
+        P = np.array([p + 1e-3 * j for j in range(5)])
+        for i in range(10):
+            gp.nll_batch(P, y)
     torch.cuda.synchronize()

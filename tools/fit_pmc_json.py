@@ -11,7 +11,7 @@ for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), 
     per = {}
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if not any(s in name for s in ("potrf", "gram_kernel", "nll_small")):
+        if not any(s in name for s in ("potrf", "gram_kernel", "gram_batch", "nll_small")):
             continue
         key = "%s grid %s" % (name, r.get("Grid_Size", "?"))
         d = per.setdefault((key, r["Dispatch_Id"]), {})
