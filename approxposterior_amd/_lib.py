@@ -60,6 +60,7 @@ SIGNATURES = {
     "apgp_nll_side_batches": (_I64, []),
     "apgp_nll_eval_batch": (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "apgp_trsv": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, ctypes.c_int, _P, _P, _P]),
+    "apgp_trsv_ex": (ctypes.c_int, [_P, _I64, _I64, _P, _F64, ctypes.c_int, _P, _P, ctypes.c_int, _P]),
     "apgp_trsv_mode": (ctypes.c_int, [ctypes.c_int]),
     "apgp_append_diag": (ctypes.c_int, [_P, _P, _F64, _P, _I64, _P]),
     "apgp_winv_apply_work_len": (_I64, [_I64]),
@@ -80,6 +81,8 @@ SIGNATURES = {
     "apgp_predict_mean_host": (ctypes.c_int, [_P, _I64, _P, _I64, _KP, _F64, _P, _P, _P]),
     "apgp_ensemble_sample": (ctypes.c_int, [_P, _I64, _KP, _F64, ctypes.POINTER(_F64), ctypes.POINTER(_F64),
                                             _I32, _I32, _I64, _F64, ctypes.c_uint64, _P, _P, _P, _P, _P, _P]),
+    "apgp_ensemble_sample_ex": (ctypes.c_int, [_P, _I64, _KP, _F64, ctypes.POINTER(_F64), ctypes.POINTER(_F64),
+                                               _I32, _I32, _I64, _F64, ctypes.c_uint64, _P, _P, _P, _P, _P, ctypes.c_int, _P]),
     "apgp_ensemble_mode": (ctypes.c_int, [ctypes.c_int]),
     "apgp_box_candidates": (ctypes.c_int, [_P, _I64, _I32, ctypes.POINTER(_F64), ctypes.POINTER(_F64), ctypes.c_uint64,
                                            _I64, _P]),

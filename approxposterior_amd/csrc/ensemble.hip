@@ -262,6 +262,7 @@ __global__ __launch_bounds__(1024) void ensemble_kernel(EnsArgs a) {
 struct EnsMwArgs {
     EnsArgs e;
     unsigned long long* xchg;      // [E][2][ENS_MAXW / 2] granules of 2 x 8 bytes
+    unsigned long long* status;    // sticky "a workgroup gave up" word of this launch (zeroed with xchg)
     unsigned long long timeout;    // 100 MHz ticks
     int G;
 };
@@ -453,6 +454,11 @@ __global__ __launch_bounds__(256) void ensemble_mw_kernel(EnsMwArgs q) {
         }
         if (a.logp_chain && g == 0 && t < W) a.logp_chain[(it * E_ + ens) * W + t] = lp[t];
     }
+    // A workgroup that gave up raises the launch's sticky word: its NaN marker in logp alone could be overwritten by the
+    // ensemble's workgroup 0 finishing normally a moment later (it has every granule it needs) while part of the last chain
+    // rows was never written; ens_mark_failed_kernel, behind this launch on the stream, turns the word
+    // into NaN log-probabilities for every ensemble -- the marker the host looks at can no longer be lost.
+    if (dead && t == 0) atomicOr(q.status, 1ull);
     if (g == 0 || dead) {
         for (int e = t; e < W * D; e += 256) {
             const int w = e / D, d = e % D;
@@ -465,9 +471,15 @@ __global__ __launch_bounds__(256) void ensemble_mw_kernel(EnsMwArgs q) {
     }
 }
 
+__global__ __launch_bounds__(256) void ens_mark_failed_kernel(const unsigned long long* status, double* logp, int count) {
+    if (*status == 0ull) return;
+    for (int i = threadIdx.x; i < count; i += 256) logp[i] = __longlong_as_double(0x7ff8000000000000ll);
+}
+
 // 0 = several workgroups per ensemble where that helps and fits (default) | 1 = the single-workgroup kernel only.
 // A test / profiling switch, not read from the environment.  Returns the previous value.
 static std::atomic<int> g_ens_mode{0};
+static thread_local int tl_ens_mode = -1;       // >= 0: this thread's current call overrides the switch (apgp_ensemble_sample_ex)
 extern "C" int apgp_ensemble_mode(int mode) {
     if (mode < 0) return g_ens_mode.load();
     return g_ens_mode.exchange(mode ? 1 : 0);
@@ -508,20 +520,20 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
         // proposals of a half-step, at most (CUs / ensembles), at least 2; every workgroup must be resident (one per CU
         // with the training stream in LDS)
         int devn = 0, cus = 0;
-        if (g_ens_mode.load() == 0 && hipGetDevice(&devn) == hipSuccess &&
+        if ((tl_ens_mode >= 0 ? tl_ens_mode : g_ens_mode.load()) == 0 && hipGetDevice(&devn) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devn) == hipSuccess && devn >= 0 && devn < 64) {
             int G = nwalkers / 2;
             if ((long long)G * nensembles > cus) G = cus / nensembles;
             if (G >= 2 && iterations > 0) {
                 std::lock_guard<std::mutex> lock(apgp_stream_lock(s));
-                const size_t words = (size_t)nensembles * 2 * (ENS_MAXW / 2) * 2;
+                const size_t words = (size_t)nensembles * 2 * (ENS_MAXW / 2) * 2 + 8;      // (+ the status word)
                 unsigned long long* xchg = (unsigned long long*)apgp_stream_scratch(4, s, words);
                 if (!xchg || hipMemsetAsync(xchg, 0, words * 8, s) != hipSuccess) {
                     apgp_set_error("apgp_ensemble_sample: exchange buffer");
                     return -2;
                 }
                 EnsMwArgs q;
-                q.e = a; q.xchg = xchg; q.timeout = 5000000ull; q.G = G;      // 50 ms of the 100 MHz clock
+                q.e = a; q.xchg = xchg; q.status = xchg + (words - 8); q.timeout = 5000000ull; q.G = G;      // 50 ms of the 100 MHz clock
                 dim3 gridm((unsigned)(nensembles * G)), blockm(256);
                 static std::mutex attr_mu_m;
                 static bool attr_done_m[5][64] = {{false}};
@@ -552,6 +564,7 @@ extern "C" int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kern
                     default: APGP_LAUNCH_ENS_MW(32, 4); break;
                 }
 #undef APGP_LAUNCH_ENS_MW
+                hipLaunchKernelGGL(ens_mark_failed_kernel, dim3(1), dim3(256), 0, s, q.status, logp, (int)(nensembles * nwalkers));
                 APGP_CHECK_LAUNCH();
                 return 0;
             }
@@ -645,4 +658,20 @@ extern "C" int apgp_box_candidates(double* T, int64_t m, int32_t ndim, const dou
     hipLaunchKernelGGL(box_candidates_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     APGP_CHECK_LAUNCH();
     return 0;
+}
+
+// apgp_ensemble_sample with the kernel chosen PER CALL (mode 0: several workgroups per ensemble where that helps, 1: the
+// single-workgroup kernel, < 0: the process-wide switch apgp_ensemble_mode): the re-run after a give-up (NaN in logp) does
+// not change what other threads' calls get.
+extern "C" int apgp_ensemble_sample_ex(const double* xs, int64_t n, const apgp_kernel_t* kern, double mean,
+                                       const double* lo, const double* hi, int32_t nwalkers,
+                                       int32_t nensembles, int64_t iterations, double a_stretch,
+                                       uint64_t seed, double* coords, double* logp, double* chain,
+                                       double* logp_chain, int64_t* naccept, int mode, void* stream) {
+    const int saved = tl_ens_mode;
+    tl_ens_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    const int rc = apgp_ensemble_sample(xs, n, kern, mean, lo, hi, nwalkers, nensembles, iterations, a_stretch, seed, coords,
+                                        logp, chain, logp_chain, naccept, stream);
+    tl_ens_mode = saved;
+    return rc;
 }

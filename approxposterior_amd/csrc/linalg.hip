@@ -494,6 +494,7 @@ __device__ __forceinline__ double trsv_diag_solve(double ri, const double inv, c
 // block in solving order), so the solution carries the same bits.
 // ---------------------------------------------------------------------------
 static std::atomic<int> g_trsv_multi_launch{0};
+static thread_local int tl_trsv_mode = -1;      // >= 0: this thread's current call overrides the switch (apgp_trsv_ex)
 // test / profiling switch: 1 = the launch-per-256-rows path (not read from the environment); returns the previous value
 extern "C" int apgp_trsv_mode(int multi_launch) {
     if (multi_launch < 0) return g_trsv_multi_launch.load();
@@ -650,7 +651,8 @@ extern "C" int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* 
     APGP_CHECK_ARG(L && b && x, "null pointer");
     APGP_CHECK_ARG(n >= 1 && n <= APGP_MAX_N && ldl >= n, "n >= 1 and ldl >= n required");
     hipStream_t st = (hipStream_t)stream;
-    if (n >= 256 && (n + 63) / 64 <= TRSV_P_MAX_NB && !g_trsv_multi_launch.load()) {
+    const int multi_launch = tl_trsv_mode >= 0 ? tl_trsv_mode : g_trsv_multi_launch.load();
+    if (n >= 256 && (n + 63) / 64 <= TRSV_P_MAX_NB && !multi_launch) {
         // ONE persistent launch (trsv_persist_kernel): flags-free granule hand-offs, call-unique tags and tickets (the
         // scratch is zeroed when it is allocated, never between calls); b may alias x (a block's owner alone touches it)
         std::lock_guard<std::mutex> enqueue_lock(apgp_stream_lock(st));
@@ -766,6 +768,18 @@ __global__ void append_diag_kernel(double* ljj, const double* ss, double kdiag, 
     const double d2 = kdiag - *ss;
     if (d2 > 0.0 && d2 < INFINITY) *ljj = sqrt(d2);
     else { *ljj = 1.0; atomicCAS(info, 0, order); }
+}
+
+// apgp_trsv with the path chosen PER CALL (mode 0: the persistent launch where it applies, 1: a launch per 256 rows, < 0: the
+// process-wide switch apgp_trsv_mode) -- what a caller uses to re-run one solve whose persistent launch gave up (NaN), without
+// changing the path of other threads' or streams' calls.
+extern "C" int apgp_trsv_ex(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
+                            int trans, double* x, double* sumsq, int mode, void* stream) {
+    const int saved = tl_trsv_mode;
+    tl_trsv_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    const int rc = apgp_trsv(L, n, ldl, b, shift, trans, x, sumsq, stream);
+    tl_trsv_mode = saved;
+    return rc;
 }
 
 extern "C" int apgp_append_diag(double* ljj, const double* ss, double kdiag, int32_t* info_dev, int64_t order,

@@ -834,15 +834,11 @@ class GP(GeorgeExtras):
                 if not via_w and self._ztz_host != self._ztz_host:
                     # NaN: the persistent solve could not get its workgroups resident (apgp.h: it writes NaN instead of
                     # hanging) -- or the factor is not finite, in which case the re-run says so too.  Once more, a launch per
-                    # 256 rows.
-                    prev = lib.apgp_trsv_mode(1)
-                    try:
-                        _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, self._ld, self._y_d.data_ptr(),
-                                                 float(self.mean.value), 0, self._z.data_ptr(),
-                                                 ztz.data_ptr(), st), "apgp_trsv(forward, multi-launch)")
-                        self._ztz_host = float(ztz.item())
-                    finally:
-                        lib.apgp_trsv_mode(prev)
+                    # 256 rows -- chosen for THIS call only (apgp_trsv_ex): other threads' and streams' solves keep their path.
+                    _lib.check(lib.apgp_trsv_ex(self._L.data_ptr(), n, self._ld, self._y_d.data_ptr(),
+                                                float(self.mean.value), 0, self._z.data_ptr(),
+                                                ztz.data_ptr(), 1, st), "apgp_trsv(forward, multi-launch)")
+                    self._ztz_host = float(ztz.item())
                 self._alpha = None
                 self._xs = None
                 self._alpha_y = np.array(y, copy=True)
@@ -859,12 +855,8 @@ class GP(GeorgeExtras):
                     _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, self._ld, self._z.data_ptr(), 0.0, 1,
                                              self._alpha.data_ptr(), asq.data_ptr(), st), "apgp_trsv(backward)")
                     if float(asq.item()) != float(asq.item()):      # (NaN: see the forward solve)
-                        prev = lib.apgp_trsv_mode(1)
-                        try:
-                            _lib.check(lib.apgp_trsv(self._L.data_ptr(), n, self._ld, self._z.data_ptr(), 0.0, 1,
-                                                     self._alpha.data_ptr(), None, st), "apgp_trsv(backward, multi-launch)")
-                        finally:
-                            lib.apgp_trsv_mode(prev)
+                        _lib.check(lib.apgp_trsv_ex(self._L.data_ptr(), n, self._ld, self._z.data_ptr(), 0.0, 1,
+                                                    self._alpha.data_ptr(), None, 1, st), "apgp_trsv(backward, multi-launch)")
                 self._xs = None
         return self._ztz_host
 
@@ -1369,23 +1361,24 @@ class GP(GeorgeExtras):
             nacc = torch.empty((E, W), dtype=torch.int64, device=dev)
             chain = torch.empty((iterations, E, W, D), dtype=torch.float64, device=dev) if store else None
             lchain = torch.empty((iterations, E, W), dtype=torch.float64, device=dev) if store else None
-            def launch():
+            def launch(mode):
                 coords.copy_(torch.from_numpy(p0))
-                _lib.check(lib.apgp_ensemble_sample(
+                _lib.check(lib.apgp_ensemble_sample_ex(
                     self._xs.data_ptr(), n, ctypes.byref(ks), float(self.mean.value), lo, hi, W, E,
                     iterations, float(a), int(seed) & 0xFFFFFFFFFFFFFFFF, coords.data_ptr(), logp.data_ptr(),
                     chain.data_ptr() if store else None, lchain.data_ptr() if store else None,
-                    nacc.data_ptr(), st), "apgp_ensemble_sample")
+                    nacc.data_ptr(), mode, st), "apgp_ensemble_sample")
                 return logp.cpu().numpy().reshape(E * W)
-            final = launch()
+            final = launch(-1)
             if np.any(np.isnan(final)):
                 # the multi-workgroup launch could not get its workgroups resident (another stream or process holds
-                # compute units): once more on the single-workgroup kernel -- slower, same posterior
-                prev = lib.apgp_ensemble_mode(1)
-                try:
-                    final = launch()
-                finally:
-                    lib.apgp_ensemble_mode(prev)
+                # compute units; the launch's sticky word turned every log-probability into NaN): once more on the
+                # single-workgroup kernel -- slower, same posterior -- chosen for THIS call only (no process-wide switch
+                # is flipped under other threads' calls)
+                final = launch(1)
+                if np.any(np.isnan(final)):
+                    raise FloatingPointError("the ensemble sampler returned NaN log-probabilities on both of its kernels: "
+                                             "the GP mean is not finite at the walkers' positions")
             out = {"coords": coords.cpu().numpy().reshape(E * W, D),
                    "final_log_prob": final,
                    "naccept": nacc.cpu().numpy().reshape(E * W),

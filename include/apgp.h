@@ -230,6 +230,11 @@ int apgp_trsv(const double* L, int64_t n, int64_t ldl, const double* b, double s
 /* Test / profiling switch (not read from the environment): 1 = the multi-launch path, 0 = default
  * (persistent launch where it applies); < 0 queries.  Returns the previous value.             */
 int apgp_trsv_mode(int multi_launch);
+/* apgp_trsv with the path chosen for THIS call (0: persistent launch where it applies, 1: a launch per
+ * 256 rows, < 0: the process-wide switch): the re-run of one solve that came back NaN, without changing
+ * what other threads' or streams' calls get (round 6).                                */
+int apgp_trsv_ex(const double* L, int64_t n, int64_t ldl, const double* b, double shift,
+                 int trans, double* x, double* sumsq, int mode, void* stream);
 
 /* ---- pivot of an appended factor row -----------------------------------------
  * Incremental fit when ApproxPosterior.findNextPoint appends a design point
@@ -375,6 +380,16 @@ int apgp_predict_mean_host(const double* T_host, int64_t m, const double* xs, in
  * 50 ms the launch writes NaN into logp[] -- the caller re-runs with apgp_ensemble_mode(1) (the Python wrapper does).
  * apgp_ensemble_mode: 0 = default, 1 = single-workgroup kernel only; < 0 queries; returns the previous value.   */
 int apgp_ensemble_mode(int mode);
+/* apgp_ensemble_sample with the kernel chosen for THIS call (0: several workgroups per ensemble where
+ * that helps, 1: the single-workgroup kernel, < 0: the process-wide switch).  Round 6: a workgroup
+ * that gives up also raises a sticky word of the launch, and a one-workgroup kernel behind it turns
+ * that word into NaN in ALL of logp[] -- the marker cannot be overwritten by a workgroup that finishes
+ * normally afterwards.                                                                                */
+int apgp_ensemble_sample_ex(const double* xs, int64_t n, const apgp_kernel_t* kern /*host*/, double mean,
+                            const double* lo /*host, MAX_DIM*/, const double* hi /*host, MAX_DIM*/,
+                            int32_t nwalkers, int32_t nensembles, int64_t iterations, double a_stretch,
+                            uint64_t seed, double* coords, double* logp, double* chain,
+                            double* logp_chain, int64_t* naccept, int mode, void* stream);
 int apgp_ensemble_sample(const double* xs, int64_t n, const apgp_kernel_t* kern /*host*/, double mean,
                          const double* lo /*host*/, const double* hi /*host*/,
                          int32_t nwalkers, int32_t nensembles, int64_t iterations,

@@ -221,6 +221,64 @@ def test_backoff_after_a_contended_persistent_launch():
         assert skipped >= 64 and gave_up <= 4
 
 
+def test_multi_workgroup_sampler_gives_up_cleanly_under_contention():
+    """a workgroup of the multi-workgroup sampler that times out used to mark the failure with NaN in
+    ``logp`` only, which the ensemble's workgroup 0 could overwrite a moment later.  Now it raises a sticky word of the launch
+    and a one-workgroup kernel behind it turns that into NaN for every log-probability; ``GP.sample_ensemble`` re-runs on the
+    single-workgroup kernel, chosen for that call only (``apgp_ensemble_sample_ex``: no process-wide switch is flipped).
+    Foreign single-workgroup kernels hold 240 of the 256 compute units while one ensemble of 64 walkers asks for 32: the
+    result must be the single-workgroup kernel's, complete and finite, and the process-wide mode untouched."""
+    import threading
+    import torch
+    from approxposterior_amd import _lib
+    go, agp = _mods()
+    lib = _lib.load()
+    X, y = _case(700, 8, 5)
+    g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 8.0), ndim=8), fit_mean=True, mean=float(np.median(y)),
+               white_noise=-12, fit_white_noise=False)
+    g.compute(X)
+    p0 = np.random.RandomState(8).uniform(-5, 5, size=(1, 64, 8))
+    bounds = [(-5, 5)] * 8
+    prev = lib.apgp_ensemble_mode(1)
+    try:
+        single = g.sample_ensemble(y, p0, 300, bounds, seed=5)
+    finally:
+        lib.apgp_ensemble_mode(prev)
+    Xb, yb = _case(600, 8, 2)
+    hog = agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 8.0), ndim=8), fit_mean=True, mean=float(np.median(yb)),
+                 white_noise=-12, fit_white_noise=False)
+    side = torch.cuda.Stream()
+    stop = threading.Event()
+
+    def foreign():
+        with torch.cuda.stream(side):
+            hog.compute(Xb)
+            q0 = np.random.RandomState(3).uniform(-5, 5, size=(240, 16, 8))
+            while not stop.is_set():
+                hog.sample_ensemble(yb, q0, 4000, bounds, seed=1, store=False)
+    th = threading.Thread(target=foreign)
+    th.start()
+    try:
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        got = g.sample_ensemble(y, p0, 300, bounds, seed=5)
+        dt = time.perf_counter() - t0
+    finally:
+        stop.set()
+        th.join()
+    assert lib.apgp_ensemble_mode(-1) == 0                               # nobody flipped the process-wide switch
+    for key in ("chain", "log_prob", "coords", "final_log_prob"):
+        assert not np.any(np.isnan(got[key])), key                        # complete: no row left unwritten, no marker left
+    gave_up = dt > 0.05
+    print("contended multi-workgroup sampler: %.1f ms (%s)" % (dt * 1e3, "gave up, re-ran on one workgroup" if gave_up else "ran"))
+    if gave_up:
+        for key in ("chain", "log_prob", "coords", "final_log_prob", "naccept"):
+            assert np.array_equal(got[key], single[key]), key             # the single-workgroup kernel's result, every bit
+    else:
+        assert np.allclose(got["chain"], single["chain"], rtol=1e-9, atol=1e-9)
+        assert np.array_equal(got["naccept"], single["naccept"])
+
+
 def test_nll_memo_answers_exact_repeats_only():
     """gpUtils._nll keeps the last 64 evaluated points of THIS training set and y (Powell re-asks f at the head of every
     line search): an exact repeat costs no device work and returns the same float; a different y, a new training set or a
