@@ -546,7 +546,8 @@ class GP(GeorgeExtras):
         x_in = x
         x = self.parse_samples(x)
         if x.shape[1] > _lib.MAX_DIM:
-            raise ValueError("at most %d dimensions are supported" % _lib.MAX_DIM)
+            raise ValueError("approxposterior_amd supports at most %d input dimensions (APGP_MAX_DIM in include/apgp.h: the "
+                             "kernels keep a point's coordinates in registers); got %d" % (_lib.MAX_DIM, x.shape[1]))
         if x is x_in or (isinstance(x_in, np.ndarray) and np.shares_memory(x, x_in)):
             x = x.copy()              # the object owns its training set: a caller who edits x in place afterwards is not seen
         same_x = self._x is not None and self._x.shape == x.shape and np.array_equal(self._x, x)
@@ -1375,6 +1376,7 @@ class GP(GeorgeExtras):
                 # compute units; the launch's sticky word turned every log-probability into NaN): once more on the
                 # single-workgroup kernel -- slower, same posterior -- chosen for THIS call only (no process-wide switch
                 # is flipped under other threads' calls)
+                self.ensemble_fallbacks = getattr(self, "ensemble_fallbacks", 0) + 1
                 final = launch(1)
                 if np.any(np.isnan(final)):
                     raise FloatingPointError("the ensemble sampler returned NaN log-probabilities on both of its kernels: "

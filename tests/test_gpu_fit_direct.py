@@ -260,23 +260,31 @@ def test_multi_workgroup_sampler_gives_up_cleanly_under_contention():
     th.start()
     try:
         time.sleep(1.0)
-        t0 = time.perf_counter()
-        got = g.sample_ensemble(y, p0, 300, bounds, seed=5)
-        dt = time.perf_counter() - t0
+        runs = []
+        for attempt in range(40):        # (a call may fall into the gap between two foreign launches: until one gives up)
+            before = getattr(g, "ensemble_fallbacks", 0)
+            t0 = time.perf_counter()
+            got = g.sample_ensemble(y, p0, 300, bounds, seed=5)
+            dt = time.perf_counter() - t0
+            runs.append((dt, got, getattr(g, "ensemble_fallbacks", 0) > before))
+            if runs[-1][2]:
+                break
     finally:
         stop.set()
         th.join()
     assert lib.apgp_ensemble_mode(-1) == 0                               # nobody flipped the process-wide switch
-    for key in ("chain", "log_prob", "coords", "final_log_prob"):
-        assert not np.any(np.isnan(got[key])), key                        # complete: no row left unwritten, no marker left
-    gave_up = dt > 0.05
-    print("contended multi-workgroup sampler: %.1f ms (%s)" % (dt * 1e3, "gave up, re-ran on one workgroup" if gave_up else "ran"))
-    if gave_up:
-        for key in ("chain", "log_prob", "coords", "final_log_prob", "naccept"):
-            assert np.array_equal(got[key], single[key]), key             # the single-workgroup kernel's result, every bit
-    else:
-        assert np.allclose(got["chain"], single["chain"], rtol=1e-9, atol=1e-9)
-        assert np.array_equal(got["naccept"], single["naccept"])
+    gave_up = sum(1 for _, _, fell_back in runs if fell_back)
+    print("contended multi-workgroup sampler: %d calls, %d gave up and re-ran on one workgroup (%s ms)"
+          % (len(runs), gave_up, ", ".join("%.1f" % (dt * 1e3) for dt, _, _ in runs[-3:])))
+    for dt, got, fell_back in runs:
+        for key in ("chain", "log_prob", "coords", "final_log_prob"):
+            assert not np.any(np.isnan(got[key])), key                    # complete: no row left unwritten, no marker left
+        if fell_back:
+            for key in ("chain", "log_prob", "coords", "final_log_prob", "naccept"):
+                assert np.array_equal(got[key], single[key]), key         # the single-workgroup kernel's result, every bit
+        else:
+            assert np.allclose(got["chain"], single["chain"], rtol=1e-9, atol=1e-9)
+            assert np.array_equal(got["naccept"], single["naccept"])
 
 
 def test_nll_memo_answers_exact_repeats_only():

@@ -434,3 +434,19 @@ def test_powell_lookahead_abscissae_are_scipys():
     for at, pts in later:
         if at + 1 < len(asked) and len(pts) == 2:                          # Brent's first step: the second is one of the two
             assert any(np.array_equal(asked[at + 1], q) for q in pts)
+
+
+def test_more_than_max_dim_dimensions_is_an_explicit_error():
+    """george has no dimension limit (gpUtils.py:150-161); this build has one (APGP_MAX_DIM = 32: the kernels keep a point's
+    coordinates in registers).  A 33-dimensional training set must be refused with a ValueError that names the limit --
+    before any device work -- by compute() and therefore by defaultGP."""
+    from approxposterior_amd import gp as agp, gpUtils, _lib
+    d = _lib.MAX_DIM + 1
+    rs = np.random.RandomState(0)
+    X, y = rs.uniform(-1, 1, size=(40, d)), rs.randn(40)
+    g = agp.GP(kernel=agp.ExpSquaredKernel(np.ones(d), ndim=d), fit_mean=True, mean=0.0, white_noise=-12, fit_white_noise=False)
+    with pytest.raises(ValueError, match=r"at most 32 input dimensions.*got 33"):
+        g.compute(X)
+    np.random.seed(1)
+    with pytest.raises(ValueError, match="APGP_MAX_DIM"):
+        gpUtils.defaultGP(X, y)
