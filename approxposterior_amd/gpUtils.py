@@ -112,7 +112,8 @@ def _powellAhead(width):
     asked for, the abscissae of up to three further evaluations are known up to a handful of cases; an evaluation
     occupies a quarter of the chip, so the likely ones ride along with f(1) in ONE batched device call and the next
     answers come from the memo -- SciPy sees the same values in the same order, bit for bit.  The same at the two later
-    points where a miss can still look ahead: the third bracket point (its Brent steps) and Brent's first step (its second).
+    points where a miss can still look ahead: the third bracket point (its Brent steps), Brent's first step (its second) and a
+    tolerance step x +- tol1 near the end of the search (the same step to the other side).
 
     The abscissae are recomputed with SciPy's own constants and expressions from the frames of the caller (``bracket`` <-
     ``Brent.get_bracket_info`` <- ``Brent.optimize``: ``_gold``, ``tol``, ``_cg``, ``_mintol``) and the points as
@@ -161,12 +162,29 @@ def _powellAhead(width):
         elif where == "optimize":
             ol = site.f_locals
             brent = ol.get("self")
-            if brent is None or ol.get("iter") != 0 or not (ol["x"] == ol["w"] == ol["v"]):
+            if brent is None:
                 return None
-            u1, ugt, ule = _brentAhead(brent, ol["xa"], ol["xb"], ol["xc"])
-            if u1 is None or u1 != alpha:
-                return None
-            abscissae = [ugt, ule]                     # Brent's first step: its second, for either outcome
+            if ol.get("iter") == 0:
+                if not (ol["x"] == ol["w"] == ol["v"]):
+                    return None
+                u1, ugt, ule = _brentAhead(brent, ol["xa"], ol["xb"], ol["xc"])
+                if u1 is None or u1 != alpha:
+                    return None
+                abscissae = [ugt, ule]                 # Brent's first step: its second, for either outcome
+            else:
+                # a TOLERANCE step: the interpolated step was shorter than tol1 (or too close to an end of the interval), so
+                # SciPy evaluates x + tol1 or x - tol1 -- the search is closing in on x.  If the value there is no better
+                # (the usual case) the interval's end moves to it and the next step is, more often than not, the same step
+                # to the other side (after which the convergence test stops the loop): one more abscissa that is known now
+                x, u, tol1 = ol["x"], ol["u"], ol["tol1"]
+                if u != alpha:
+                    return None
+                if u == x + tol1:
+                    abscissae = [x - tol1]
+                elif u == x - tol1:
+                    abscissae = [x + tol1]
+                else:
+                    return None
         else:
             return None
         return [base + a_ * xi for a_ in abscissae if a_ is not None][:width]
