@@ -221,6 +221,62 @@ def test_backoff_after_a_contended_persistent_launch():
         assert skipped >= 64 and gave_up <= 4
 
 
+def test_side_by_side_batch_under_contention_equals_single_evaluations():
+    """Round 6: ``apgp_nll_eval_batch`` runs 2 .. 6 persistent factorisations side by side in one launch; when foreign
+    kernels hold most compute units its workgroups cannot all be resident, a matrix gives up, and the whole batch is
+    redone on the batched launch-per-step path (then the back-off of the single call applies).  Whatever path served it,
+    every value equals the single evaluation's, bit for bit."""
+    import threading
+    import torch
+    from approxposterior_amd import _lib, gpUtils
+    go, agp = _mods()
+    lib = _lib.load()
+    n = 900
+    X, y = _case(n, 8, 19)
+    g = agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 8.0), ndim=8), fit_mean=True, mean=float(np.median(y)),
+               white_noise=-12, fit_white_noise=False)
+    g.compute(X)
+    g.lookahead = 0
+    p0 = g.get_parameter_vector()
+    P = np.array([p0 + np.concatenate([[0.0], np.random.RandomState(k).uniform(-0.3, 0.3, size=8)]) for k in range(5)])
+    lib.apgp_potrf_mode(0)
+    want = []
+    for p in P:
+        g._nllMemo = None
+        want.append(gpUtils._nll(p, g, y, None))
+    want = np.array(want)
+    assert np.array_equal(g.nll_batch(P, y), want)
+    Xb, yb = _case(600, 8, 2)
+    hog = agp.GP(kernel=agp.ExpSquaredKernel(np.full(8, 8.0), ndim=8), fit_mean=True, mean=float(np.median(yb)),
+                 white_noise=-12, fit_white_noise=False)
+    side = torch.cuda.Stream()
+    stop = threading.Event()
+
+    def foreign():
+        with torch.cuda.stream(side):
+            hog.compute(Xb)
+            q0 = np.random.RandomState(3).uniform(-5, 5, size=(220, 16, 8))
+            while not stop.is_set():
+                hog.sample_ensemble(yb, q0, 4000, [(-5, 5)] * 8, seed=1, store=False)
+    th = threading.Thread(target=foreign)
+    th.start()
+    try:
+        time.sleep(1.0)
+        fb, sb, sk = lib.apgp_potrf_fallbacks(), lib.apgp_nll_side_batches(), lib.apgp_potrf_backoff_skips()
+        t0 = time.perf_counter()
+        for rep in range(120):
+            got = g.nll_batch(P[:2 + rep % 4], y)
+            assert np.array_equal(got, want[:2 + rep % 4]), rep
+        dt = (time.perf_counter() - t0) / 120
+    finally:
+        stop.set()
+        th.join()
+        lib.apgp_potrf_mode(0)
+    print("contended batches: %.3f ms on average, %d served side by side, %d gave up, %d skipped the persistent launch"
+          % (dt * 1e3, lib.apgp_nll_side_batches() - sb, lib.apgp_potrf_fallbacks() - fb, lib.apgp_potrf_backoff_skips() - sk))
+    assert dt < 4e-3
+
+
 def test_multi_workgroup_sampler_gives_up_cleanly_under_contention():
     """a workgroup of the multi-workgroup sampler that times out used to mark the failure with NaN in
     ``logp`` only, which the ensemble's workgroup 0 could overwrite a moment later.  Now it raises a sticky word of the launch
