@@ -119,3 +119,39 @@ def test_run_under_rccl_group_equals_run_without(rccl_world1, tmp_path, monkeypa
     for a, b in zip(out[False], out[None]):
         assert np.array_equal(a, b)
     assert out[None][0].shape == (96 + 8, D)
+
+
+def test_run_loop_two_ranks_sharing_the_gpu_equals_one_rank(tmp_path):
+    """Round 6: the product loop under a REAL multi-rank process group on the one GPU the driver has -- two processes,
+    both on cuda:0, host collectives (``tools/run_c5_dist.py --backend gloo --share-device``): the sweep sharded by rank
+    over the HIP kernels' device records, the restarts spread, one replica ensemble per rank, the forward model on rank 0.
+    Both ranks must end with the same training set and hyper-parameters (``ranks_agree``), equal to the single-rank run's
+    (``digest``), with twice the walkers in the gathered chain.  approx.py:396-424, :664-672, :839-856."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--points", "3", "--nmax", "2", "--m0", "200", "--candidates", "20000", "--iterations", "300", "--walkers", "16",
+             "--restarts", "2", "--backend", "gloo", "--share-device"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "tools", "run_c5_dist.py")] + small,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=800)
+    assert two.returncode == 0, two.stderr[-3000:]
+    rec2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    env1 = dict(env, MASTER_PORT=str(port + 1))
+    one = subprocess.run([sys.executable, os.path.join(root, "tools", "run_c5_dist.py")] + small,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env1, timeout=800)
+    assert one.returncode == 0, one.stderr[-3000:]
+    rec1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec2["world"] == 2 and rec2["ranks_agree"] and rec1["world"] == 1
+    assert rec2["n_train"] == rec1["n_train"] == 206
+    assert rec2["digest"] == rec1["digest"]                       # same design points, values and hyper-parameters, every bit
+    assert rec2["chain_walkers"] == 2 * rec1["chain_walkers"] == 32

@@ -5,7 +5,8 @@
         tools/run_c5_dist.py [--m 64 --nmax 10 --candidates 1000000 --iterations 20000 --restarts 1]
 
 (also runs as a plain ``python tools/run_c5_dist.py`` = one rank; ``--backend gloo`` keeps the collectives on the host, the
-arithmetic still runs on the GPU: there is no CPU path).  The process group is created BEFORE anything touches the GPU and the script never
+arithmetic still runs on the GPU: there is no CPU path; ``--backend gloo --share-device`` puts all ranks on cuda:0 -- the
+whole multi-rank loop on the one GPU the driver has, ``tests/test_gpu_dist_nccl.py``).  The process group is created BEFORE anything touches the GPU and the script never
 re-executes itself.  What the ranks share (approxposterior_amd/dist.py): the candidate sweep is sharded by rank with one
 16-byte-per-rank all-gather, every rank samples its own replica ensemble and the chains are gathered once, optimiser
 restarts are spread over the ranks, the forward model runs on rank 0 and its value is broadcast.  Rank 0 prints one JSON
@@ -24,7 +25,9 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap_ = argparse.ArgumentParser()
-    ap_.add_argument("--m", type=int, default=64)
+    ap_.add_argument("--m", "--points", dest="m", type=int, default=64,
+                     help="design points per outer iteration (--points: torch.distributed.run's own parser takes a bare --m as "
+                          "an ambiguous prefix of its options)")
     ap_.add_argument("--nmax", type=int, default=10)
     ap_.add_argument("--m0", type=int, default=512)
     ap_.add_argument("--dim", type=int, default=8)
@@ -33,7 +36,11 @@ def main():
     ap_.add_argument("--walkers", type=int, default=64)
     ap_.add_argument("--restarts", type=int, default=1)
     ap_.add_argument("--backend", default="nccl")
+    ap_.add_argument("--share-device", action="store_true",
+                     help="all ranks on cuda:0 (needs --backend gloo): the multi-rank loop rehearsed on ONE GPU")
     args = ap_.parse_args()
+    if args.share_device and args.backend != "gloo":
+        ap_.error("--share-device needs --backend gloo (RCCL refuses two ranks on one device)")
 
     import numpy as np
     import torch
@@ -43,7 +50,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(0 if args.share_device else local)
     dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from scipy.optimize import rosen
@@ -90,7 +97,7 @@ def main():
                           "training_s": [round(v, 2) for v in driver.trainingTime],
                           "mcmc_s": [round(v, 2) for v in driver.mcmcTime],
                           "n_train": int(len(driver.y)), "chain_walkers": int(driver.sampler.get_chain().shape[1]),
-                          "ranks_agree": same}))
+                          "ranks_agree": same, "digest": digest.hex()}))
     dist.destroy_process_group()
     if not same:
         sys.exit(3)
