@@ -218,7 +218,31 @@ def fit_leg(agp, dev, seconds_cap=20.0):
         o.set_parameter_vector(p)
         llo = o.log_likelihood(y, quiet=True)
         flops = n ** 3 / 3.0
-        out.append({"n_train": n, "ndim": d, "nll_ms": gpu_ms, "tflops": flops / (gpu_ms * 1e-3) / 1e12,
+        # what an optimiser pays per evaluation (gpUtils.py:238: SciPy's Powell on _nll), without / with the look-ahead of
+        # gpUtils._powellAhead -- same points, same values, fewer device rounds
+        powell = {}
+        if n > 64:
+            from scipy.optimize import minimize
+            from approxposterior_amd import gpUtils
+            for tag, ahead in (("off", 0), ("on", None)):
+                g.lookahead = ahead
+                g._nllMemo = None
+                g.set_parameter_vector(p)
+                cnt = [0]
+
+                def fobj(q):
+                    cnt[0] += 1
+                    return gpUtils._nll(q, g, y)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                with np.errstate(all="ignore"):
+                    res = minimize(fobj, p, method="powell", options={"maxfev": 500 if n <= 1152 else 200})
+                powell[tag] = {"ms_per_evaluation": (time.time() - t0) / max(cnt[0], 1) * 1e3, "evaluations": cnt[0],
+                               "fun": float(res["fun"])}
+            g.lookahead = None
+            powell["same_optimum"] = powell["off"]["fun"] == powell["on"]["fun"]
+            powell["lookahead_width"] = g.lookahead_width()
+        out.append({"n_train": n, "ndim": d, "nll_ms": gpu_ms, "tflops": flops / (gpu_ms * 1e-3) / 1e12, "powell": powell,
                     "frac_of_f64_peak": flops / (gpu_ms * 1e-3) / 1e12 / PEAK_F64_TFLOPS,
                     "cpu_nll_ms": float(np.median(tc)) * 1e3, "cpu_cores": os.cpu_count(), "cpu_blas_threads": blas_threads,
                     "cpu_kind": "port",
@@ -624,9 +648,9 @@ def main():
             for i in range(20, 300):
                 gp.predict(y, t1[i:i + 1], return_var=True)
             out["cpu_baseline"]["scalar_path_gpu_value"] = 280.0 / (time.time() - t0)
-            if not args.no_fit_leg:
-                out["fit"] = fit_leg(agp, dev)
-                out["mid_n"] = mid_n_leg(agp, dev)
+        if world == 1 and not args.no_fit_leg:
+            out["fit"] = fit_leg(agp, dev)
+            out["mid_n"] = mid_n_leg(agp, dev)
         print(json.dumps(out))
     if launched:
         dist.destroy_process_group()
