@@ -1010,7 +1010,7 @@ class GP(GeorgeExtras):
                             torch.empty((nb, n), dtype=torch.float64, device=dev),
                             torch.empty(nb, dtype=torch.int32, device=dev),
                             torch.empty((nb, 5), dtype=torch.float64, device=dev))
-                    if 8 * nb * n * n <= (64 << 20):      # (large work spaces are not hoarded)
+                    if 8 * nb * n * n <= (256 << 20):     # (larger work spaces are not hoarded; 6 matrices of N = 2300 fit)
                         cache["bufs"][nb] = bufs
                 K, z, info, o_d = bufs
                 o = np.empty((nb, 5), dtype=np.float64)
