@@ -102,7 +102,42 @@ def _brentAhead(brent, xa, xb, xc):
     return u1, _brentGolden(brent, x, ag, bg), _brentGolden(brent, u1, al, bl)
 
 
-def _powellAhead(width):
+_GOLD = 1.618034          # scipy.optimize._optimize.bracket's ``_gold`` (read from its frame where one is at hand; pinned by a test)
+
+
+def _nextSearchAhead(site, brent, base, xi, x):
+    """The first points of the NEXT line search of ``_minimize_powell``, assuming the current one ends at Brent's current
+    best abscissa ``x`` -- which is what a tolerance step x +- tol1 announces (nine line searches in ten end with one, and
+    its value is rarely better than f(x)).  SciPy returns ``p + x * xi`` as the new point and goes on along ``direc[i + 1]``:
+    f(0) there is f(x) (a memo hit), then f(1), the third bracket point and Brent's first two steps -- the abscissae of
+    :func:`_powellAhead`, none of which depends on the point.  After the last direction of a sweep the next evaluation is
+    the extrapolated point ``x + (x - x1)``.  Only for the searches of the direction loop (``xi`` is a row of ``direc``);
+    anything else: nothing."""
+    fr = site
+    for name in ("_minimize_scalar_brent", "_recover_from_bracket_error", "_linesearch_powell", "_minimize_powell"):
+        fr = fr.f_back
+        if fr is None or fr.f_code.co_name != name:
+            return []
+    loc = fr.f_locals
+    direc, i, n = loc["direc"], loc["i"], loc["N"]
+    if loc.get("lower_bound") is not None or loc.get("upper_bound") is not None:
+        return []
+    if not (0 <= i < n and np.shares_memory(xi, direc) and np.array_equal(direc[i], xi)):
+        return []
+    new = base + x * xi                                   # _linesearch_powell: xi = alpha_min * xi; return fret, p + xi, xi
+    if i + 1 == n:
+        direc1 = new - loc["x1"]                          # the extrapolated point (lmax = 1 without bounds)
+        return [new + 1 * direc1]
+    nxt = direc[i + 1]
+    if not np.any(nxt):
+        return []
+    xa, xb = np.asarray([0.0, 1.0])
+    cB = xa + _GOLD * (xa - xb)
+    uB = _brentAhead(brent, xb, xa, cB)
+    return [new + a_ * nxt for a_ in (xb, cB, uB[0], uB[1]) if a_ is not None]
+
+
+def _powellAhead(width, explain=False):
     """The points SciPy's Powell line search is going to ask for NEXT, known before any value is (gpUtils.py:238:
     ``minimize(_nll, method="powell")``).  ``_linesearch_powell`` minimises ``myfunc(alpha) = f(p + alpha xi)`` with
     Brent's method, which first brackets from (0, 1): f(0) is the current point (a memo hit), then f(1), then
@@ -113,7 +148,8 @@ def _powellAhead(width):
     occupies a quarter of the chip, so the likely ones ride along with f(1) in ONE batched device call and the next
     answers come from the memo -- SciPy sees the same values in the same order, bit for bit.  The same at the two later
     points where a miss can still look ahead: the third bracket point (its Brent steps), Brent's first step (its second) and a
-    tolerance step x +- tol1 near the end of the search (the same step to the other side).
+    tolerance step x +- tol1 near the end of the search (the same step to the other side, and the first points of the NEXT
+    line search from the point this one is about to return: :func:`_nextSearchAhead`).
 
     The abscissae are recomputed with SciPy's own constants and expressions from the frames of the caller (``bracket`` <-
     ``Brent.get_bracket_info`` <- ``Brent.optimize``: ``_gold``, ``tol``, ``_cg``, ``_mintol``) and the points as
@@ -121,7 +157,8 @@ def _powellAhead(width):
     frames (another SciPy, another method, another call site): no look-ahead, nothing else changes.  A wrong guess
     costs idle-CU work only: a point that is never asked for is never used.
 
-    Returns up to ``width`` points (most likely first), or None."""
+    Returns up to ``width`` points (most likely first), or None; with ``explain`` (tests) ``(call site, points)``, the call
+    site one of "f(1)", "third bracket point", "Brent's first step", "tolerance step"."""
     try:
         line = sys._getframe(2)                        # _nll's caller: SciPy's function wrapper <- myfunc(alpha)
         for _ in range(4):                             # (a caller's own thin wrapper around _nll may sit in between)
@@ -136,7 +173,7 @@ def _powellAhead(width):
         loc = line.f_locals
         alpha, base, xi = loc["alpha"], loc["p"], loc["xi"]
         where = site.f_code.co_name
-        abscissae = []
+        abscissae, extra, kind = [], [], None
         if where == "bracket":
             bl = site.f_locals
             info = site.f_back
@@ -148,17 +185,21 @@ def _powellAhead(width):
                 if not (alpha == 1.0 and bl["xa"] == 0.0 and bl["xb"] == 1.0):
                     return None
                 gold, xa, xb = bl["_gold"], bl["xa"], bl["xb"]
+                if gold != _GOLD:
+                    return None                        # (another SciPy: _nextSearchAhead's constant would be wrong too)
                 # f(0) < f(1): SciPy swaps (xa, xb) and goes on to -1.618034 -- that case first; else no swap, 2.618034
                 cB, cA = xa + gold * (xa - xb), xb + gold * (xb - xa)
                 uB = uA = (None, None, None)
                 if brent is not None and width > 1:
                     uB, uA = _brentAhead(brent, xb, xa, cB), _brentAhead(brent, xa, xb, cA)
                 abscissae = [cB, uB[0], uB[1], cA, uA[0], uB[2], uA[1], uA[2]]
+                kind = "f(1)"
             else:
                 # fc = func(xc): if it closes the bracket, Brent's first two steps on (xa, xb, xc)
                 if brent is None or alpha != bl["xc"]:
                     return None
                 abscissae = list(_brentAhead(brent, bl["xa"], bl["xb"], bl["xc"]))
+                kind = "third bracket point"
         elif where == "optimize":
             ol = site.f_locals
             brent = ol.get("self")
@@ -171,6 +212,7 @@ def _powellAhead(width):
                 if u1 is None or u1 != alpha:
                     return None
                 abscissae = [ugt, ule]                 # Brent's first step: its second, for either outcome
+                kind = "Brent's first step"
             else:
                 # a TOLERANCE step: the interpolated step was shorter than tol1 (or too close to an end of the interval), so
                 # SciPy evaluates x + tol1 or x - tol1 -- the search is closing in on x.  If the value there is no better
@@ -185,9 +227,12 @@ def _powellAhead(width):
                     abscissae = [x + tol1]
                 else:
                     return None
+                extra = _nextSearchAhead(site, brent, base, xi, x)
+                kind = "tolerance step"
         else:
             return None
-        return [base + a_ * xi for a_ in abscissae if a_ is not None][:width]
+        points = ([base + a_ * xi for a_ in abscissae if a_ is not None] + extra)[:width]
+        return (kind, points) if explain else points
     except (KeyError, AttributeError, ValueError, TypeError):
         return None
 

@@ -406,34 +406,42 @@ def test_powell_lookahead_serves_scipy_the_same_values_in_fewer_device_rounds(mo
 
 def test_powell_lookahead_abscissae_are_scipys():
     """The look-ahead recomputes SciPy's abscissae from SciPy's frames; pin them for the SciPy in this image: at f(1) of
-    a line search the third bracket point is always among the guesses, and most of the evaluations that follow a
-    recognised call site are too."""
-    from scipy.optimize import minimize
+    a line search the third bracket point is always among the guesses and most often the two evaluations after it too; at
+    Brent's first step the second is one of the two guesses; a tolerance step's second guess is f(1) of the NEXT search
+    whenever the search ends where the step said it would."""
+    import inspect
+    from scipy.optimize import minimize, _optimize
     from approxposterior_amd import gpUtils
     asked, guessed = [], []
 
     def g(p):        # same depth as _nll -> _powellAhead: objective -> helper
         asked.append(np.array(p))
-        pts = gpUtils._powellAhead(8)
-        if pts is not None:
-            guessed.append((len(asked) - 1, [np.array(q) for q in pts]))
+        got = gpUtils._powellAhead(8, explain=True)
+        if got is not None:
+            guessed.append((len(asked) - 1, got[0], [np.array(q) for q in got[1]]))
         return float(np.sum((p - np.array([0.3, -1.2, 0.8])) ** 2) + 0.1 * np.sum(p ** 4) + np.sin(3.0 * p[0]))
     minimize(g, np.array([2.0, 1.5, -0.7]), method="powell", options={"maxiter": 6})
-    starts = [(at, pts) for at, pts in guessed if len(pts) >= 4]         # f(1) of a line search: all eight cases
+
+    def among(a, pts):
+        return any(np.array_equal(a, q) for q in pts)
+    starts = [(at, pts) for at, kind, pts in guessed if kind == "f(1)"]
     assert len(starts) >= 6, "no line search was recognised: SciPy's Powell has changed shape -- see gpUtils._powellAhead"
-    third = two_more = 0
+    two_more = 0
     for at, pts in starts:
         assert len(pts) == 8
-        assert any(np.array_equal(asked[at + 1], q) for q in (pts[0], pts[3]))        # -1.618034 or 2.618034
-        third += 1
+        assert among(asked[at + 1], (pts[0], pts[3]))                     # -1.618034 or 2.618034
         nxt = asked[at + 2:at + 4]
-        if len(nxt) == 2 and all(any(np.array_equal(a, q) for q in pts) for a in nxt):
-            two_more += 1                                                  # the bracket closed: Brent's first two steps
+        two_more += int(len(nxt) == 2 and all(among(a, pts) for a in nxt))   # the bracket closed: Brent's first two steps
     assert two_more >= len(starts) // 2, (two_more, len(starts))
-    later = [(at, pts) for at, pts in guessed if len(pts) < 4]             # third bracket point / Brent's first step
-    for at, pts in later:
-        if at + 1 < len(asked) and len(pts) == 2:                          # Brent's first step: the second is one of the two
-            assert any(np.array_equal(asked[at + 1], q) for q in pts)
+    for at, kind, pts in guessed:
+        if kind == "Brent's first step" and at + 1 < len(asked):
+            assert len(pts) == 2 and among(asked[at + 1], pts)
+    tol = [(at, pts) for at, kind, pts in guessed if kind == "tolerance step"]
+    across = [(at, pts) for at, pts in tol if len(pts) == 5]             # ... + f(1), third point, two Brent steps of the next search
+    hits = sum(1 for at, pts in across if any(among(a, pts[1:2]) for a in asked[at + 1:at + 4]))
+    assert len(tol) >= 6 and len(across) >= 4 and hits >= len(across) // 2, (len(tol), len(across), hits)
+    # the constant the cross-search look-ahead hard-codes is the one SciPy's bracket uses
+    assert "_gold = %r" % gpUtils._GOLD in inspect.getsource(_optimize.bracket)
 
 
 def test_more_than_max_dim_dimensions_is_an_explicit_error():

@@ -10,6 +10,9 @@ if "--lib" in sys.argv:
     i = sys.argv.index("--lib"); _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1]); del sys.argv[i:i + 2]
 from approxposterior_amd import gpUtils
 from scipy.optimize import rosen, minimize
+WIDTHS = [0, None]
+if "--width" in sys.argv:
+    i = sys.argv.index("--width"); WIDTHS = [0] + [int(w) for w in sys.argv[i + 1].split(",")]; del sys.argv[i:i + 2]
 D = 8
 for N in [int(a) for a in sys.argv[1:]] or [512, 1152]:
     rs = np.random.RandomState(0)
@@ -21,7 +24,7 @@ for N in [int(a) for a in sys.argv[1:]] or [512, 1152]:
         cnt[0] += 1
         return gpUtils._nll(p, g, y)
     lib = _lib.load()
-    for ahead in (0, None):       # without / with the Powell look-ahead (gpUtils._powellAhead; width by size)
+    for ahead in WIDTHS:          # without / with the Powell look-ahead (gpUtils._powellAhead; width by size, or --width a,b,..)
         g.lookahead = ahead
         g._nllMemo = None
         minimize(f, p0, method="powell", options={"maxfev": 200})
