@@ -884,8 +884,9 @@ class GP(GeorgeExtras):
     # Powell look-ahead (gpUtils._powellAhead): how many points beyond the one asked for are worth evaluating in the same
     # device call -- where a small batch costs little more than one evaluation (apgp_nll_eval_batch: one launch with a
     # workgroup per matrix up to n = 128; the persistent factorisations side by side in one launch above that, each on
-    # 1 / batch of the CUs -- tools/nll_side_batch.py, profiles/r06c_*: 5 matrices 1.04 / 1.15 / 1.19 x one evaluation at
-    # n = 512 / 832 / 1152, 3 matrices 1.14 x at 1664, 2 matrices 1.13 x at 2048); 0 = off.
+    # 1 / batch of the CUs -- tools/nll_side_batch.py, profiles/r06c_*: 6 matrices 1.2 / 1.2 / 1.3 x one evaluation at
+    # n = 512 / 832 / 1152, 4 matrices 1.4 x at 1664, 2 matrices 1.13 x at 2048); widths measured inside SciPy's Powell
+    # (tools/nll_powell_rate.py --width 3,4,5; profiles/r06p_*): 5 is best up to n = 1152, 3 at 1600; 0 = off.
     lookahead = None              # None: by size; 0: off; k: that many points
 
     def lookahead_width(self):
@@ -894,7 +895,7 @@ class GP(GeorgeExtras):
         n = 0 if self._x is None else len(self._x)
         if n <= 0:
             return 0
-        return 5 if n <= 832 else (4 if n <= 1344 else (2 if n <= 1728 else (1 if n <= 2112 else 0)))
+        return 5 if n <= 1216 else (3 if n <= 1728 else (1 if n <= 2112 else 0))
 
     def _fast_structs(self, P, out):
         """The C ABI's kernel structs + means of the hyper-vectors ``P`` (B x len(self)) written straight into ``out``
