@@ -9,6 +9,11 @@ public names and argument meaning (``defaultHyperPrior`` :22-43, ``_nll`` :46-80
 ``george`` objects the reference builds are replaced by the HIP-backed ones of
 :py:mod:`approxposterior_amd.gp`; every objective evaluation SciPy requests is
 one Gram + Cholesky + solve on the GPU through the C ABI.
+
+Two things sit between SciPy and the device, neither of which changes a value SciPy sees: a memo of exact repeats
+(Powell re-asks f at the head of every line search) and, for ``method="powell"``, a look-ahead -- the points of a
+line search whose abscissae depend on no function value are evaluated together with the one asked for, side by side
+on the idle compute units, and answered from the memo when SciPy gets to them (:func:`_powellAhead`).
 """
 
 import sys
@@ -237,6 +242,47 @@ def _powellAhead(width, explain=False):
         return None
 
 
+def _nelderMeadAhead(width):
+    """The same idea for ``method="nelder-mead"`` (the reference's other derivative-free choice, gpUtils.py:233-236): within
+    one iteration of ``_minimize_neldermead`` the reflected point is followed by the expanded, the outside-contracted or
+    the inside-contracted point -- or by none -- depending on f(reflected), but all three are functions of the simplex
+    alone; so are the N + 1 vertices of the initial simplex and the N vertices of a shrink.  Recomputed with SciPy's own
+    expressions from its frame; unbounded searches only.  Returns up to ``width`` points or None."""
+    try:
+        fr = sys._getframe(2)                          # _nll's caller: SciPy's function wrapper <- _minimize_neldermead
+        for _ in range(4):
+            if fr is None or fr.f_code.co_name == "_minimize_neldermead":
+                break
+            fr = fr.f_back
+        if fr is None or fr.f_code.co_name != "_minimize_neldermead":
+            return None
+        loc = fr.f_locals
+        if loc.get("bounds") is not None:
+            return None
+        asked = sys._getframe(1).f_locals["p"]
+        sim = loc["sim"]
+        if "xbar" not in loc:
+            # the initial simplex: fsim[k] = func(sim[k]) for k = 0 .. N
+            k = loc.get("k")
+            if k is None or not np.array_equal(sim[k], asked):
+                return None
+            return [sim[j] for j in range(k + 1, min(len(sim), k + 1 + width))]
+        if np.array_equal(loc["xr"], asked) and not loc.get("doshrink"):
+            xbar, rho, chi, psi = loc["xbar"], loc["rho"], loc["chi"], loc["psi"]
+            worst = sim[-1]
+            if not np.array_equal((1 + rho) * xbar - rho * worst, asked):
+                return None                            # (a stale xr of an earlier iteration)
+            return [(1 + rho * chi) * xbar - rho * chi * worst,          # expansion
+                    (1 - psi) * xbar + psi * worst,                      # inside contraction
+                    (1 + psi * rho) * xbar - psi * rho * worst][:width]  # outside contraction
+        if loc.get("doshrink") and "j" in loc and np.array_equal(sim[loc["j"]], asked):
+            sigma, j = loc["sigma"], loc["j"]
+            return [sim[0] + sigma * (sim[m] - sim[0]) for m in range(j + 1, min(len(sim), j + 1 + width))]
+        return None
+    except (KeyError, AttributeError, ValueError, TypeError, IndexError):
+        return None
+
+
 def _nll(p, gp, y, priorFn=None):
     """Negative marginal log-likelihood at hyper-parameters ``p``; +inf where the
     prior forbids ``p`` or the Gram matrix is not positive definite
@@ -257,6 +303,8 @@ def _nll(p, gp, y, priorFn=None):
         width = gp.lookahead_width() if hasattr(gp, "lookahead_width") else 0
         if width > 0:
             ahead = _powellAhead(width)
+            if ahead is None:
+                ahead = _nelderMeadAhead(width)
             if ahead:
                 ahead = [q for q in ahead if priorFn is None or np.isfinite(priorFn(q))]
             if ahead:

@@ -398,12 +398,14 @@ def test_optimizegp_batched_restarts_equal_sequential():
     print("optimizeGP 4 restarts N=60: sequential %.2f s, batched %.2f s" % (out[False][1], out["always"][1]))
 
 
-@pytest.mark.parametrize("n,d,amp", [(90, 2, True), (400, 3, False), (1152, 8, False)])
-def test_powell_lookahead_same_optimum_fewer_device_rounds(n, d, amp):
+@pytest.mark.parametrize("n,d,amp,method", [(90, 2, True, "powell"), (400, 3, False, "powell"), (1152, 8, False, "powell"),
+                                            (90, 2, True, "nelder-mead"), (700, 4, False, "nelder-mead")])
+def test_powell_lookahead_same_optimum_fewer_device_rounds(n, d, amp, method):
     """gpUtils._nll's look-ahead (round 6): when SciPy's Powell asks for f(1) of a line search, the abscissae it asks for
     next ride along in ONE batched device call -- side-by-side persistent factorisations above n = 128, a workgroup per
     matrix below -- and SciPy sees the same values in the same order: the optimum of optimizeGP (gpUtils.py:184-257) is the
-    same in every bit with and without, in fewer device rounds."""
+    same in every bit with and without, in fewer device rounds.  The same for ``method="nelder-mead"`` (the points behind a
+    reflection, the initial simplex, a shrink: gpUtils._nelderMeadAhead)."""
     from approxposterior_amd import gpUtils, _lib
     lib = _lib.load()
     rs = np.random.RandomState(n)
@@ -425,7 +427,8 @@ def test_powell_lookahead_same_optimum_fewer_device_rounds(n, d, amp):
         try:
             before = lib.apgp_nll_side_batches()
             with np.errstate(all="ignore"):
-                gp = gpUtils.optimizeGP(gp, X, y, seed=1, nGPRestarts=1, method="powell", options={"maxiter": 3})
+                gp = gpUtils.optimizeGP(gp, X, y, seed=1, nGPRestarts=1, method=method,
+                                        options={"maxiter": 3} if method == "powell" else {"maxiter": 120, "adaptive": True})
             side = lib.apgp_nll_side_batches() - before
         finally:
             gpUtils._nll = inner

@@ -458,3 +458,36 @@ def test_more_than_max_dim_dimensions_is_an_explicit_error():
     np.random.seed(1)
     with pytest.raises(ValueError, match="APGP_MAX_DIM"):
         gpUtils.defaultGP(X, y)
+
+
+def test_nelder_mead_lookahead_serves_scipy_the_same_values_in_fewer_device_rounds(monkeypatch):
+    """The look-ahead for ``method="nelder-mead"`` (gpUtils._nelderMeadAhead): the initial simplex, the expanded / contracted
+    points behind a reflection and the vertices of a shrink are functions of the simplex alone -- they ride along; SciPy sees
+    the same points and values in the same order."""
+    from scipy.optimize import minimize, rosen
+    results = {}
+    for width in (0, 3, 5):
+        Stub, gpUtils, go = _lookahead_stub(width)
+        monkeypatch.setattr(gpUtils, "george", go)
+        rs = np.random.RandomState(5)
+        X = rs.uniform(-5, 5, size=(50, 3))
+        y = np.array([-rosen(x) / 100.0 for x in X])
+        gp = Stub(kernel=go.ExpSquaredKernel(np.fabs(rs.randn(3)) + 0.5, ndim=3), fit_mean=True, mean=np.median(y),
+                  white_noise=-12, fit_white_noise=False)
+        gp.compute(X)
+        seen = []
+
+        def fn(p, *args):
+            v = gpUtils._nll(p, *args)
+            seen.append((np.array(p).tobytes(), v))
+            return v
+        x0 = [np.median(y)] + list(rs.randn(3))
+        with np.errstate(all="ignore"):
+            res = minimize(fn, x0, args=(gp, y, gpUtils.defaultHyperPrior), method="nelder-mead",
+                           options={"maxiter": 60, "adaptive": True})
+        results[width] = (res["x"].tobytes(), res["nfev"], seen, Stub.rounds, Stub.batched)
+    base = results[0]
+    for width in (3, 5):
+        got = results[width]
+        assert got[0] == base[0] and got[1] == base[1] and got[2] == base[2]
+        assert got[4] > 0 and got[3] <= 0.8 * base[3], (got[3], base[3])
