@@ -918,17 +918,20 @@ class GP(GeorgeExtras):
         ints = out.view(np.int32)
         out[:] = 0.0
         ints[:, 0] = d
-        for b in range(len(P)):
-            q = P[b]
-            wn = float(q[at]) if self.fit_white_noise else self.white_noise.value
-            c = at + int(self.fit_white_noise)
-            if amp_dim:
-                out[b, 1] = float(amp_dim * np.exp(float(q[c])))
-                c += 1
-            else:
-                out[b, 1] = 1.0
-            out[b, 2] = float(self._yerr2) + float(np.exp(wn))
-            out[b, 3:3 + d] = np.exp(-np.array(q[c:c + d], dtype=np.float64))
+        c = at + int(self.fit_white_noise)
+        # (np.exp is an element-wise ufunc: the value of an element does not depend on the array it sits in, so these are
+        # the bits of _kernel_struct's scalar / length-d calls -- asserted by the look-ahead tests, which compare an
+        # optimiser's whole trajectory through this path with the one through single evaluations)
+        if self.fit_white_noise:
+            out[:, 2] = float(self._yerr2) + np.exp(np.ascontiguousarray(P[:, at]))      # (contiguous: the ufunc's SIMD loop)
+        else:
+            out[:, 2] = float(self._yerr2) + float(np.exp(self.white_noise.value))
+        if amp_dim:
+            out[:, 1] = amp_dim * np.exp(np.ascontiguousarray(P[:, c]))
+            c += 1
+        else:
+            out[:, 1] = 1.0
+        out[:, 3:3 + d] = np.exp(-P[:, c:c + d])
         return means
 
     def nll_batch(self, P, y):

@@ -110,6 +110,24 @@ def _brentAhead(brent, xa, xb, xc):
 _GOLD = 1.618034          # scipy.optimize._optimize.bracket's ``_gold`` (read from its frame where one is at hand; pinned by a test)
 
 
+_AHEAD_CACHE = {}
+
+
+def _firstAbscissae(brent, gold):
+    """The value-independent abscissae of a line search that brackets from (0, 1) -- third point, Brent's first step, its second
+    for either outcome; for the swapped bracket (f(0) < f(1)) and the unswapped one -- as functions of SciPy's constants
+    only: computed once per (gold, tol, _cg, _mintol)."""
+    key = (float(gold), float(brent.tol), float(brent._cg), float(brent._mintol))
+    got = _AHEAD_CACHE.get(key)
+    if got is None:
+        xa, xb = np.asarray([0.0, 1.0])
+        cB, cA = xa + gold * (xa - xb), xb + gold * (xb - xa)
+        got = _AHEAD_CACHE[key] = (xb, cB, _brentAhead(brent, xb, xa, cB), cA, _brentAhead(brent, xa, xb, cA))
+        if len(_AHEAD_CACHE) > 64:
+            _AHEAD_CACHE.pop(next(iter(_AHEAD_CACHE)))
+    return got
+
+
 def _nextSearchAhead(site, brent, base, xi, x):
     """The first points of the NEXT line search of ``_minimize_powell``, assuming the current one ends at Brent's current
     best abscissa ``x`` -- which is what a tolerance step x +- tol1 announces (nine line searches in ten end with one, and
@@ -136,9 +154,7 @@ def _nextSearchAhead(site, brent, base, xi, x):
     nxt = direc[i + 1]
     if not np.any(nxt):
         return []
-    xa, xb = np.asarray([0.0, 1.0])
-    cB = xa + _GOLD * (xa - xb)
-    uB = _brentAhead(brent, xb, xa, cB)
+    xb, cB, uB, _, _ = _firstAbscissae(brent, _GOLD)
     return [new + a_ * nxt for a_ in (xb, cB, uB[0], uB[1]) if a_ is not None]
 
 
@@ -193,10 +209,11 @@ def _powellAhead(width, explain=False):
                 if gold != _GOLD:
                     return None                        # (another SciPy: _nextSearchAhead's constant would be wrong too)
                 # f(0) < f(1): SciPy swaps (xa, xb) and goes on to -1.618034 -- that case first; else no swap, 2.618034
-                cB, cA = xa + gold * (xa - xb), xb + gold * (xb - xa)
-                uB = uA = (None, None, None)
-                if brent is not None and width > 1:
-                    uB, uA = _brentAhead(brent, xb, xa, cB), _brentAhead(brent, xa, xb, cA)
+                if brent is not None:
+                    _, cB, uB, cA, uA = _firstAbscissae(brent, gold)
+                else:
+                    cB, cA = xa + gold * (xa - xb), xb + gold * (xb - xa)
+                    uB = uA = (None, None, None)
                 abscissae = [cB, uB[0], uB[1], cA, uA[0], uB[2], uA[1], uA[2]]
                 kind = "f(1)"
             else:
@@ -305,8 +322,13 @@ def _nll(p, gp, y, priorFn=None):
             ahead = _powellAhead(width)
             if ahead is None:
                 ahead = _nelderMeadAhead(width)
-            if ahead:
-                ahead = [q for q in ahead if priorFn is None or np.isfinite(priorFn(q))]
+            if ahead and priorFn is not None:
+                if priorFn is defaultHyperPrior:                       # (its own expression, on all guesses at once)
+                    keep = ~(np.fabs(np.array(ahead))[:, 1:] > 20).any(axis=1)
+                    if not keep.all():
+                        ahead = [q for q, k in zip(ahead, keep) if k]
+                else:
+                    ahead = [q for q in ahead if np.isfinite(priorFn(q))]
             if ahead:
                 vals = gp.nll_batch(np.array([p] + ahead), y)      # entry b: what _nll(P[b]) returns, bit for bit
                 for q, v in zip(ahead, vals[1:]):
