@@ -179,7 +179,7 @@ def _powellAhead(width, explain=False):
     costs idle-CU work only: a point that is never asked for is never used.
 
     Returns up to ``width`` points (most likely first), or None; with ``explain`` (tests) ``(call site, points)``, the call
-    site one of "f(1)", "third bracket point", "Brent's first step", "tolerance step", "interpolated step"."""
+    site one of "f(1)", "third bracket point", "Brent's first step", "tolerance step"."""
     try:
         line = sys._getframe(2)                        # _nll's caller: SciPy's function wrapper <- myfunc(alpha)
         for _ in range(4):                             # (a caller's own thin wrapper around _nll may sit in between)
@@ -247,17 +247,10 @@ def _powellAhead(width, explain=False):
                     abscissae = [x - tol1]
                 elif u == x - tol1:
                     abscissae = [x + tol1]
-                elif ol.get("iter", 0) >= 2:
-                    # an interpolated step: if its value is the best so far, x moves to u, and near the end of a search the
-                    # next step is then -- one time in three -- a tolerance step around u, to either side
-                    tu = brent.tol * np.abs(u) + brent._mintol
-                    abscissae = [u + tu, u - tu]
-                    kind = "interpolated step"
                 else:
                     return None
-                if kind is None:
-                    extra = _nextSearchAhead(site, brent, base, xi, x)
-                    kind = "tolerance step"
+                extra = _nextSearchAhead(site, brent, base, xi, x)
+                kind = "tolerance step"
         else:
             return None
         points = ([base + a_ * xi for a_ in abscissae if a_ is not None] + extra)[:width]
@@ -321,25 +314,10 @@ def _nll(p, gp, y, priorFn=None):
     if table is not None:
         key = _memoKey(p, gp)      # (after set_parameter_vector: a fitted mean / white noise is part of p)
         hit = table.get(key)
-        width = gp.lookahead_width() if hasattr(gp, "lookahead_width") else 0
         if hit is not None:
             table.move_to_end(key)
-            if width > 1:
-                # a guessed tolerance step: the search is about to end -- what a MISS here would have fetched (its mirror
-                # image, the next search's first points) is worth a device round of its own
-                got = _powellAhead(width, explain=True)
-                if got is not None and got[0] == "tolerance step":
-                    fresh = [q for q in got[1] if _memoKey(q, gp) not in table]
-                    if priorFn is not None:
-                        fresh = [q for q in fresh if np.isfinite(priorFn(q))]
-                    if len(fresh) > 1:
-                        vals = gp.nll_batch(np.array(fresh), y)
-                        for q, v in zip(fresh, vals):
-                            table[_memoKey(q, gp)] = float(v)
-                        while len(table) > _MEMO_SIZE:
-                            table.popitem(last=False)
-                        gp.set_parameter_vector(p)
             return hit
+        width = gp.lookahead_width() if hasattr(gp, "lookahead_width") else 0
         if width > 0:
             ahead = _powellAhead(width)
             if ahead is None:
