@@ -221,6 +221,59 @@ def test_backoff_after_a_contended_persistent_launch():
         assert skipped >= 64 and gave_up <= 4
 
 
+@pytest.mark.parametrize("n,D,B", [(300, 3, 4), (1152, 8, 5), (1152, 8, 6), (1700, 4, 3), (2048, 8, 2), (3100, 2, 2)])
+def test_side_by_side_batch_against_lapack_and_oracle(n, D, B):
+    """``apgp_nll_eval_batch`` on its side-by-side path (round 6: ``potrf_persist_batch_kernel``, gridDim.y = B) DIRECTLY
+    against LAPACK and the oracle -- not only against the single-evaluation HIP path it shares its code with: every
+    matrix's factor against ``scipy.linalg.cholesky`` of the oracle's Gram matrix at THAT matrix's hyper-parameters, z
+    against ``solve_triangular``, log-determinant / z.z to 1e-11, and ``GP.nll_batch`` against the oracle's log-likelihood."""
+    import torch
+    from scipy.linalg import cholesky, solve_triangular
+    from approxposterior_amd import _lib
+    go, agp = _mods()
+    lib = _lib.load()
+    X, y = _case(n, D, n + B)
+    rs = np.random.RandomState(B * n)
+    metrics = [np.exp(rs.uniform(np.log(4.0), np.log(12.0), size=D)) for _ in range(B)]
+    means = np.array([float(np.median(y)) + 0.1 * b for b in range(B)])
+    karr = (_lib.KernelStruct * B)()
+    for b in range(B):
+        g = agp.GP(kernel=agp.ExpSquaredKernel(metrics[b], ndim=D), fit_mean=True, mean=means[b], white_noise=-12,
+                   fit_white_noise=False)
+        g._x = X; g._yerr2 = 0.0
+        karr[b] = g._kernel_struct()
+    X_d, y_d = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    K = torch.zeros((B, n, n), dtype=torch.float64, device="cuda")
+    z = torch.empty((B, n), dtype=torch.float64, device="cuda")
+    info = torch.empty(B, dtype=torch.int32, device="cuda")
+    o5 = torch.empty((B, 5), dtype=torch.float64, device="cuda")
+    o = np.empty((B, 5))
+    lib.apgp_potrf_mode(0)
+    sb, fb = lib.apgp_nll_side_batches(), lib.apgp_potrf_fallbacks()
+    rc = lib.apgp_nll_eval_batch(X_d.data_ptr(), n, B, ctypes.addressof(karr), y_d.data_ptr(), means.ctypes.data, K.data_ptr(),
+                                 z.data_ptr(), info.data_ptr(), o5.data_ptr(), o.ctypes.data, None)
+    assert rc == 0, lib.apgp_last_error()
+    torch.cuda.synchronize()
+    assert lib.apgp_nll_side_batches() == sb + 1 and lib.apgp_potrf_fallbacks() == fb      # served side by side, nobody gave up
+    for b in range(B):
+        ko = go.ExpSquaredKernel(metrics[b], ndim=D)
+        Ko = ko.get_value(X)
+        Ko[np.diag_indices(n)] += np.exp(-12.0)
+        Lo = cholesky(Ko, lower=True)
+        zo = solve_triangular(Lo, y - means[b], lower=True)
+        Lh, zh = torch.tril(K[b]).cpu().numpy(), z[b].cpu().numpy()
+        assert int(info[b].item()) == 0 and o[b, 4] == 0.0
+        assert np.abs(Lh - Lo).max() <= 1e-11 * np.abs(Lo).max()
+        assert np.abs(zh - zo).max() <= 1e-9 * np.abs(zo).max()
+        logdet = 2.0 * np.sum(np.log(np.diag(Lo)))
+        assert abs(o[b, 0] - logdet) <= 1e-11 * abs(logdet)
+        assert abs(o[b, 3] - zo @ zo) <= 1e-11 * (zo @ zo)
+        gpo = go.GP(kernel=ko, fit_mean=True, mean=means[b], white_noise=-12, fit_white_noise=False)
+        gpo.compute(X)
+        ll = -0.5 * (n * np.log(2.0 * np.pi) + o[b, 0]) - 0.5 * o[b, 3]
+        assert abs(ll - gpo.log_likelihood(y)) <= 1e-11 * abs(gpo.log_likelihood(y))
+
+
 def test_side_by_side_batch_under_contention_equals_single_evaluations():
     """Round 6: ``apgp_nll_eval_batch`` runs 2 .. 6 persistent factorisations side by side in one launch; when foreign
     kernels hold most compute units its workgroups cannot all be resident, a matrix gives up, and the whole batch is
