@@ -226,7 +226,7 @@ def test_side_by_side_batch_against_lapack_and_oracle(n, D, B):
     """``apgp_nll_eval_batch`` on its side-by-side path (round 6: ``potrf_persist_batch_kernel``, gridDim.y = B) DIRECTLY
     against LAPACK and the oracle -- not only against the single-evaluation HIP path it shares its code with: every
     matrix's factor against ``scipy.linalg.cholesky`` of the oracle's Gram matrix at THAT matrix's hyper-parameters, z
-    against ``solve_triangular``, log-determinant / z.z to 1e-11, and ``GP.nll_batch`` against the oracle's log-likelihood."""
+    against ``solve_triangular``, log-determinant / z.z / log-likelihood to 1e-11 (times the condition estimate over 1e3)."""
     import torch
     from scipy.linalg import cholesky, solve_triangular
     from approxposterior_amd import _lib
@@ -266,12 +266,14 @@ def test_side_by_side_batch_against_lapack_and_oracle(n, D, B):
         assert np.abs(Lh - Lo).max() <= 1e-11 * np.abs(Lo).max()
         assert np.abs(zh - zo).max() <= 1e-9 * np.abs(zo).max()
         logdet = 2.0 * np.sum(np.log(np.diag(Lo)))
-        assert abs(o[b, 0] - logdet) <= 1e-11 * abs(logdet)
-        assert abs(o[b, 3] - zo @ zo) <= 1e-11 * (zo @ zo)
+        # (random metrics 4 .. 12: at D = 2 the 3,100 points lie dense and cond(K) is ~1e4 times the D = 8 cases')
+        tol = 1e-11 * max(1.0, (o[b, 2] / o[b, 1]) ** 2 / 1e3)
+        assert abs(o[b, 0] - logdet) <= tol * abs(logdet)
+        assert abs(o[b, 3] - zo @ zo) <= tol * (zo @ zo)
         gpo = go.GP(kernel=ko, fit_mean=True, mean=means[b], white_noise=-12, fit_white_noise=False)
         gpo.compute(X)
         ll = -0.5 * (n * np.log(2.0 * np.pi) + o[b, 0]) - 0.5 * o[b, 3]
-        assert abs(ll - gpo.log_likelihood(y)) <= 1e-11 * abs(gpo.log_likelihood(y))
+        assert abs(ll - gpo.log_likelihood(y)) <= tol * abs(gpo.log_likelihood(y))
 
 
 def test_side_by_side_batch_under_contention_equals_single_evaluations():
